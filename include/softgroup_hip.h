@@ -1,0 +1,260 @@
+/*
+ * softgroup_hip.h -- C ABI of libsoftgroup_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the SoftGroup hot path: plain pointers and sizes, no
+ * torch/ATen types.  Each entry point replaces one symbol the reference binds
+ * through pybind (softgroup/ops/src/softgroup_api.cpp:8-28) or one piece of the
+ * un-vendored spconv 2.1 library the reference model calls
+ * (softgroup/model/softgroup.py:60-62, softgroup/model/blocks.py:31-119).
+ * The replaced reference interface is cited at every declaration (paths relative
+ * to the reference repository root).
+ *
+ * Conventions
+ *   - all `const T* x` / `T* x` arguments are DEVICE pointers unless the name ends in
+ *     `_host` or the function name contains `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     kernel is launched on it, nothing synchronises unless documented;
+ *   - no function allocates device memory: scratch comes from the caller through
+ *     (`ws`, `ws_bytes`) sized by the matching `*_workspace_bytes` query;
+ *   - return value: SG_OK (0) or a negative SG_ERR_* code; sg_last_error() gives text;
+ *   - functions whose output size is data dependent are split into a sizing pass
+ *     that writes small int32 "meta" scalars to device memory (the caller reads them
+ *     back) and a fill pass.
+ */
+#ifndef SOFTGROUP_HIP_H
+#define SOFTGROUP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sg_stream_t;
+
+#define SG_OK 0
+#define SG_ERR_ARG (-1)
+#define SG_ERR_WORKSPACE (-2)
+#define SG_ERR_LAUNCH (-3)
+#define SG_ERR_UNSUPPORTED (-4)
+
+#define SG_BALLQUERY_MAX_NEIGHBORS 1000 /* bfs_cluster.cu:24 `int idx_temp[1000]` */
+#define SG_OCTREE_NUM_NODES 585         /* octree_ball_query.cu:10 */
+#define SG_OCTREE_NUM_LEAVES 512        /* octree_ball_query.cu:11 */
+
+int sg_version(void);
+const char *sg_last_error(void);
+/* name/CU count/clock of the current device, for bench records */
+int sg_device_info(char *name_host, int name_cap, int *num_cu_host, int *clock_khz_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelisation index build.  Replaces `voxelize_idx` (softgroup_api.cpp:12,
+ * voxelize/voxelize.cpp:11-165; Python: ops/functions.py:168-197).
+ * coords: int64 [n, ncol], ncol = 3 or 4 (column 0 = batch index when 4).
+ * Voxel id = first-seen order; rule row = [count, ascending point idx..., 0 pad].
+ * mode: 4 mean / 3 sum (same indices); 0,1 keep first point, 2 keeps last (voxelize.cpp:127-149).
+ * ---------------------------------------------------------------------------------------- */
+/* Host (CPU) variant -- what the reference runs inside DataLoader workers (data/custom.py:239).
+ * Pass 1 fills input_map[n], returns M and maxActive; pass 2 fills the two outputs. */
+int sg_voxelize_idx_host(const int64_t *coords_host, int n, int ncol, int mode,
+                         int32_t *input_map_host, int32_t *num_voxels_host,
+                         int32_t *max_active_host);
+int sg_voxelize_idx_fill_host(const int64_t *coords_host, int n, int ncol, int mode,
+                              const int32_t *input_map_host, int num_voxels, int max_active,
+                              int64_t *out_coords_host, int32_t *out_map_host);
+/* Device variant (used in-model: softgroup.py:494,703).  meta[0]=M, meta[1]=maxActive.
+ * `fill` must get the same ws buffer, untouched since `build`. */
+size_t sg_voxelize_idx_workspace_bytes(int n);
+int sg_voxelize_idx_build(const int64_t *coords, int n, int ncol, int mode, int32_t *input_map,
+                          int32_t *meta, void *ws, size_t ws_bytes, sg_stream_t stream);
+int sg_voxelize_idx_fill(const int64_t *coords, int n, int ncol, int mode,
+                         const int32_t *input_map, int num_voxels, int max_active,
+                         int64_t *out_coords, int32_t *out_map, void *ws, size_t ws_bytes,
+                         sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxel feature pooling.  Replaces `voxelize_fp` / `voxelize_bp` (softgroup_api.cpp:13-14,
+ * voxelize/voxelize.cu:10-62; Python ops/functions.py:200-234).
+ * out[row,:] = sum_{i=1..rules[row,0]} m * feats[rules[row,i],:], m = 1/count if average.
+ * Bit-exact with the reference: sequential order, separate multiply and add.
+ * ---------------------------------------------------------------------------------------- */
+int sg_voxelize_fp(const float *feats, const int32_t *rules, int num_voxels, int max_active,
+                   int channels, int average, float *out, sg_stream_t stream);
+/* d_feats must be pre-zeroed by the caller (functions.py:228) */
+int sg_voxelize_bp(const float *d_out, const int32_t *rules, int num_voxels, int max_active,
+                   int channels, int average, float *d_feats, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ball query.  Replaces `ballquery_batch_p` (softgroup_api.cpp:19, bfs_cluster/bfs_cluster.cpp:17-31,
+ * bfs_cluster.cu:15-101; Python ops/functions.py:237-275).
+ * Per point: ascending list of the (at most 1000 smallest) indices k of the same batch with
+ * d2(k) < radius^2 (strict), self included.  Two passes give a deterministic CSR:
+ *   count : start_len[i,1] = min(cnt,1000); meta[0] = total (int32, saturates at INT32_MAX)
+ *   (caller exclusive-scans start_len[:,1] into start_len[:,0] -- sg_exclusive_scan_startlen)
+ *   fill  : idx[start .. start+len) = neighbours.
+ * The reference's `nActive > n*meanActive` retry protocol (functions.py:258-266) is kept in
+ * the Python facade; the kernels never truncate.
+ * ---------------------------------------------------------------------------------------- */
+size_t sg_ballquery_workspace_bytes(int n);
+int sg_ballquery_build_grid(const float *xyz, const int32_t *batch_idxs, int n, float radius,
+                            void *ws, size_t ws_bytes, sg_stream_t stream);
+int sg_ballquery_count(const float *xyz, const int32_t *batch_idxs, int n, float radius,
+                       int32_t *start_len, int32_t *meta, void *ws, size_t ws_bytes,
+                       sg_stream_t stream);
+int sg_ballquery_fill(const float *xyz, const int32_t *batch_idxs, int n, float radius,
+                      const int32_t *start_len, int32_t *idx, void *ws, size_t ws_bytes,
+                      sg_stream_t stream);
+/* start_len[i,0] = sum_{j<i} start_len[j,1]; meta[0] = total.  ws >= sg_scan_workspace_bytes(n) */
+size_t sg_scan_workspace_bytes(int n);
+int sg_exclusive_scan_startlen(int32_t *start_len, int n, int32_t *meta, void *ws,
+                               size_t ws_bytes, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Octree ball query (SoftGroup++).  Replaces `build_and_export_octree` + `octree_ball_query`
+ * (softgroup_api.cpp:16-18, octree_ball_query/octree_ball_query.cpp:8-188, .cu:14-147;
+ * Python ops/functions.py:14-44).  Fixed 3 levels / 585 nodes / 512 leaves.
+ * Neighbour order = leaf export order, then within-leaf order; capped at the first 1000.
+ * ---------------------------------------------------------------------------------------- */
+int sg_octree_build_host(const float *points_host, const float *xyzwhl_host, int num_points,
+                         int num_levels, float *boxes_host, int32_t *pt_inds_host,
+                         int32_t *pt_start_len_host);
+int sg_octree_ballquery_count(const float *points, const float *boxes, const int32_t *pt_inds,
+                              const int32_t *pt_start_len, int n, float radius,
+                              int32_t *start_len, sg_stream_t stream);
+int sg_octree_ballquery_fill(const float *points, const float *boxes, const int32_t *pt_inds,
+                             const int32_t *pt_start_len, int n, float radius,
+                             const int32_t *start_len, int32_t *idx, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BFS clustering (soft grouping).  Replaces `bfs_cluster` (softgroup_api.cpp:20,
+ * bfs_cluster/bfs_cluster.cpp:33-126; Python ops/functions.py:278-308) -- CPU single thread in
+ * the reference, wavefront-parallel here.  Output identical to the sequential algorithm:
+ * seeds ascending, members in FIFO-BFS order, clusters with (float)size >= thr kept, where
+ * thr = threshold if class_numpoint_mean == -1 else threshold * class_numpoint_mean.
+ * `seg_thr[n_seg]` generalises the single (class_id) call to many classes per launch: point i
+ * belongs to segment seg_of_point[i] (NULL = all segment 0) and thr = seg_thr[segment].
+ *   label : min-ancestor labelling (directed reachability), sizes, kept clusters
+ *   emit  : cluster_idxs int32 [sumNPoint,2] = (cluster_id, point_idx), cluster_offsets [nCluster+1]
+ * ---------------------------------------------------------------------------------------- */
+size_t sg_bfs_workspace_bytes(int n, int64_t n_edges);
+/* lists_sorted: 1 when every neighbour list is ascending (ball query), 0 otherwise (octree).
+ * SYNCHRONISES `stream`: the number of kept clusters sizes the outputs, so it is returned to
+ * host memory (*n_cluster_host, *sum_npoint_host). */
+int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n,
+                         int64_t n_edges, int lists_sorted, const int32_t *seg_of_point,
+                         const float *seg_thr, int n_seg, int32_t *n_cluster_host,
+                         int32_t *sum_npoint_host, void *ws, size_t ws_bytes, sg_stream_t stream);
+/* same ws buffer, untouched since sg_bfs_cluster_label */
+int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
+                        const int32_t *seg_of_point, const float *seg_thr, int n_cluster,
+                        int sum_npoint, int32_t *cluster_idxs, int32_t *cluster_offsets, void *ws,
+                        size_t ws_bytes, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Segment reductions.  Replace `sec_mean` / `sec_min` / `sec_max` (softgroup_api.cpp:25-27,
+ * sec_mean/sec_mean.cu:13-93; Python ops/functions.py:351-438) and `global_avg_pool_fp/bp`
+ * (softgroup_api.cpp:22-23, roipool/roipool.cu:12-71; Python ops/functions.py:311-348).
+ * inp float32 [S, C], offsets int32 [nP+1] -> out float32 [nP, C].
+ * ---------------------------------------------------------------------------------------- */
+int sg_sec_mean(const float *inp, const int32_t *offsets, int n_seg, int channels, float *out,
+                sg_stream_t stream);
+int sg_sec_min(const float *inp, const int32_t *offsets, int n_seg, int channels, float *out,
+               sg_stream_t stream);
+int sg_sec_max(const float *inp, const int32_t *offsets, int n_seg, int channels, float *out,
+               sg_stream_t stream);
+int sg_global_avg_pool_fp(const float *feats, const int32_t *offsets, int n_seg, int channels,
+                          float *out, sg_stream_t stream);
+/* d_feats[i,:] += d_out[p,:] / n_p  (d_feats pre-zeroed by the caller, functions.py:341) */
+int sg_global_avg_pool_bp(float *d_feats, const int32_t *offsets, const float *d_out, int n_seg,
+                          int channels, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Proposal/GT mask IoU and mask targets (training).  Replace `get_mask_iou_on_cluster`,
+ * `get_mask_iou_on_pred`, `get_mask_label` (softgroup_api.cpp:8-10,
+ * cal_iou_and_masklabel/cal_iou_and_masklabel.cu:9-164; Python ops/functions.py:47-165).
+ * O(S) per-proposal label histogram in LDS instead of the reference's O(nP*nI*|P|);
+ * the IoU quotient is evaluated in double and rounded to float like the reference.
+ * ---------------------------------------------------------------------------------------- */
+int sg_get_mask_iou_on_cluster(const int32_t *proposals_idx, const int32_t *proposals_offset,
+                               const int64_t *instance_labels, const int32_t *instance_pointnum,
+                               int n_instance, int n_proposal, float *proposals_iou,
+                               sg_stream_t stream);
+int sg_get_mask_iou_on_pred(const int32_t *proposals_idx, const int32_t *proposals_offset,
+                            const int64_t *instance_labels, const int32_t *instance_pointnum,
+                            const float *mask_scores_sigmoid, int n_instance, int n_proposal,
+                            float *proposals_iou, sg_stream_t stream);
+/* mask_label pre-filled with -1 by the caller (functions.py:147) */
+int sg_get_mask_label(const int32_t *proposals_idx, const int32_t *proposals_offset,
+                      const int64_t *instance_labels, const int64_t *instance_cls,
+                      const float *proposals_iou, int n_instance, int n_proposal, float iou_thr,
+                      float *mask_label, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution (the spconv.pytorch subset of SURVEY.md 2.4).
+ * indices int32 [M,4] = (batch, d0, d1, d2); spatial_shape int32[3] on the host.
+ *
+ * Rulebooks ("gather tables", output-stationary): nbr[j*K + k] = input row feeding output row
+ * j through kernel offset k, or -1.
+ *   SubM k3 p1 (SubMConv3d, softgroup.py:61-62, blocks.py:57-70): K=27, k=(dx+1)*9+(dy+1)*3+(dz+1)
+ *   strided k2 s2 (SparseConv3d, blocks.py:101-107): output coords = c//2 in first-seen order,
+ *       inputs with c//2 >= shape//2 dropped; K=8, k=(c0&1)*4+(c1&1)*2+(c2&1)
+ *   inverse k2 (SparseInverseConv3d, blocks.py:114-119): K=8, one entry per row
+ *       (k = parity of the fine coordinate, value = parent row) -- built from the saved pair.
+ * ---------------------------------------------------------------------------------------- */
+size_t sg_spconv_hash_workspace_bytes(int num_rows);
+/* builds the coordinate hash in ws, then fills nbr[M,27] */
+int sg_spconv_subm_rulebook(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
+                            int32_t *nbr, void *ws, size_t ws_bytes, sg_stream_t stream);
+/* pass 1: in2out[M] (-1 = dropped), meta[0] = M_out.  pass 2: out_indices[M_out,4], child[M_out,8] */
+int sg_spconv_down_build(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
+                         int32_t *in2out, int32_t *meta, void *ws, size_t ws_bytes,
+                         sg_stream_t stream);
+int sg_spconv_down_fill(const int32_t *indices, int num_rows, const int32_t *in2out,
+                        int num_out_rows, int32_t *out_indices, int32_t *child, void *ws,
+                        size_t ws_bytes, sg_stream_t stream);
+/* inv_nbr[M,8] from (fine indices, in2out) */
+int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2out, int num_rows,
+                               int32_t *inv_nbr, sg_stream_t stream);
+
+/* Tile plan for the implicit-GEMM kernel: rows are processed in mask-sorted order so that a
+ * 32-row MFMA tile only visits kernel offsets some row of the tile really has.
+ *   order[M_out]      : permutation (row ids sorted by their K-bit neighbour mask)
+ *   tile_mask[ceil(M_out/32)] : OR of the masks of the tile's rows
+ * Row order behind the API is untouched: tile t computes rows order[32t .. 32t+31] and stores
+ * them back at their own row index. */
+size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
+int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
+                   uint32_t *tile_mask, void *ws, size_t ws_bytes, sg_stream_t stream);
+
+/* weight re-layout [Cout, K, Cin] (spconv "OKKKI", tools/convert_checkpoint.py:17-19) -> [K, Cin, Cout] */
+int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, float *w_kio,
+                            sg_stream_t stream);
+
+/* out[j,:] = (residual ? residual[j,:] : 0) + sum_k W[k] . act(in[nbr[j,k],:])
+ *   act(x) = relu(x * bn_scale + bn_shift) when bn_scale != NULL (fused eval-mode BatchNorm1d +
+ *   ReLU that precede every conv in blocks.py:57-70,99-119), identity otherwise.
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 32 == 0 for the MFMA
+ * path; other shapes take the scalar path of the same kernel family. order/tile_mask from
+ * sg_spconv_plan (NULL = natural order, all offsets). */
+int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr,
+                              int num_out_rows, int kvol, int cin, int cout, const float *w_kio,
+                              const float *bn_scale, const float *bn_shift,
+                              const float *residual, const int32_t *order,
+                              const uint32_t *tile_mask, float *out, sg_stream_t stream);
+
+/* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):
+ * out = relu(x*scale + shift) (relu optional). */
+int sg_bn_relu_f32(const float *x, const float *scale, const float *shift, int64_t num_rows,
+                   int channels, int relu, float *out, sg_stream_t stream);
+
+/* Row gather: out[i,:] = in[index[i],:]  (devoxelize, softgroup.py:374; feats[c_idxs], :677) */
+int sg_gather_rows_f32(const float *in, const int32_t *index, int64_t num_out_rows, int channels,
+                       float *out, sg_stream_t stream);
+int sg_gather_rows_i64idx_f32(const float *in, const int64_t *index, int64_t num_out_rows,
+                              int channels, float *out, sg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTGROUP_HIP_H */

@@ -1,0 +1,163 @@
+// host_ops.cpp -- the two operators the reference itself runs on the CPU and that callers use
+// without a GPU context (DataLoader worker processes): voxel index build and octree export.
+// Native C++ (no torch, no HIP); the device variants live in voxelize_idx.hip / octree.hip.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/softgroup_hip.h"
+
+namespace sg {
+void set_error(const char *fmt, ...);
+}
+
+namespace {
+
+struct CellKey {
+  int32_t b, x, y, z;
+  bool operator==(const CellKey &o) const { return b == o.b && x == o.x && y == o.y && z == o.z; }
+};
+
+inline uint64_t hash_key(const CellKey &k) {
+  uint64_t h = (static_cast<uint64_t>(static_cast<uint32_t>(k.b)) << 32) ^ static_cast<uint32_t>(k.x);
+  h *= 0x9E3779B97F4A7C15ULL;
+  h ^= (static_cast<uint64_t>(static_cast<uint32_t>(k.y)) << 32) | static_cast<uint32_t>(k.z);
+  h ^= h >> 31;
+  h *= 0xD6E8FEB86659FD93ULL;
+  return h ^ (h >> 32);
+}
+
+inline CellKey load_key(const int64_t *row, int ncol) {
+  // coordinates are narrowed to int32 like the reference (voxelize.cpp:86-102)
+  if (ncol == 3) return {0, static_cast<int32_t>(row[0]), static_cast<int32_t>(row[1]), static_cast<int32_t>(row[2])};
+  return {static_cast<int32_t>(row[0]), static_cast<int32_t>(row[1]), static_cast<int32_t>(row[2]),
+          static_cast<int32_t>(row[3])};
+}
+
+}  // namespace
+
+extern "C" {
+
+// voxel id = order of first appearance; reference: voxelize/voxelize.cpp:70-163
+int sg_voxelize_idx_host(const int64_t *coords, int n, int ncol, int mode, int32_t *input_map,
+                         int32_t *num_voxels, int32_t *max_active) {
+  if (n < 0 || (ncol != 3 && ncol != 4) || mode < 0 || mode > 4) {
+    sg::set_error("sg_voxelize_idx_host: bad arguments (n=%d ncol=%d mode=%d)", n, ncol, mode);
+    return SG_ERR_ARG;
+  }
+  size_t cap = 64;
+  while (cap < static_cast<size_t>(n) * 2) cap <<= 1;
+  struct Slot { int32_t first; int32_t voxel; };
+  std::vector<Slot> table(cap, Slot{-1, -1});
+  std::vector<int32_t> counts;
+  counts.reserve(static_cast<size_t>(n) / 2 + 1);
+  for (int i = 0; i < n; ++i) {
+    const CellKey k = load_key(coords + static_cast<size_t>(i) * ncol, ncol);
+    size_t s = hash_key(k) & (cap - 1);
+    while (true) {
+      Slot &sl = table[s];
+      if (sl.first < 0) {
+        sl.first = i;
+        sl.voxel = static_cast<int32_t>(counts.size());
+        counts.push_back(0);
+      } else if (!(load_key(coords + static_cast<size_t>(sl.first) * ncol, ncol) == k)) {
+        s = (s + 1) & (cap - 1);
+        continue;
+      }
+      input_map[i] = sl.voxel;
+      ++counts[sl.voxel];
+      break;
+    }
+  }
+  int32_t ma = 1;
+  if (mode == 3 || mode == 4)
+    for (int32_t c : counts) ma = std::max(ma, c);
+  *num_voxels = static_cast<int32_t>(counts.size());
+  *max_active = ma;
+  return SG_OK;
+}
+
+int sg_voxelize_idx_fill_host(const int64_t *coords, int n, int ncol, int mode,
+                              const int32_t *input_map, int num_voxels, int max_active,
+                              int64_t *out_coords, int32_t *out_map) {
+  if (n < 0 || num_voxels < 0 || max_active < 1 || (ncol != 3 && ncol != 4)) {
+    sg::set_error("sg_voxelize_idx_fill_host: bad arguments");
+    return SG_ERR_ARG;
+  }
+  const size_t stride = static_cast<size_t>(max_active) + 1;
+  std::fill(out_map, out_map + static_cast<size_t>(num_voxels) * stride, 0);
+  const bool pooled = (mode == 3 || mode == 4);
+  for (int i = 0; i < n; ++i) {
+    int32_t *row = out_map + static_cast<size_t>(input_map[i]) * stride;
+    if (pooled) {
+      row[1 + row[0]] = i;  // points arrive in ascending index order
+      ++row[0];
+    } else if (row[0] == 0 || mode == 2) {  // modes 0/1 keep the first point, 2 the last
+      row[0] = 1;
+      row[1] = i;
+    }
+  }
+  for (int v = 0; v < num_voxels; ++v)
+    std::memcpy(out_coords + static_cast<size_t>(v) * ncol,
+                coords + static_cast<size_t>(out_map[v * stride + 1]) * ncol, sizeof(int64_t) * ncol);
+  return SG_OK;
+}
+
+// Octree export without building a pointer tree.  Reference: octree_ball_query.cpp:8-165.
+// The tree is complete, so node `path` at level L sits at BFS slot first[L] + path where
+// path = base-8 digits (octant per level) and the box of a child follows from its parent's
+// with the reference's float expressions (cpp:60-82).  A point's leaf is found by walking the
+// boxes with the reference's `<` tests (cpp:52-57); leaves hold their points in ascending
+// index order because every level of the reference splits an ascending list in order.
+int sg_octree_build_host(const float *points, const float *xyzwhl, int num_points, int num_levels,
+                         float *boxes, int32_t *pt_inds, int32_t *pt_start_len) {
+  if (num_points < 0 || num_levels < 1 || num_levels > 7) {
+    sg::set_error("sg_octree_build_host: bad arguments (n=%d levels=%d)", num_points, num_levels);
+    return SG_ERR_ARG;
+  }
+  std::vector<size_t> first(num_levels + 2, 0);
+  size_t width = 1;
+  for (int l = 0; l <= num_levels; ++l) {
+    first[l + 1] = first[l] + width;
+    width *= 8;
+  }
+  std::memcpy(boxes, xyzwhl, 6 * sizeof(float));
+  width = 1;
+  for (int l = 0; l < num_levels; ++l, width *= 8) {
+    for (size_t path = 0; path < width; ++path) {
+      const float *pa = boxes + (first[l] + path) * 6;
+      const float w = pa[3] / 2, h = pa[4] / 2, d = pa[5] / 2;
+      for (int oct = 0; oct < 8; ++oct) {
+        float *c = boxes + (first[l + 1] + path * 8 + oct) * 6;
+        c[0] = (oct & 1) ? pa[0] + w / 2 : pa[0] - w / 2;
+        c[1] = (oct & 2) ? pa[1] + h / 2 : pa[1] - h / 2;
+        c[2] = (oct & 4) ? pa[2] + d / 2 : pa[2] - d / 2;
+        c[3] = w; c[4] = h; c[5] = d;
+      }
+    }
+  }
+  const size_t num_leaves = width;
+  std::vector<int32_t> leaf_of(static_cast<size_t>(num_points));
+  std::vector<int32_t> fill(num_leaves + 1, 0);
+  for (int i = 0; i < num_points; ++i) {
+    const float *p = points + static_cast<size_t>(i) * 3;
+    size_t path = 0;
+    for (int l = 0; l < num_levels; ++l) {
+      const float *b = boxes + (first[l] + path) * 6;
+      const int oct = (p[0] < b[0] ? 0 : 1) | (p[1] < b[1] ? 0 : 2) | (p[2] < b[2] ? 0 : 4);
+      path = path * 8 + oct;
+    }
+    leaf_of[i] = static_cast<int32_t>(path);
+    ++fill[path + 1];
+  }
+  for (size_t l = 0; l < num_leaves; ++l) {
+    pt_start_len[2 * l] = fill[l];
+    pt_start_len[2 * l + 1] = fill[l + 1];
+    fill[l + 1] += fill[l];
+  }
+  for (int i = 0; i < num_points; ++i) pt_inds[fill[leaf_of[i]]++] = i;
+  return SG_OK;
+}
+
+}  // extern "C"

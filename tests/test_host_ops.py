@@ -1,0 +1,49 @@
+"""Host (CPU) entry points of the library -- the two operators the reference itself runs on the
+CPU -- against the golden vectors produced by the reference's own C++."""
+import numpy as np
+import torch
+
+from softgroup_amd import _lib as L
+from softgroup_amd import ops
+
+
+def test_voxelization_idx_cpu_matches_reference(golden):
+    g = golden('voxelize_idx')
+    for i in range(int(g['vox_ncases'])):
+        for mode in (4, 3):
+            p = f'vox{i}_m{mode}_'
+            oc, im, om = ops.voxelization_idx(torch.from_numpy(g[p + 'coords']), int(g[p + 'batch']),
+                                              mode)
+            assert not oc.is_cuda and oc.dtype == torch.int64 and im.dtype == torch.int32
+            assert np.array_equal(oc.numpy(), g[p + 'out_coords'])
+            assert np.array_equal(im.numpy(), g[p + 'input_map'])
+            assert np.array_equal(om.numpy(), g[p + 'output_map'])
+
+
+def test_voxelization_idx_cpu_edge_cases():
+    oc, im, om = ops.voxelization_idx(torch.zeros((0, 4), dtype=torch.int64), 1)
+    assert oc.shape == (0, 4) and im.shape == (0,) and om.shape == (0, 2)
+    c = torch.tensor([[0, -5, 7, 1 << 20]] * 3)
+    oc, im, om = ops.voxelization_idx(c, 1)
+    assert om.tolist() == [[3, 0, 1, 2]] and oc.tolist() == [[0, -5, 7, 1 << 20]]
+    # modes 1 (first) / 2 (last), voxelize.cpp:134-149
+    c = torch.tensor([[0, 1, 1, 1], [0, 2, 2, 2], [0, 1, 1, 1]])
+    assert ops.voxelization_idx(c, 1, 1)[2].tolist() == [[1, 0], [1, 1]]
+    assert ops.voxelization_idx(c, 1, 2)[2].tolist() == [[1, 2], [1, 1]]
+
+
+def test_octree_build_host_matches_reference(golden):
+    g = golden('octree')
+    lib = L.lib()
+    for k in range(int(g['oct_ncases'])):
+        p = f'oct{k}_'
+        pts = torch.from_numpy(g[p + 'points'])
+        n = pts.shape[0]
+        boxes = torch.zeros((585, 6))
+        pt_inds = torch.zeros(n, dtype=torch.int32)
+        psl = torch.zeros((512, 2), dtype=torch.int32)
+        L.check(lib.sg_octree_build_host(L.ptr(pts), L.ptr(torch.from_numpy(g[p + 'xyzwhl'])), n, 3,
+                                         L.ptr(boxes), L.ptr(pt_inds), L.ptr(psl)))
+        assert np.array_equal(boxes.numpy(), g[p + 'boxes'])
+        assert np.array_equal(pt_inds.numpy(), g[p + 'pt_inds'])
+        assert np.array_equal(psl.numpy(), g[p + 'pt_start_len'])

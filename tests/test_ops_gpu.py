@@ -1,0 +1,297 @@
+"""GPU parity tests of the grouping-head operators: HIP path (through the C ABI) vs the CPU
+oracle on the same seeded inputs, plus the golden vectors generated from the reference.
+
+Bar: bit-exact for every integer/index product and for the order-preserving fp32 sums;
+exact for min/max and IoU (integer counts, f64 quotient)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from softgroup_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return x if dtype is None else x.to(dtype)
+
+
+# ----------------------------------------------------------------------------- voxelisation
+def test_voxelization_idx_gpu_golden(golden):
+    g = golden('voxelize_idx')
+    for i in range(int(g['vox_ncases'])):
+        for mode in (4, 3):
+            p = f'vox{i}_m{mode}_'
+            oc, im, om = ops.voxelization_idx(t(g[p + 'coords']), int(g[p + 'batch']), mode)
+            assert oc.is_cuda and oc.dtype == torch.int64 and om.dtype == torch.int32
+            assert np.array_equal(oc.cpu().numpy(), g[p + 'out_coords'])
+            assert np.array_equal(im.cpu().numpy(), g[p + 'input_map'])
+            assert np.array_equal(om.cpu().numpy(), g[p + 'output_map'])
+
+
+@pytest.mark.parametrize('n,hi,B', [(150000, 300, 1), (100000, 20, 200), (5000, 2, 1), (1, 5, 1)])
+def test_voxelization_idx_gpu_vs_oracle(n, hi, B):
+    rng = np.random.default_rng(n + hi)
+    c = rng.integers(0, hi, (n, 4)).astype(np.int64)
+    c[:, 0] = np.sort(rng.integers(0, B, n))
+    oc, im, om = ops.voxelization_idx(t(c), B)
+    roc, rim, rom = oracle.voxelization_idx(c, B)
+    assert np.array_equal(oc.cpu().numpy(), roc)
+    assert np.array_equal(im.cpu().numpy(), rim)
+    assert np.array_equal(om.cpu().numpy(), rom)
+
+
+def test_voxelization_idx_gpu_modes_and_empty():
+    c = torch.tensor([[0, 1, 1, 1], [0, 2, 2, 2], [0, 1, 1, 1]], device=DEV)
+    assert ops.voxelization_idx(c, 1, 1)[2].tolist() == [[1, 0], [1, 1]]
+    assert ops.voxelization_idx(c, 1, 2)[2].tolist() == [[1, 2], [1, 1]]
+    oc, im, om = ops.voxelization_idx(torch.zeros((0, 4), dtype=torch.int64, device=DEV), 1)
+    assert oc.shape == (0, 4) and im.shape == (0,) and om.shape[0] == 0
+
+
+@pytest.mark.parametrize('C', [6, 32, 3, 1, 33])
+def test_voxelization_fp_bp_bit_exact(C):
+    rng = np.random.default_rng(C)
+    n = 40000
+    c = rng.integers(0, 24, (n, 4)).astype(np.int64)
+    c[:, 0] = 0
+    _, _, om = oracle.voxelization_idx(c, 1)
+    feats = rng.standard_normal((n, C)).astype(np.float32)
+    for mode in (4, 3):
+        ref = oracle.voxelization(feats, om, mode)
+        f = t(feats).requires_grad_(True)
+        out = ops.voxelization(f, t(om), mode)
+        assert np.array_equal(out.detach().cpu().numpy(), ref)          # bit exact
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        out.backward(t(g))
+        assert np.array_equal(f.grad.cpu().numpy(), oracle.voxelization_bp(g, om, n, mode))
+
+
+# ----------------------------------------------------------------------------- ball query
+def _blob_cloud(rng, n_blobs, per_blob, n_noise, sigma=0.03):
+    ctr = rng.random((n_blobs, 3)) * np.array([6, 5, 2.7])
+    pts = [ctr[i] + rng.normal(0, sigma, (per_blob, 3)) for i in range(n_blobs)]
+    pts.append(rng.random((n_noise, 3)) * np.array([6, 5, 2.7]))
+    xyz = np.concatenate(pts).astype(np.float32)
+    return xyz[rng.permutation(len(xyz))]
+
+
+def _check_ballquery(xyz, bi, radius):
+    n = xyz.shape[0]
+    B = int(bi.max()) + 1 if n else 1
+    bo = np.concatenate([[0], np.cumsum(np.bincount(bi, minlength=B))]).astype(np.int32)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(bi), t(bo), radius, 300)
+    ridx, rsl = oracle.ballquery_batch_p(xyz, bi, bo, radius, 300)
+    idx, sl = idx.cpu().numpy(), sl.cpu().numpy()
+    assert np.array_equal(sl[:, 1], rsl[:, 1])
+    assert np.array_equal(sl[:, 0], np.concatenate([[0], np.cumsum(sl[:-1, 1])]))   # ascending CSR
+    assert np.array_equal(idx, ridx)     # oracle also lays lists out in point order
+    return idx, sl
+
+
+def test_ballquery_vs_oracle_blobs():
+    rng = np.random.default_rng(2)
+    xyz = _blob_cloud(rng, 12, 300, 2000)
+    n = len(xyz)
+    bi = np.sort(rng.integers(0, 2, n)).astype(np.int32)
+    _check_ballquery(xyz, bi, 0.04)
+
+
+def test_ballquery_negative_coords_and_cell_boundaries():
+    rng = np.random.default_rng(5)
+    # lattice points exactly on multiples of the radius: stresses strict '<' and cell edges
+    g = np.stack(np.meshgrid(*[np.arange(-6, 6)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    xyz = (g * 0.05).astype(np.float32)
+    xyz = np.concatenate([xyz, xyz + np.float32(1e-4), (rng.random((500, 3)) - 0.5).astype(np.float32)])
+    _check_ballquery(xyz, np.zeros(len(xyz), np.int32), 0.05)
+
+
+def test_ballquery_cap_1000_keeps_smallest_indices():
+    rng = np.random.default_rng(7)
+    # 2600 points inside a 1 cm ball: every list hits the cap; > LDS stage (2048) -> slow path
+    xyz = (rng.normal(0, 0.002, (2600, 3))).astype(np.float32)
+    xyz = np.concatenate([xyz, rng.random((400, 3)).astype(np.float32) + 1]).astype(np.float32)
+    idx, sl = _check_ballquery(xyz, np.zeros(len(xyz), np.int32), 0.04)
+    assert (sl[:2600, 1] == 1000).all()
+    # 1500 points: cap hit, but fits the LDS stage (fast path, rank < 1000 filter)
+    xyz2 = (rng.normal(0, 0.002, (1500, 3))).astype(np.float32)
+    _check_ballquery(xyz2, np.zeros(1500, np.int32), 0.04)
+
+
+def test_ballquery_empty_and_single():
+    z = torch.zeros((0, 3), device=DEV)
+    idx, sl = ops.ballquery_batch_p(z, torch.zeros(0, dtype=torch.int32, device=DEV),
+                                    torch.zeros(2, dtype=torch.int32, device=DEV), 0.04, 300)
+    assert idx.numel() == 0 and sl.shape == (0, 2)
+    idx, sl = ops.ballquery_batch_p(torch.ones((1, 3), device=DEV),
+                                    torch.zeros(1, dtype=torch.int32, device=DEV),
+                                    torch.tensor([0, 1], dtype=torch.int32, device=DEV), 0.04, 300)
+    assert idx.tolist() == [0] and sl.tolist() == [[0, 1]]
+
+
+def test_octree_ball_query_vs_oracle():
+    rng = np.random.default_rng(11)
+    xyz = _blob_cloud(rng, 10, 400, 3000, sigma=0.3) * np.float32(40)
+    idx, sl = ops.octree_ball_query(t(xyz), 3, 0.9 * 3)
+    ridx, rsl = oracle.octree_ball_query(xyz, 3, 0.9 * 3)
+    assert np.array_equal(sl.cpu().numpy(), rsl)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    # cap: dense clump -> lists stop at the first 1000 in leaf order
+    clump = rng.normal(0, 0.01, (1800, 3)).astype(np.float32)
+    idx, sl = ops.octree_ball_query(t(clump), 3, 1.0)
+    ridx, rsl = oracle.octree_ball_query(clump, 3, 1.0)
+    assert (rsl[:, 1] == 1000).all()
+    assert np.array_equal(sl.cpu().numpy(), rsl) and np.array_equal(idx.cpu().numpy(), ridx)
+
+
+# ----------------------------------------------------------------------------- clustering
+def test_bfs_cluster_golden(golden):
+    g = golden('bfs_cluster')
+    for k in range(int(g['bfs_ncases'])):
+        p = f'bfs{k}_'
+        for dev in ('cpu', DEV):        # CPU tensors in -> CPU out (reference contract); CUDA -> CUDA
+            ci, co = ops.bfs_cluster(torch.from_numpy(g[p + 'mean']),
+                                     torch.from_numpy(g[p + 'idx']).to(dev),
+                                     torch.from_numpy(g[p + 'start_len']).to(dev),
+                                     float(g[p + 'thr']), int(g[p + 'cid']))
+            assert ci.device.type == torch.device(dev).type and ci.dtype == torch.int32
+            assert np.array_equal(ci.cpu().numpy().reshape(-1, 2), g[p + 'cluster_idxs']), k
+            assert np.array_equal(co.cpu().numpy(), g[p + 'cluster_offsets']), k
+
+
+def test_bfs_cluster_vs_oracle_large_and_order():
+    rng = np.random.default_rng(13)
+    xyz = _blob_cloud(rng, 40, 1000, 10000)
+    n = len(xyz)
+    bi = np.zeros(n, np.int32)
+    bo = np.array([0, n], np.int32)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(bi), t(bo), 0.04, 300)
+    mean = torch.tensor([-1.0, 2000.0])
+    for cid, thr in ((0, 100.0), (1, 0.05)):
+        ci, co = ops.bfs_cluster(mean, idx, sl, thr, cid)
+        rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), thr, cid)
+        assert np.array_equal(co.cpu().numpy(), rco)
+        assert np.array_equal(ci.cpu().numpy(), rci)       # membership AND member order
+    assert len(rco) - 1 >= 40
+
+
+def test_bfs_cluster_directed_lists_capped():
+    """cap-hit regime: lists keep the 1000 smallest indices -> asymmetric graph -> the reference
+    semantics is directed reachability from ascending seeds."""
+    rng = np.random.default_rng(17)
+    a = rng.normal(0, 0.004, (1800, 3))
+    b = rng.normal(0, 0.004, (1500, 3)) + np.array([0.03, 0, 0])
+    c = rng.random((700, 3)) + 1.0
+    xyz = np.concatenate([a, b, c]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    n = len(xyz)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(np.zeros(n, np.int32)), t(np.array([0, n], np.int32)),
+                                    0.04, 300)
+    assert (sl[:, 1] == 1000).any()
+    mean = torch.tensor([-1.0])
+    ci, co = ops.bfs_cluster(mean, idx, sl, 2.0, 0)
+    rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 2.0, 0)
+    assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
+    # unsorted lists (octree order) take the linear membership test
+    oidx, osl = ops.octree_ball_query(t(xyz), 3, 0.04)
+    ci, co = ops.bfs_cluster(mean, oidx, osl, 2.0, 0)
+    rci, rco = oracle.bfs_cluster(mean.numpy(), oidx.cpu().numpy(), osl.cpu().numpy(), 2.0, 0)
+    assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
+
+
+def test_bfs_cluster_empty_and_all_dropped():
+    mean = torch.tensor([-1.0])
+    ci, co = ops.bfs_cluster(mean, torch.zeros(0, dtype=torch.int32, device=DEV),
+                             torch.zeros((0, 2), dtype=torch.int32, device=DEV), 1.0, 0)
+    assert ci.shape == (0, 2) and co.tolist() == [0]
+    idx = torch.arange(5, dtype=torch.int32, device=DEV)
+    sl = torch.stack([torch.arange(5), torch.ones(5, dtype=torch.long)], 1).int().to(DEV)
+    ci, co = ops.bfs_cluster(mean, idx, sl, 2.0, 0)        # singletons < thr
+    assert ci.shape == (0, 2) and co.tolist() == [0]
+    ci, co = ops.bfs_cluster(mean, idx, sl, 1.0, 0)
+    assert ci.tolist() == [[i, i] for i in range(5)] and co.tolist() == list(range(6))
+
+
+def test_bfs_cluster_multi_segment_equals_per_class():
+    rng = np.random.default_rng(19)
+    parts, segs = [], []
+    for s in range(3):
+        x = _blob_cloud(rng, 6, 250, 800)
+        parts.append(x)
+        segs.append(np.full(len(x), s, np.int32))
+    xyz = np.concatenate(parts)
+    seg = np.concatenate(segs)
+    n = len(xyz)
+    # segments are kept apart by giving each its own "batch" id
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(seg), t(np.array([0, n], np.int32)), 0.04, 300)
+    thr = np.array([50.0, 120.0, 10.0], np.float32)
+    ci, co = ops.bfs_cluster_segments(idx, sl, t(thr), t(seg), True)
+    # reference: one call per class on the class-local sub-problem, then merged (softgroup.py:464-473)
+    exp_idx, exp_off, base, nclu = [], [0], 0, 0
+    for s in range(3):
+        m = len(parts[s])
+        li, lsl = oracle.ballquery_batch_p(parts[s], np.zeros(m, np.int32), np.array([0, m], np.int32),
+                                           0.04, 300)
+        rci, rco = oracle.bfs_cluster(np.array([-1.0], np.float32), li, lsl, float(thr[s]), 0)
+        rci = rci.copy()
+        rci[:, 0] += nclu
+        rci[:, 1] += base
+        exp_idx.append(rci)
+        last = exp_off[-1]
+        exp_off.extend((rco[1:] + last).tolist())
+        base += m
+        nclu += len(rco) - 1
+    assert np.array_equal(ci.cpu().numpy(), np.concatenate(exp_idx))
+    assert np.array_equal(co.cpu().numpy(), np.array(exp_off, np.int32))
+
+
+# ----------------------------------------------------------------------------- segment ops
+def _segments(rng, nP, lo, hi):
+    lens = rng.integers(lo, hi, nP)
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+@pytest.mark.parametrize('C', [3, 32, 64, 300])
+def test_sec_min_max_mean_avgpool(C):
+    rng = np.random.default_rng(C)
+    off = _segments(rng, 57, 1, 900)
+    off[5] = off[4]                                     # an empty segment
+    x = rng.standard_normal((off[-1], C)).astype(np.float32)
+    assert np.array_equal(ops.sec_min(t(x), t(off)).cpu().numpy(), oracle.sec_min(x, off))
+    assert np.array_equal(ops.sec_max(t(x), t(off)).cpu().numpy(), oracle.sec_max(x, off))
+    np.testing.assert_array_equal(ops.sec_mean(t(x), t(off)).cpu().numpy(), oracle.sec_mean(x, off))
+    xt = t(x).requires_grad_(True)
+    out = ops.global_avg_pool(xt, t(off))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.global_avg_pool(x, off))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(t(g))
+    ref = oracle.global_avg_pool_bp(g, off, x.shape[0])
+    got = xt.grad.cpu().numpy()
+    ok = np.isfinite(ref).all(1)                        # rows of the empty segment: none exist
+    np.testing.assert_array_equal(got[ok], ref[ok])
+
+
+# ----------------------------------------------------------------------------- mask IoU / label
+def test_mask_iou_and_label():
+    rng = np.random.default_rng(23)
+    N, nI, nP = 60000, 37, 90
+    inst = rng.integers(-1, nI, N).astype(np.int64)
+    inst[inst < 0] = -100
+    pointnum = np.array([(inst == g).sum() for g in range(nI)], np.int32)
+    off = _segments(rng, nP, 20, 1500)
+    pidx = rng.integers(0, N, off[-1]).astype(np.int32)
+    cls = rng.integers(0, 18, nI).astype(np.int64)
+    cls[[3, 9]] = -100
+    sig = rng.random(off[-1]).astype(np.float32)
+    iou = ops.get_mask_iou_on_cluster(t(pidx), t(off), t(inst), t(pointnum))
+    ref = oracle.get_mask_iou_on_cluster(pidx, off, inst, pointnum)
+    assert np.array_equal(iou.cpu().numpy(), ref)
+    iou2 = ops.get_mask_iou_on_pred(t(pidx), t(off), t(inst), t(pointnum), t(sig))
+    assert np.array_equal(iou2.cpu().numpy(), oracle.get_mask_iou_on_pred(pidx, off, inst, pointnum, sig))
+    for thr in (0.0, 0.01, 0.5):
+        ml = ops.get_mask_label(t(pidx), t(off), t(inst), t(cls), t(pointnum), iou, thr)
+        assert np.array_equal(ml.cpu().numpy(),
+                              oracle.get_mask_label(pidx, off, inst, cls, pointnum, ref, thr))
