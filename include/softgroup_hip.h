@@ -42,6 +42,8 @@ typedef void *sg_stream_t;
 #define SG_BALLQUERY_MAX_NEIGHBORS 1000 /* bfs_cluster.cu:24 `int idx_temp[1000]` */
 #define SG_OCTREE_NUM_NODES 585         /* octree_ball_query.cu:10 */
 #define SG_OCTREE_NUM_LEAVES 512        /* octree_ball_query.cu:11 */
+#define SG_LISTS_SORTED 1
+#define SG_LISTS_RADIUS 2
 
 int sg_version(void);
 const char *sg_last_error(void);
@@ -138,11 +140,15 @@ int sg_octree_ballquery_fill(const float *points, const float *boxes, const int3
  *   emit  : cluster_idxs int32 [sumNPoint,2] = (cluster_id, point_idx), cluster_offsets [nCluster+1]
  * ---------------------------------------------------------------------------------------- */
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges);
-/* lists_sorted: 1 when every neighbour list is ascending (ball query), 0 otherwise (octree).
+/* list_flags: SG_LISTS_SORTED  every list is strictly ascending (sg_ballquery_* output);
+ *             SG_LISTS_RADIUS  lists come from a radius query, i.e. u in list(v) <=> v in list(u)
+ *                              unless one of the two lists is capped at 1000 entries
+ *                              (sg_ballquery_* and sg_octree_ballquery_* output).
+ *             0 = arbitrary directed lists (every edge is checked for its reverse).
  * SYNCHRONISES `stream`: the number of kept clusters sizes the outputs, so it is returned to
  * host memory (*n_cluster_host, *sum_npoint_host). */
 int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n,
-                         int64_t n_edges, int lists_sorted, const int32_t *seg_of_point,
+                         int64_t n_edges, int list_flags, const int32_t *seg_of_point,
                          const float *seg_thr, int n_seg, int32_t *n_cluster_host,
                          int32_t *sum_npoint_host, void *ws, size_t ws_bytes, sg_stream_t stream);
 /* same ws buffer, untouched since sg_bfs_cluster_label */

@@ -7,9 +7,9 @@
 // point v, the cluster of the smallest-index point that can reach v ("min ancestor").  That
 // labelling is what we compute:
 //   A. union-find over the symmetric edges (hook the larger root under the smaller, so every
-//      root is the minimum index of its set).  An edge u->v is known symmetric when neither
-//      list is capped; otherwise membership of u in list(v) is checked (binary search on the
-//      ascending lists the ball query emits, linear wave scan for unsorted octree lists).
+//      root is the minimum index of its set).  For lists that come from a radius query
+//      (SG_LISTS_RADIUS) an edge u->v is known symmetric when neither list is capped; otherwise
+//      membership of u in list(v) is checked (binary search when SG_LISTS_SORTED, else a scan).
 //   B. only if asymmetric edges exist: min-label propagation across them to the fixed point.
 //   C. cluster sizes, threshold test per segment (class), ids = rank among kept seeds,
 //      offsets = prefix sum of kept sizes.
@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(256) bfs_init_kernel(int n, int32_t *parent, i
 // one wave per source node u; lanes stride over list(u)
 __global__ void __launch_bounds__(256) bfs_union_kernel(const int32_t *__restrict__ idx,
                                                        const int32_t *__restrict__ start_len, int n,
-                                                       int lists_sorted, int32_t *parent,
-                                                       int32_t *asym_nodes, int32_t *counters) {
+                                                       int lists_sorted, int radius_lists,
+                                                       int32_t *parent, int32_t *asym_nodes,
+                                                       int32_t *counters) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int u = blockIdx.x * 4 + wave; u < n; u += gridDim.x * 4) {
     const int st = start_len[2 * u], ln = start_len[2 * u + 1];
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256) bfs_union_kernel(const int32_t *__restric
       bool sym = true;
       if (v != u) {
         const int vst = start_len[2 * v], vln = start_len[2 * v + 1];
-        if (u_capped || vln >= kCap) {
+        if (!radius_lists || u_capped || vln >= kCap) {
           if (lists_sorted) {
             sym = list_has_sorted(idx + vst, vln, u);
           } else {
@@ -363,7 +364,7 @@ size_t sg_bfs_workspace_bytes(int n, int64_t n_edges) {
 
 // Synchronises `stream` (the cluster count decides the size of the outputs).
 int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n, int64_t n_edges,
-                         int lists_sorted, const int32_t *seg_of_point, const float *seg_thr,
+                         int list_flags, const int32_t *seg_of_point, const float *seg_thr,
                          int n_seg, int32_t *n_cluster_host, int32_t *sum_npoint_host, void *ws,
                          size_t ws_bytes, sg_stream_t stream_) {
   (void)n_edges;
@@ -381,8 +382,9 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
   hipMemsetAsync(w.counters, 0, 64 * 4, stream);
   bfs_init_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.size, w.owner);
   bfs_union_kernel<<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, start_len, n,
-                                                               lists_sorted, w.parent,
-                                                               w.asym_nodes, w.counters);
+                                                               list_flags & SG_LISTS_SORTED,
+                                                               list_flags & SG_LISTS_RADIUS,
+                                                               w.parent, w.asym_nodes, w.counters);
   bfs_flatten_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab);
   bfs_store_root_kernel<<<grid, 256, 0, stream>>>(n, w.lab, w.parent);  // parent := root_of
 

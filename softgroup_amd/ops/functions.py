@@ -71,6 +71,7 @@ def octree_ball_query(coords, mean_active, radius):
     L.check(lib.sg_octree_ballquery_fill(L.ptr(pts), L.ptr(boxes), L.ptr(pt_inds),
                                          L.ptr(pt_start_len), n, float(radius), L.ptr(start_len),
                                          L.ptr(out_inds), st), 'sg_octree_ballquery_fill')
+    out_inds._sg_flags = LISTS_RADIUS
     return out_inds, start_len
 
 
@@ -125,7 +126,7 @@ class BallQueryBatchP(Function):
 
 def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
     idx, start_len = BallQueryBatchP.apply(coords, batch_idxs, batch_offsets, radius, meanActive)
-    idx._sg_sorted = True   # lists are ascending: lets bfs_cluster skip its sortedness probe
+    idx._sg_flags = LISTS_SORTED | LISTS_RADIUS   # lets bfs_cluster skip its probes
     return idx, start_len
 
 
@@ -134,8 +135,6 @@ def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
 # ---------------------------------------------------------------------------------------------
 def _lists_sorted(idx, start_len):
     """True iff every CSR neighbour list is strictly ascending (decides the membership test)."""
-    if getattr(idx, '_sg_sorted', False):
-        return True
     if idx.numel() < 2:
         return True
     bad = idx[1:] <= idx[:-1]
@@ -146,7 +145,10 @@ def _lists_sorted(idx, start_len):
     return not bool(bad.any().item())
 
 
-def bfs_cluster_segments(ball_query_idxs, start_len, seg_thr, seg_of_point=None, lists_sorted=None):
+LISTS_SORTED, LISTS_RADIUS = 1, 2
+
+
+def bfs_cluster_segments(ball_query_idxs, start_len, seg_thr, seg_of_point=None, list_flags=None):
     """Generalised clustering entry: several classes (segments) in one launch.
 
     ball_query_idxs int32 [nActive], start_len int32 [n,2] (CUDA), seg_thr float32 [n_seg]
@@ -156,15 +158,17 @@ def bfs_cluster_segments(ball_query_idxs, start_len, seg_thr, seg_of_point=None,
     lib = L.lib()
     dev = ball_query_idxs.device
     n = start_len.size(0)
-    if lists_sorted is None:
-        lists_sorted = _lists_sorted(ball_query_idxs, start_len)
+    if list_flags is None:
+        list_flags = getattr(ball_query_idxs, '_sg_flags', None)
+    if list_flags is None:     # unknown producer: trust nothing except what we can verify
+        list_flags = LISTS_SORTED if _lists_sorted(ball_query_idxs, start_len) else 0
     n_edges = ball_query_idxs.numel()
     nb = lib.sg_bfs_workspace_bytes(n, n_edges)
     ws = L.workspace(nb, dev)
     st = L.stream()
     nc, sp = C.c_int32(0), C.c_int32(0)
     L.check(lib.sg_bfs_cluster_label(L.ptr(ball_query_idxs), L.ptr(start_len), n, n_edges,
-                                     int(bool(lists_sorted)), L.ptr(seg_of_point), L.ptr(seg_thr),
+                                     int(list_flags), L.ptr(seg_of_point), L.ptr(seg_thr),
                                      seg_thr.numel(), C.byref(nc), C.byref(sp), L.ptr(ws), nb, st),
             'sg_bfs_cluster_label')
     cluster_idxs = torch.empty((sp.value, 2), dtype=torch.int32, device=dev)
@@ -191,7 +195,7 @@ class BFSCluster(Function):
         mean = np.float32(cluster_numpoint_mean.detach().cpu().float()[class_id].item())
         thr = np.float32(threshold) if mean == np.float32(-1) else np.float32(threshold) * mean
         seg_thr = torch.tensor([float(thr)], dtype=torch.float32, device=dev)
-        srt = True if getattr(ball_query_idxs, '_sg_sorted', False) else None
+        srt = getattr(ball_query_idxs, '_sg_flags', None)
         idxs = ball_query_idxs.to(dev, torch.int32)
         sl = start_len.to(dev, torch.int32)
         cluster_idxs, cluster_offsets = bfs_cluster_segments(idxs, sl, seg_thr, None, srt)

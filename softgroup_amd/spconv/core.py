@@ -1,0 +1,405 @@
+"""Host-side mirror of the ``spconv.pytorch`` subset the reference model uses.
+
+Reference call sites (paths relative to the reference repository):
+  SparseConvTensor      softgroup/model/softgroup.py:120,307,388,671,706; blocks.py:37,73,134
+  SubMConv3d            softgroup/model/softgroup.py:61-62; blocks.py:57-70
+  SparseConv3d          blocks.py:31 (base of Custom1x1Subm3d), 101-107 (k2, s2)
+  SparseInverseConv3d   blocks.py:114-119
+  SparseSequential      softgroup/model/softgroup.py:60,65,74; blocks.py:50-55,96-129
+  modules.SparseModule  blocks.py:5,44
+
+Parameters keep spconv 2.x naming and layout -- ``weight`` of shape [Cout, kD, kH, kW, Cin]
+("OKKKI", tools/convert_checkpoint.py:17-19), optional ``bias`` -- so reference checkpoints load.
+All arithmetic runs in libsoftgroup_hip.so (spconv_rulebook.hip, spconv_conv.hip).
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------
+class SparseConvTensor:
+    """features [M,C] float, indices int32 [M,4] = (batch, d0, d1, d2), spatial_shape, batch_size.
+    ``indice_dict`` caches rulebooks by ``indice_key`` and is shared by tensors derived from it."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None,
+                 indice_dict=None, benchmark=False):
+        assert features.dim() == 2 and indices.dim() == 2 and indices.shape[1] == 4
+        assert indices.dtype == torch.int32, 'indices must be int32 (spconv contract)'
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {} if indice_dict is None else indice_dict
+        self.grid = grid
+        self.voxel_num = voxel_num
+        self.benchmark = benchmark
+
+    def replace_feature(self, feature):
+        new = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid,
+                               self.voxel_num, self.indice_dict, self.benchmark)
+        return new
+
+    @property
+    def spatial_size(self):
+        return int(torch.tensor(self.spatial_shape).prod())
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        shape = [self.batch_size] + self.spatial_shape + [self.features.shape[1]]
+        out = self.features.new_zeros(shape)
+        idx = self.indices.long()
+        out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = self.features
+        return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
+
+
+# ------------------------------------------------------------------------------------------------
+# rulebooks
+# ------------------------------------------------------------------------------------------------
+class _Plan:
+    """gather table + mask-sorted tile plan for the implicit-GEMM kernel"""
+    __slots__ = ('nbr', 'order', 'tile_mask', 'num_out', 'kvol')
+
+    def __init__(self, nbr, num_out, kvol):
+        lib = L.lib()
+        dev = nbr.device
+        self.nbr, self.num_out, self.kvol = nbr, num_out, kvol
+        self.order = torch.empty(num_out, dtype=torch.int32, device=dev)
+        self.tile_mask = torch.empty((num_out + 31) // 32, dtype=torch.int32, device=dev)
+        if num_out:
+            nb = lib.sg_spconv_plan_workspace_bytes(num_out)
+            ws = L.workspace(nb, dev)
+            L.check(lib.sg_spconv_plan(L.ptr(nbr), num_out, kvol, L.ptr(self.order),
+                                       L.ptr(self.tile_mask), L.ptr(ws), nb, L.stream()),
+                    'sg_spconv_plan')
+
+
+class SubMRule:
+    def __init__(self, indices, spatial_shape):
+        lib = L.lib()
+        M = indices.shape[0]
+        dev = indices.device
+        nbr = torch.empty((M, 27), dtype=torch.int32, device=dev)
+        if M:
+            nb = lib.sg_spconv_hash_workspace_bytes(M)
+            ws = L.workspace(nb, dev)
+            shape = (C.c_int32 * 3)(*spatial_shape)
+            L.check(lib.sg_spconv_subm_rulebook(L.ptr(indices), M, shape, L.ptr(nbr), L.ptr(ws), nb,
+                                                L.stream()), 'sg_spconv_subm_rulebook')
+        self.num_rows = M
+        self.plan = _Plan(nbr, M, 27)
+
+
+class DownRule:
+    """SparseConv3d(k=2, s=2) pairs; also serves the paired SparseInverseConv3d."""
+
+    def __init__(self, indices, spatial_shape, batch_size):
+        lib = L.lib()
+        M = indices.shape[0]
+        dev = indices.device
+        self.in_indices = indices
+        self.in_spatial_shape = list(spatial_shape)
+        self.out_spatial_shape = [s // 2 for s in spatial_shape]   # floor((D-2)/2)+1
+        self.batch_size = batch_size
+        self.in2out = torch.empty(M, dtype=torch.int32, device=dev)
+        meta = torch.zeros(2, dtype=torch.int32, device=dev)
+        nb = lib.sg_spconv_hash_workspace_bytes(M)
+        ws = L.workspace(nb, dev)
+        shape = (C.c_int32 * 3)(*spatial_shape)
+        st = L.stream()
+        L.check(lib.sg_spconv_down_build(L.ptr(indices), M, shape, L.ptr(self.in2out), L.ptr(meta),
+                                         L.ptr(ws), nb, st), 'sg_spconv_down_build')
+        m_out = int(meta[0].item())
+        self.num_in, self.num_out = M, m_out
+        self.out_indices = torch.empty((m_out, 4), dtype=torch.int32, device=dev)
+        child = torch.empty((m_out, 8), dtype=torch.int32, device=dev)
+        L.check(lib.sg_spconv_down_fill(L.ptr(indices), M, L.ptr(self.in2out), m_out,
+                                        L.ptr(self.out_indices), L.ptr(child), L.ptr(ws), nb, st),
+                'sg_spconv_down_fill')
+        self.plan = _Plan(child, m_out, 8)
+        self._inv_plan = None
+
+    @property
+    def inv_plan(self):
+        if self._inv_plan is None:
+            lib = L.lib()
+            inv = torch.empty((self.num_in, 8), dtype=torch.int32, device=self.in2out.device)
+            if self.num_in:
+                L.check(lib.sg_spconv_inverse_rulebook(L.ptr(self.in_indices), L.ptr(self.in2out),
+                                                       self.num_in, L.ptr(inv), L.stream()),
+                        'sg_spconv_inverse_rulebook')
+            self._inv_plan = _Plan(inv, self.num_in, 8)
+        return self._inv_plan
+
+
+# ------------------------------------------------------------------------------------------------
+# the conv operator
+# ------------------------------------------------------------------------------------------------
+def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, residual=None):
+    """out[j] = residual[j] + sum_k act(features[nbr[j,k]]) @ w_kio[k]   (fp32, HIP)"""
+    lib = L.lib()
+    assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+    cin = features.shape[1]
+    out = torch.empty((plan.num_out, cout), dtype=torch.float32, device=features.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    L.check(lib.sg_spconv_gather_conv_f32(
+        L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
+        L.ptr(w_kio), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(residual), L.ptr(plan.order),
+        L.ptr(plan.tile_mask), L.ptr(out), L.stream()), 'sg_spconv_gather_conv_f32')
+    return out
+
+
+class SparseModule(nn.Module):
+    """marker base class: SparseSequential hands these the SparseConvTensor itself"""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v, v, v)
+
+
+class SparseConvolution(SparseModule):
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        assert ndim == 3 and groups == 1
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._kio_cache = None
+        self.reset_parameters()
+        ks, st, pd = self.kernel_size, self.stride, self.padding
+        ok = ((subm and ks == (3, 3, 3) and st == (1, 1, 1) and pd == (1, 1, 1))
+              or (not subm and not inverse and ks == (2, 2, 2) and st == (2, 2, 2) and pd == (0, 0, 0))
+              or (inverse and ks == (2, 2, 2)) or self.conv1x1)
+        if not ok or any(d != 1 for d in self.dilation):
+            raise NotImplementedError(
+                f'softgroup_amd.spconv covers the conv shapes the SoftGroup model uses (SubM k3 p1, '
+                f'SparseConv k2 s2 p0, SparseInverse k2, k1); got subm={subm} inverse={inverse} '
+                f'kernel={ks} stride={st} padding={pd} dilation={self.dilation}')
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * int(torch.tensor(self.kernel_size).prod())
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, '
+                f'stride={self.stride}, subm={self.subm}, inverse={self.inverse}, '
+                f'indice_key={self.indice_key}')
+
+    # [Cout, K, Cin] -> [K, Cin, Cout], cached until the weight changes
+    def weight_kio(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), w.device, w.dtype)
+        if self._kio_cache is None or self._kio_cache[0] != key:
+            kvol = int(torch.tensor(self.kernel_size).prod())
+            src = w.detach().float().contiguous()
+            out = torch.empty((kvol, self.in_channels, self.out_channels), dtype=torch.float32,
+                              device=w.device)
+            L.check(L.lib().sg_spconv_weight_to_kio(L.ptr(src), self.out_channels, kvol,
+                                                    self.in_channels, L.ptr(out), L.stream()),
+                    'sg_spconv_weight_to_kio')
+            self._kio_cache = (key, out)
+        return self._kio_cache[1]
+
+    def _rule_and_plan(self, input):
+        """-> (plan, out_indices, out_spatial_shape)"""
+        key = self.indice_key
+        if self.subm:
+            rule = input.find_indice_pair(key)
+            if not isinstance(rule, SubMRule) or rule.num_rows != input.indices.shape[0]:
+                rule = SubMRule(input.indices, input.spatial_shape)
+                if key is not None:
+                    input.indice_dict[key] = rule
+            return rule.plan, input.indices, input.spatial_shape
+        if self.inverse:
+            rule = input.find_indice_pair(key)
+            if not isinstance(rule, DownRule):
+                raise RuntimeError(f'SparseInverseConv3d: no SparseConv3d rulebook under indice_key '
+                                   f'{key!r} (spconv requires the paired down conv to run first)')
+            assert rule.num_out == input.indices.shape[0], 'inverse conv input does not match its pair'
+            return rule.inv_plan, rule.in_indices, rule.in_spatial_shape
+        rule = input.find_indice_pair(key)
+        if (not isinstance(rule, DownRule) or rule.num_in != input.indices.shape[0]
+                or rule.in_indices.data_ptr() != input.indices.data_ptr()):
+            rule = DownRule(input.indices, input.spatial_shape, input.batch_size)
+            if key is not None:
+                input.indice_dict[key] = rule
+        return rule.plan, rule.out_indices, rule.out_spatial_shape
+
+    def forward(self, input, bn_scale=None, bn_shift=None, residual=None):
+        assert isinstance(input, SparseConvTensor)
+        feats = input.features
+        if self.conv1x1:   # plain GEMM on the active rows (blocks.py:31-41 semantics)
+            assert bn_scale is None and residual is None
+            out = torch.mm(feats, self.weight.view(self.out_channels, self.in_channels).T)
+            if self.bias is not None:
+                out = out + self.bias
+            return input.replace_feature(out)
+        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError(
+                'softgroup_amd.spconv: sparse-conv backward is not built yet (inference path only); '
+                'run under torch.no_grad()')
+        plan, out_indices, out_shape = self._rule_and_plan(input)
+        x = feats if feats.dtype == torch.float32 else feats.float()
+        out = gather_conv(x.contiguous(), plan, self.weight_kio(), self.out_channels, bn_scale,
+                          bn_shift, residual)
+        if self.bias is not None:
+            out += self.bias.float()
+        if out.dtype != feats.dtype:
+            out = out.to(feats.dtype)
+        return SparseConvTensor(out, out_indices, out_shape, input.batch_size, input.grid,
+                                input.voxel_num, input.indice_dict, input.benchmark)
+
+
+class SubMConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, True, indice_key=indice_key, algo=algo, name=name)
+
+
+class SparseConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, indice_key=indice_key, algo=algo, name=name)
+
+
+class SparseInverseConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, algo=None,
+                 fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key, algo=algo, name=name)
+
+
+# ------------------------------------------------------------------------------------------------
+def _bn_affine(bn):
+    """eval-mode BatchNorm1d as y = x*scale + shift; cached until any of its tensors changes"""
+    tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t._version, t.data_ptr()) if t is not None else None for t in tensors)
+    cache = getattr(bn, '_sg_affine', None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+            scale = inv * bn.weight.float() if bn.weight is not None else inv
+            shift = -bn.running_mean.float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.float()
+        cache = (key, scale.contiguous(), shift.contiguous())
+        bn._sg_affine = cache
+    return cache[1], cache[2]
+
+
+def _fusable_bn(m):
+    return (isinstance(m, nn.BatchNorm1d) and not m.training and m.track_running_stats
+            and m.running_mean is not None)
+
+
+class SparseSequential(SparseModule):
+    """spconv's sequential container: sparse modules receive the SparseConvTensor, dense modules
+    (BatchNorm1d, ReLU, Identity ...) are applied to ``.features``.  Children are named
+    '0','1',... or by the OrderedDict keys (state-dict compatibility).
+
+    In eval mode the pre-activation pattern BatchNorm1d -> ReLU -> sparse conv (blocks.py:57-70,
+    99-119) runs as ONE kernel (BN+ReLU applied to the gathered rows), and BatchNorm1d -> ReLU at
+    the end of a sequence (softgroup.py:65) as one elementwise kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError('name exists.')
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f'index {idx} is out of range')
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+        self.add_module(name, module)
+
+    def forward(self, input, residual=None):
+        mods = list(self._modules.values())
+        last_conv = max((i for i, m in enumerate(mods) if isinstance(m, SparseConvolution)),
+                        default=-1)
+        if residual is not None and last_conv != len(mods) - 1:
+            raise ValueError('residual fusion needs the sequence to end in a sparse convolution')
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            sparse_in = isinstance(input, SparseConvTensor)
+            fast = (sparse_in and not torch.is_grad_enabled() and input.features.is_cuda
+                    and input.features.dtype == torch.float32 and input.indices.shape[0] != 0)
+            if fast and _fusable_bn(m) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                scale, shift = _bn_affine(m)
+                nxt = mods[i + 2] if i + 2 < len(mods) else None
+                if isinstance(nxt, SparseConvolution) and not nxt.conv1x1:
+                    input = nxt(input, scale, shift, residual if i + 2 == last_conv else None)
+                    i += 3
+                    continue
+                feats = input.features.contiguous()
+                out = torch.empty_like(feats)
+                L.check(L.lib().sg_bn_relu_f32(L.ptr(feats), L.ptr(scale), L.ptr(shift),
+                                               feats.shape[0], feats.shape[1], 1, L.ptr(out),
+                                               L.stream()), 'sg_bn_relu_f32')
+                input = input.replace_feature(out)
+                i += 2
+                continue
+            if is_spconv_module(m):
+                if isinstance(m, SparseConvolution) and i == last_conv and residual is not None:
+                    input = m(input, residual=residual)
+                else:
+                    input = m(input)
+            elif sparse_in:
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(m(input.features))
+            else:
+                input = m(input)
+            i += 1
+        return input

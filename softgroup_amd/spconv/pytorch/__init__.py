@@ -1,0 +1,3 @@
+from ..core import (SparseConv3d, SparseConvTensor, SparseConvolution, SparseInverseConv3d,  # noqa: F401
+                    SparseModule, SparseSequential, SubMConv3d, is_spconv_module)
+from . import modules  # noqa: F401

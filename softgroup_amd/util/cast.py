@@ -1,0 +1,61 @@
+"""Argument-casting decorators with the semantics of the reference's ``cuda_cast``
+(softgroup/util/utils.py:157-173) and ``force_fp32`` (softgroup/util/fp16.py:24-66).
+``force_fp32`` additionally up-casts bfloat16 (BASELINE config 3 trains in bf16; the reference
+only knows torch.half)."""
+import functools
+import inspect
+from collections import abc
+
+import torch
+
+from ..spconv import SparseConvTensor
+
+_LOW = (torch.half, torch.bfloat16)
+
+
+def cuda_cast(func):
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        args = [a.cuda(non_blocking=True) if isinstance(a, torch.Tensor) else a for a in args]
+        kwargs = {k: (v.cuda(non_blocking=True) if isinstance(v, torch.Tensor) else v)
+                  for k, v in kwargs.items()}
+        return func(*args, **kwargs)
+
+    return wrapper
+
+
+def _to_fp32(x):
+    if isinstance(x, torch.Tensor):
+        return x.float() if x.dtype in _LOW else x
+    if isinstance(x, SparseConvTensor):
+        return x.replace_feature(x.features.float()) if x.features.dtype in _LOW else x
+    if isinstance(x, (str, bytes)):
+        return x
+    if isinstance(x, abc.Mapping):
+        return type(x)({k: _to_fp32(v) for k, v in x.items()})
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_fp32(v) for v in x)
+    return x
+
+
+def force_fp32(apply_to=None):
+    """Cast the named arguments (all when None) to fp32 and run the method with autocast off."""
+
+    def deco(method):
+        names = inspect.getfullargspec(method).args
+
+        @functools.wraps(method)
+        def wrapper(*args, **kwargs):
+            if not isinstance(args[0], torch.nn.Module):
+                raise TypeError('@force_fp32 can only be used to decorate the method of nn.Module')
+            chosen = names if apply_to is None else apply_to
+            args = [_to_fp32(a) if n in chosen else a for n, a in zip(names, args)] + \
+                list(args[len(names):])
+            kwargs = {k: (_to_fp32(v) if k in chosen else v) for k, v in kwargs.items()}
+            with torch.autocast('cuda', enabled=False):
+                return method(*args, **kwargs)
+
+        return wrapper
+
+    return deco

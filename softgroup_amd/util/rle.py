@@ -1,0 +1,30 @@
+"""Run-length encoding of 1-D binary masks in the wire format of the reference
+(softgroup/util/rle.py:5-41): ``{'length': N, 'counts': 'start len start len ...'}`` with
+1-based starts."""
+import numpy as np
+
+
+def rle_encode(mask):
+    mask = np.asarray(mask)
+    padded = np.concatenate([[0], mask, [0]])
+    edges = np.flatnonzero(padded[1:] != padded[:-1]) + 1
+    edges[1::2] -= edges[::2]
+    return dict(length=mask.shape[0], counts=' '.join(str(x) for x in edges))
+
+
+def rle_encode_runs(length, starts, lengths):
+    """Same dict from 0-based run starts and lengths (already sorted)."""
+    flat = np.empty(2 * len(starts), dtype=np.int64)
+    flat[0::2] = np.asarray(starts, dtype=np.int64) + 1
+    flat[1::2] = lengths
+    return dict(length=int(length), counts=' '.join(map(str, flat.tolist())))
+
+
+def rle_decode(rle):
+    tok = rle['counts'].split()
+    starts = np.asarray(tok[0::2], dtype=np.int64) - 1
+    lens = np.asarray(tok[1::2], dtype=np.int64)
+    mask = np.zeros(rle['length'], dtype=np.uint8)
+    for lo, n in zip(starts, lens):
+        mask[lo:lo + n] = 1
+    return mask

@@ -228,7 +228,7 @@ def test_bfs_cluster_multi_segment_equals_per_class():
     # segments are kept apart by giving each its own "batch" id
     idx, sl = ops.ballquery_batch_p(t(xyz), t(seg), t(np.array([0, n], np.int32)), 0.04, 300)
     thr = np.array([50.0, 120.0, 10.0], np.float32)
-    ci, co = ops.bfs_cluster_segments(idx, sl, t(thr), t(seg), True)
+    ci, co = ops.bfs_cluster_segments(idx, sl, t(thr), t(seg))
     # reference: one call per class on the class-local sub-problem, then merged (softgroup.py:464-473)
     exp_idx, exp_off, base, nclu = [], [0], 0, 0
     for s in range(3):

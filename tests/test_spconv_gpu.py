@@ -1,0 +1,184 @@
+"""GPU parity tests of the sparse-conv layer (spconv.pytorch subset): rulebooks bit-exact vs the
+CPU oracle, conv outputs within 1e-4 (fp32; the summation order differs by design) vs the oracle,
+the dense torch.nn.functional golden vectors and an unfused PyTorch fp32 reference."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import oracle
+import softgroup_amd.spconv.pytorch as spconv
+from softgroup_amd.spconv import core
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = dict(atol=1e-4, rtol=1e-4)   # north-star tolerance for float features
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _scene(rng, n, extent, B=1):
+    """random surface-ish active set: unique voxels in first-seen order"""
+    pts = rng.random((n, 3)) * extent
+    pts[:, 2] = (np.sin(pts[:, 0] * 0.3) + np.cos(pts[:, 1] * 0.2)) * 3 + extent[2] / 2 + rng.normal(0, 0.6, n)
+    v = np.clip(np.floor(pts), 0, np.array(extent) - 1).astype(np.int64)
+    b = np.sort(rng.integers(0, B, n))
+    key = ((b * extent[0] + v[:, 0]) * extent[1] + v[:, 1]) * extent[2] + v[:, 2]
+    _, first = np.unique(key, return_index=True)
+    first = np.sort(first)
+    return np.concatenate([b[first, None], v[first]], 1).astype(np.int32)
+
+
+def test_subm_rulebook_and_plan_exact():
+    rng = np.random.default_rng(0)
+    shape = [131, 97, 41]
+    idx = _scene(rng, 60000, shape, B=2)
+    rule = core.SubMRule(t(idx), shape)
+    nbr = rule.plan.nbr.cpu().numpy()
+    assert np.array_equal(nbr, oracle.subm_rulebook(idx, shape))
+    order = rule.plan.order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(idx)))
+    mask = ((nbr >= 0) << np.arange(27)).sum(1).astype(np.uint32)
+    assert (np.diff(mask[order].astype(np.int64)) >= 0).all()          # sorted by mask
+    tm = rule.plan.tile_mask.cpu().numpy().view(np.uint32)
+    pad = (-len(order)) % 32
+    exp = np.bitwise_or.reduce(np.concatenate([mask[order], np.zeros(pad, np.uint32)]).reshape(-1, 32), 1)
+    assert np.array_equal(tm, exp)
+
+
+def test_down_rulebook_exact_incl_odd_extent_drop():
+    rng = np.random.default_rng(1)
+    shape = [129, 65, 33]                           # odd: last plane of every axis is dropped
+    idx = _scene(rng, 40000, shape, B=3)
+    idx[:50, 1] = 128
+    rule = core.DownRule(t(idx), shape, 3)
+    oi, in2out, child, oshape = oracle.down_rulebook(idx, shape)
+    assert rule.out_spatial_shape == oshape == [64, 32, 16]
+    assert np.array_equal(rule.in2out.cpu().numpy(), in2out)
+    assert np.array_equal(rule.out_indices.cpu().numpy(), oi)
+    assert np.array_equal(rule.plan.nbr.cpu().numpy(), child)
+    assert (in2out[:50] == -1).all()
+    inv = rule.inv_plan.nbr.cpu().numpy()
+    k = (idx[:, 1] & 1) * 4 + (idx[:, 2] & 1) * 2 + (idx[:, 3] & 1)
+    exp = np.full((len(idx), 8), -1, np.int32)
+    exp[np.arange(len(idx)), k] = in2out
+    assert np.array_equal(inv, exp)
+
+
+@pytest.mark.parametrize('cin,cout', [(6, 32), (32, 32), (64, 32), (64, 64), (96, 224), (32, 16), (3, 48)])
+def test_subm_conv_vs_oracle(cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = [64, 64, 32]
+    idx = _scene(rng, 9000, shape)
+    f = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    conv = spconv.SubMConv3d(cin, cout, kernel_size=3, padding=1, bias=False, indice_key='s').to(DEV)
+    with torch.no_grad():
+        out = conv(spconv.SparseConvTensor(t(f), t(idx), shape, 1))
+    ref = oracle.subm_conv3d(f, oracle.subm_rulebook(idx, shape), conv.weight.detach().cpu().numpy())
+    np.testing.assert_allclose(out.features.cpu().numpy(), ref, **TOL)
+    assert out.indices.data_ptr() == out.indices.data_ptr() and out.spatial_shape == shape
+
+
+def test_conv_golden_dense_equivalence(golden):
+    """SubM / strided / inverse against torch.nn.functional conv3d / conv_transpose3d on the dense
+    grid (fixtures from tests/golden/make_golden.py); extent 9 is odd -> last plane dropped."""
+    g = golden('sparse_conv_dense')
+    idx, f, shape = g['indices'], g['feats'], [int(s) for s in g['shape']]
+    x = spconv.SparseConvTensor(t(f), t(idx), shape, 2)
+    subm = spconv.SubMConv3d(32, 64, 3, padding=1, bias=False, indice_key='subm1').to(DEV)
+    down = spconv.SparseConv3d(32, 64, kernel_size=2, stride=2, bias=False, indice_key='spconv1').to(DEV)
+    inv = spconv.SparseInverseConv3d(64, 32, kernel_size=2, bias=False, indice_key='spconv1').to(DEV)
+    with torch.no_grad():
+        subm.weight.copy_(t(g['W_subm']))
+        down.weight.copy_(t(g['W_down']))
+        inv.weight.copy_(t(g['W_inv']))
+        y = subm(x)
+        np.testing.assert_allclose(y.features.cpu().numpy(), g['subm_out'], **TOL)
+        d = down(x)
+        assert d.spatial_shape == [4, 4, 4]
+        oi = d.indices.cpu().numpy()
+        np.testing.assert_allclose(d.features.cpu().numpy(),
+                                   g['down_dense'][oi[:, 0], oi[:, 1], oi[:, 2], oi[:, 3]], **TOL)
+        u = inv(d)
+        assert u.indices.data_ptr() == x.indices.data_ptr() and u.spatial_shape == shape
+        np.testing.assert_allclose(u.features.cpu().numpy(), g['inverse_out'], **TOL)
+
+
+def test_fused_bn_relu_residual_matches_unfused_torch():
+    rng = np.random.default_rng(9)
+    shape = [48, 48, 48]
+    idx = _scene(rng, 7000, shape)
+    f = rng.standard_normal((len(idx), 64)).astype(np.float32)
+    bn = nn.BatchNorm1d(64, eps=1e-4).to(DEV)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.normal_(1, 0.2)
+        bn.bias.normal_(0, 0.2)
+    conv = spconv.SubMConv3d(64, 32, 3, padding=1, bias=False, indice_key='k').to(DEV)
+    seq = spconv.SparseSequential(bn, nn.ReLU(), conv).eval()
+    x = spconv.SparseConvTensor(t(f), t(idx), shape, 1)
+    res = torch.randn(len(idx), 32, device=DEV)
+    with torch.no_grad():
+        fused = seq(x, residual=res).features
+        act = torch.relu(bn(x.features))
+        unf = conv(x.replace_feature(act)).features + res
+    np.testing.assert_allclose(fused.cpu().numpy(), unf.cpu().numpy(), **TOL)
+    # and against the CPU oracle on the same activations
+    ref = oracle.subm_conv3d(act.cpu().numpy(), oracle.subm_rulebook(idx, shape),
+                             conv.weight.detach().cpu().numpy()) + res.cpu().numpy()
+    np.testing.assert_allclose(fused.cpu().numpy(), ref, **TOL)
+    # absent neighbours must contribute 0, not act(0): a lone voxel sees only its centre tap
+    lone = spconv.SparseConvTensor(torch.zeros(1, 64, device=DEV), torch.tensor([[0, 5, 5, 5]], dtype=torch.int32, device=DEV), shape, 1)
+    with torch.no_grad():
+        y = seq(lone).features
+        exp = torch.relu(bn(lone.features)) @ conv.weight[:, 1, 1, 1, :].T
+    np.testing.assert_allclose(y.cpu().numpy(), exp.cpu().numpy(), **TOL)
+    # BN -> ReLU tail (output_layer) as one elementwise kernel
+    tail = spconv.SparseSequential(bn, nn.ReLU()).eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(tail(x).features.cpu().numpy(), act.cpu().numpy(), atol=1e-6, rtol=1e-6)
+
+
+def test_rulebook_shared_by_indice_key_and_empty_input():
+    shape = [32, 32, 32]
+    rng = np.random.default_rng(4)
+    idx = _scene(rng, 2000, shape)
+    x = spconv.SparseConvTensor(torch.randn(len(idx), 32, device=DEV), t(idx), shape, 1)
+    a = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key='subm1').to(DEV)
+    b = spconv.SubMConv3d(32, 64, 3, padding=1, bias=False, indice_key='subm1').to(DEV)
+    with torch.no_grad():
+        y = a(x)
+        rule = x.indice_dict['subm1']
+        z = b(y)
+        assert y.indice_dict is x.indice_dict and z.indice_dict['subm1'] is rule
+        e = spconv.SparseConvTensor(torch.zeros(0, 32, device=DEV), torch.zeros((0, 4), dtype=torch.int32, device=DEV), shape, 1)
+        assert a(e).features.shape == (0, 32)
+    inv = spconv.SparseInverseConv3d(32, 32, 2, bias=False, indice_key='nokey').to(DEV)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            inv(x)
+    with pytest.raises(NotImplementedError):
+        spconv.SparseConv3d(8, 8, kernel_size=3, stride=2)
+
+
+def test_large_scene_linearity_and_determinism():
+    """full-size property checks (sizes the oracle would take long on): conv(a*x + b*y) =
+    a*conv(x) + b*conv(y), and two runs are bit-identical (output-stationary, no atomics)."""
+    rng = np.random.default_rng(12)
+    shape = [320, 270, 150]
+    idx = _scene(rng, 200000, shape)
+    M = len(idx)
+    conv = spconv.SubMConv3d(64, 64, 3, padding=1, bias=False, indice_key='k').to(DEV)
+    x = torch.randn(M, 64, device=DEV)
+    y = torch.randn(M, 64, device=DEV)
+    ti = t(idx)
+    with torch.no_grad():
+        cx = conv(spconv.SparseConvTensor(x, ti, shape, 1)).features
+        cy = conv(spconv.SparseConvTensor(y, ti, shape, 1)).features
+        cxy = conv(spconv.SparseConvTensor(2 * x - 3 * y, ti, shape, 1)).features
+        cx2 = conv(spconv.SparseConvTensor(x, ti, shape, 1)).features
+    assert torch.equal(cx, cx2)
+    np.testing.assert_allclose(cxy.cpu().numpy(), (2 * cx - 3 * cy).cpu().numpy(), atol=2e-4, rtol=1e-4)
