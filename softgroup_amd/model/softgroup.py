@@ -1,0 +1,679 @@
+"""SoftGroup ``nn.Module`` hosted on the MI355X-native operators.
+
+The constructor signature, attribute/parameter names (checkpoint contract), the
+``model(batch, return_loss)`` entry and the result dictionaries are those of the reference
+(softgroup/model/softgroup.py); YAML ``model:`` sections are passed unchanged as kwargs.
+What differs is how the forward is driven:
+
+  * the backbone runs BN+ReLU+conv(+residual) as single HIP kernels (softgroup_amd.spconv);
+  * grouping handles ALL semantic classes in one ball-query + one clustering launch set on the
+    GPU (the reference loops over classes with a device->host copy and a single-threaded CPU BFS
+    per class, softgroup.py:433-473) -- proposals come out in the same order, bit for bit;
+  * proposal voxelisation builds its index on the GPU (reference: CPU hash, softgroup.py:703);
+  * instance masks are run-length encoded from sorted (proposal, point) pairs instead of dense
+    [nProposal, N] int masks (reference softgroup.py:568-603).
+"""
+import functools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..spconv import pytorch as spconv
+from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_runs
+from .blocks import MLP, ResidualBlock, UBlock
+
+
+def _cfg(cfg, key, default=None):
+    """config sections arrive as Munch / dict / namespace depending on the caller"""
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class SoftGroup(nn.Module):
+
+    def __init__(self,
+                 in_channels=3,
+                 channels=32,
+                 num_blocks=7,
+                 semantic_only=False,
+                 semantic_classes=20,
+                 instance_classes=18,
+                 semantic_weight=None,
+                 sem2ins_classes=[],
+                 ignore_label=-100,
+                 with_coords=True,
+                 grouping_cfg=None,
+                 instance_voxel_cfg=None,
+                 train_cfg=None,
+                 test_cfg=None,
+                 fixed_modules=[]):
+        super().__init__()
+        self.in_channels = in_channels + (3 if with_coords else 0)
+        self.channels = channels
+        self.num_blocks = num_blocks
+        self.semantic_only = semantic_only
+        self.semantic_classes = semantic_classes
+        self.instance_classes = instance_classes
+        self.semantic_weight = semantic_weight
+        self.sem2ins_classes = sem2ins_classes
+        self.ignore_label = ignore_label
+        self.with_coords = with_coords
+        self.grouping_cfg = grouping_cfg
+        self.instance_voxel_cfg = instance_voxel_cfg
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.fixed_modules = fixed_modules
+
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+
+        # sparse U-Net backbone
+        self.input_conv = spconv.SparseSequential(
+            spconv.SubMConv3d(self.in_channels, channels, kernel_size=3, padding=1, bias=False,
+                              indice_key='subm1'))
+        self.unet = UBlock([channels * (i + 1) for i in range(num_blocks)], norm_fn, 2,
+                           ResidualBlock, indice_key_id=1)
+        self.output_layer = spconv.SparseSequential(norm_fn(channels), nn.ReLU())
+
+        # point-wise heads
+        self.semantic_linear = MLP(channels, semantic_classes, norm_fn=norm_fn, num_layers=2)
+        self.offset_linear = MLP(channels, 3, norm_fn=norm_fn, num_layers=2)
+
+        # top-down refinement
+        if not semantic_only:
+            self.tiny_unet = UBlock([channels, 2 * channels], norm_fn, 2, ResidualBlock,
+                                    indice_key_id=11)
+            self.tiny_unet_outputlayer = spconv.SparseSequential(norm_fn(channels), nn.ReLU())
+            self.cls_linear = nn.Linear(channels, instance_classes + 1)
+            self.mask_linear = MLP(channels, instance_classes + 1, norm_fn=None, num_layers=2)
+            self.iou_score_linear = nn.Linear(channels, instance_classes + 1)
+
+        self.init_weights()
+        for name in fixed_modules:
+            for p in getattr(self, name).parameters():
+                p.requires_grad = False
+
+    # ------------------------------------------------------------------ housekeeping
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, MLP):
+                m.init_weights()
+        if not self.semantic_only:
+            for lin in (self.cls_linear, self.iou_score_linear):
+                nn.init.normal_(lin.weight, 0, 0.01)
+                nn.init.constant_(lin.bias, 0)
+
+    def train(self, mode=True):
+        super().train(mode)
+        for name in self.fixed_modules:      # frozen parts keep BN statistics frozen too
+            for m in getattr(self, name).modules():
+                if isinstance(m, nn.BatchNorm1d):
+                    m.eval()
+        return self
+
+    def forward(self, batch, return_loss=False):
+        return self.forward_train(**batch) if return_loss else self.forward_test(**batch)
+
+    # ------------------------------------------------------------------ inference
+    @cuda_cast
+    def forward_test(self, batch_idxs, voxel_coords, p2v_map, v2p_map, coords_float, feats,
+                     semantic_labels, instance_labels, pt_offset_labels, spatial_shape, batch_size,
+                     scan_ids, **kwargs):
+        tcfg = self.test_cfg
+        color_feats = feats
+        if self.with_coords:
+            feats = torch.cat((feats, coords_float), 1)
+        voxel_feats = ops.voxelization(feats, p2v_map)
+        x = spconv.SparseConvTensor(voxel_feats, voxel_coords.int(), spatial_shape, batch_size)
+
+        lvl_fusion = _cfg(tcfg, 'lvl_fusion', False)
+        x4_split = _cfg(tcfg, 'x4_split', False)
+        semantic_scores, pt_offsets, output_feats = self.forward_backbone(
+            x, v2p_map, x4_split=x4_split, lvl_fusion=lvl_fusion)
+        if x4_split:
+            coords_float = self.merge_4_parts(coords_float)
+            semantic_labels = self.merge_4_parts(semantic_labels)
+            instance_labels = self.merge_4_parts(instance_labels)
+            pt_offset_labels = self.merge_4_parts(pt_offset_labels)
+        semantic_preds = semantic_scores.max(1)[1]
+        tasks = _cfg(tcfg, 'eval_tasks')
+        ret = dict(scan_id=scan_ids[0])
+        if 'semantic' in tasks or 'panoptic' in tasks:
+            ret.update(semantic_labels=semantic_labels.cpu().numpy(),
+                       instance_labels=instance_labels.cpu().numpy())
+        if 'semantic' in tasks:
+            ret.update(self.get_point_wise_results(coords_float, color_feats, semantic_preds,
+                                                   pt_offsets, pt_offset_labels, v2p_map, lvl_fusion))
+        if not self.semantic_only:
+            if 'instance' in tasks or 'panoptic' in tasks:
+                if lvl_fusion:
+                    batch_idxs = x.indices[:, 0].int()
+                    coords_float = ops.voxelization(coords_float, p2v_map)
+                proposals_idx, proposals_offset = self.forward_grouping(
+                    semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
+                    lvl_fusion=lvl_fusion)
+                inst_feats, inst_map = self.clusters_voxelization(
+                    proposals_idx, proposals_offset, output_feats, coords_float,
+                    **self.instance_voxel_cfg)
+                _, cls_scores, iou_scores, mask_scores = self.forward_instance(inst_feats, inst_map)
+                pred_instances = self.get_instances(scan_ids[0], proposals_idx, semantic_scores,
+                                                    cls_scores, iou_scores, mask_scores,
+                                                    v2p_map=v2p_map, lvl_fusion=lvl_fusion)
+            if 'instance' in tasks:
+                ret.update(pred_instances=pred_instances,
+                           gt_instances=self.get_gt_instances(semantic_labels, instance_labels))
+            if 'panoptic' in tasks:
+                ret.update(panoptic_preds=self.panoptic_fusion(semantic_preds.cpu().numpy(),
+                                                               pred_instances))
+        return ret
+
+    def _unet_features(self, x):
+        return self.output_layer(self.unet(self.input_conv(x))).features
+
+    def forward_backbone(self, input, input_map, x4_split=False, lvl_fusion=False):
+        if x4_split:
+            assert not lvl_fusion, 'x4_split not support lvl_fusion'
+            output_feats = self.merge_4_parts(self.forward_4_parts(input, input_map))
+        else:
+            output_feats = self._unet_features(input)
+            if not lvl_fusion:
+                output_feats = _take_rows(output_feats, input_map)       # devoxelize
+        semantic_scores = self.semantic_linear(output_feats)
+        pt_offsets = self.offset_linear(output_feats)
+        return semantic_scores, pt_offsets, output_feats
+
+    def forward_4_parts(self, x, input_map):
+        """S3DIS: the scene arrives as 4 interleaved sub-clouds (batch ids 0..3); run them one at a
+        time with batch id 0 and stack the voxel features (reference softgroup.py:380-395)."""
+        outs = []
+        for part in range(4):
+            sel = x.indices[:, 0] == part
+            coords = x.indices[sel].clone()
+            coords[:, 0] = 0
+            sub = spconv.SparseConvTensor(x.features[sel], coords, x.spatial_shape, 1)
+            outs.append(self._unet_features(sub))
+        return _take_rows(torch.cat(outs, dim=0), input_map)
+
+    def merge_4_parts(self, x):
+        """inverse of the stride-4 interleave of data/s3dis.py:50-54"""
+        n = x.size(0)
+        sizes = [(n - p + 3) // 4 for p in range(4)]
+        out = torch.zeros_like(x)
+        for p, chunk in enumerate(torch.split(x, sizes)):
+            out[p::4] = chunk
+        return out
+
+    # ------------------------------------------------------------------ grouping
+    @force_fp32(apply_to=('semantic_scores', 'pt_offsets'))
+    def forward_grouping(self, semantic_scores, pt_offsets, batch_idxs, coords_float,
+                         grouping_cfg=None, lvl_fusion=False):
+        """-> proposals_idx int32 [S,2] (proposal id, point idx), proposals_offset int32 [nP+1].
+        Same values and order as the reference (softgroup.py:411-480), kept on the GPU."""
+        g = self.grouping_cfg
+        dev = semantic_scores.device
+        radius, mean_active = _cfg(g, 'radius'), _cfg(g, 'mean_active')
+        npoint_thr = _cfg(g, 'npoint_thr')
+        with_pyramid = _cfg(g, 'with_pyramid', False)
+        with_octree = _cfg(g, 'with_octree', False)
+        base_size = _cfg(g, 'pyramid_base_size', 0.02)
+        class_mean = torch.tensor(_cfg(g, 'class_numpoint_mean'), dtype=torch.float32)
+        assert class_mean.size(0) == self.semantic_classes
+        ignore = set(_cfg(g, 'ignore_classes'))
+        classes = [c for c in range(self.semantic_classes) if c not in ignore]
+        min_npoint = _cfg(self.test_cfg, 'min_npoint')
+        batch_size = int(batch_idxs.max()) + 1
+        scores = semantic_scores.softmax(dim=-1)
+
+        if with_pyramid or with_octree:
+            return self._grouping_per_class(scores, pt_offsets, batch_idxs, coords_float, classes,
+                                            class_mean, batch_size, radius, mean_active, npoint_thr,
+                                            with_pyramid, with_octree, base_size, min_npoint,
+                                            lvl_fusion)
+
+        # ---- all classes at once: segment s = position of the class in `classes`
+        cls_t = torch.tensor(classes, device=dev)
+        sel = scores[:, cls_t].t() > _cfg(g, 'score_thr')                  # [n_seg, N]
+        sel &= (sel.sum(1, keepdim=True) >= min_npoint)                    # small classes are skipped
+        seg, obj = sel.nonzero(as_tuple=True)                              # class-major, point-ascending
+        if obj.numel() == 0:
+            return (torch.zeros((0, 2), dtype=torch.int32, device=dev),
+                    torch.zeros((0, ), dtype=torch.int32, device=dev))
+        pts = (coords_float[obj] + pt_offsets[obj]).contiguous()
+        seg32 = seg.int()
+        key = (seg32 * batch_size + batch_idxs[obj].int()).contiguous()    # never mix classes/scenes
+        dummy_offsets = torch.zeros(2, dtype=torch.int32, device=dev)
+        nbr_idx, start_len = ops.ballquery_batch_p(pts, key, dummy_offsets, radius, mean_active)
+        # thr = npoint_thr (absolute) if class mean == -1 else npoint_thr * mean, fp32
+        m = class_mean[classes].numpy()
+        thr = np.where(m == np.float32(-1), np.float32(npoint_thr), np.float32(npoint_thr) * m)
+        seg_thr = torch.from_numpy(thr.astype(np.float32)).to(dev)
+        proposals_idx, proposals_offset = ops.bfs_cluster_segments(
+            nbr_idx, start_len, seg_thr, seg32.contiguous(), ops.LISTS_SORTED | ops.LISTS_RADIUS)
+        if proposals_idx.shape[0] == 0:
+            return proposals_idx, torch.zeros((0, ), dtype=torch.int32, device=dev)
+        proposals_idx[:, 1] = obj[proposals_idx[:, 1].long()].int()       # local -> scene point index
+        return proposals_idx, proposals_offset
+
+    def _grouping_per_class(self, scores, pt_offsets, batch_idxs, coords_float, classes, class_mean,
+                            batch_size, radius0, mean_active, npoint_thr, with_pyramid, with_octree,
+                            base_size, min_npoint, lvl_fusion):
+        """SoftGroup++ path (octree query / pyramid levels depend on the per-class point count,
+        reference softgroup.py:443-463): one class at a time, everything on the GPU."""
+        dev = scores.device
+        idx_list, off_list = [], []
+        n_prop, n_pts = 0, 0
+        for class_id in classes:
+            obj = (scores[:, class_id] > _cfg(self.grouping_cfg, 'score_thr')).nonzero().view(-1)
+            if obj.size(0) < min_npoint:
+                continue
+            b_, c_, o_ = batch_idxs[obj], coords_float[obj], pt_offsets[obj]
+            radius, level, l2p_map = radius0, 1, None
+            if with_pyramid:
+                level = self.get_level(c_.size(0))
+                radius = radius0 * level
+                if level > 1 or not lvl_fusion:
+                    c_, o_, b_, l2p_map = self.pyramid_map(c_, o_, b_, level, base_size)
+            offs = self.get_batch_offsets(b_, batch_size)
+            nbr, start_len = ops.ball_query((c_ + o_).contiguous(), b_.int().contiguous(), offs,
+                                            radius, mean_active, with_octree=with_octree)
+            pidx, poff = ops.bfs_cluster(class_mean, nbr, start_len, npoint_thr, class_id)
+            if l2p_map is not None:
+                pidx, poff = self.pyramid_inverse_map(pidx, poff, c_.size(0), l2p_map)
+            if pidx.size(0) == 0:
+                continue
+            pidx = pidx.clone()
+            pidx[:, 1] = obj[pidx[:, 1].long()].int()
+            pidx[:, 0] += n_prop
+            idx_list.append(pidx)
+            off_list.append(poff[1:] + n_pts if off_list else poff + n_pts)
+            n_prop += poff.numel() - 1
+            n_pts += pidx.size(0)
+        if not idx_list:
+            return (torch.zeros((0, 2), dtype=torch.int32, device=dev),
+                    torch.zeros((0, ), dtype=torch.int32, device=dev))
+        return torch.cat(idx_list, 0), torch.cat(off_list).int()
+
+    def get_level(self, num_points):
+        if num_points > 1000000:
+            return 3
+        return 2 if num_points > 100000 else 1
+
+    def pyramid_map(self, coords_float, pt_offsets, batch_idxs, level=1, base_size=0.02):
+        """coarse voxels for big classes; .long() truncates toward zero like the reference
+        (softgroup.py:491-498)"""
+        vox = (coords_float / (base_size * level)).long()
+        vox = torch.cat([batch_idxs[:, None].long(), vox], dim=1).contiguous()
+        out_coords, l2p_map, p2l_map = ops.voxelization_idx(vox, int(batch_idxs[-1].item()) + 1)
+        coords_float = ops.voxelization(coords_float.contiguous(), p2l_map)
+        pt_offsets = ops.voxelization(pt_offsets.contiguous(), p2l_map)
+        return coords_float, pt_offsets, out_coords[:, 0].int(), l2p_map
+
+    def pyramid_inverse_map(self, proposals_idx, proposals_offset, num_points, l2p_map):
+        """expand level voxels back to the class's points: proposal p contains point j iff it
+        contains voxel l2p_map[j]; rows ordered (proposal, point) ascending like the reference's
+        dense nonzero (softgroup.py:500-507)."""
+        dev = proposals_idx.device
+        n_prop = proposals_offset.numel() - 1
+        n_orig = l2p_map.numel()
+        member = torch.zeros((n_prop, num_points), dtype=torch.bool, device=dev)
+        member[proposals_idx[:, 0].long(), proposals_idx[:, 1].long()] = True
+        expanded = member[:, l2p_map.long().to(dev)]
+        assert expanded.shape[1] == n_orig
+        pidx = expanded.nonzero().int()
+        counts = expanded.sum(1)
+        poff = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
+        return pidx, poff
+
+    def get_batch_offsets(self, batch_idxs, bs):
+        counts = torch.bincount(batch_idxs.long(), minlength=bs)
+        offs = torch.zeros(bs + 1, dtype=torch.int32, device=batch_idxs.device)
+        offs[1:] = torch.cumsum(counts, 0)
+        return offs
+
+    # ------------------------------------------------------------------ proposal voxelisation
+    @force_fp32(apply_to='feats')
+    def clusters_voxelization(self, clusters_idx, clusters_offset, feats, coords, scale,
+                              spatial_shape, rand_quantize=False):
+        dev = feats.device
+        if clusters_idx.size(0) == 0:        # dummy 2-voxel tensor (reference softgroup.py:664-673)
+            far = spatial_shape - 1
+            dummy = torch.tensor([[0, 0, 0, 0], [0, far, far, far]], dtype=torch.int32, device=dev)
+            t = spconv.SparseConvTensor(feats[0:2], dummy, [spatial_shape] * 3, 1)
+            return t, feats.new_zeros((1, ), dtype=torch.long)
+
+        clusters_idx = clusters_idx.to(dev)
+        clusters_offset = clusters_offset.to(dev).int().contiguous()
+        cluster_of = clusters_idx[:, 0].long()
+        pt = clusters_idx[:, 1].contiguous()
+        feats = _take_rows(feats, pt)
+        coords = _take_rows(coords, pt)
+
+        lo = ops.sec_min(coords, clusters_offset)
+        hi = ops.sec_max(coords, clusters_offset)
+        # 0.01 keeps voxel coords < spatial_shape
+        cscale = 1 / ((hi - lo) / spatial_shape).max(1)[0] - 0.01
+        cscale = torch.clamp(cscale, min=None, max=scale)
+        lo = lo * cscale[:, None]
+        hi = hi * cscale[:, None]
+        coords = coords * cscale[cluster_of][:, None]
+        if rand_quantize:
+            span = hi - lo
+            lo -= torch.clamp(spatial_shape - span - 0.001, min=0) * torch.rand(3, device=dev)
+            lo -= torch.clamp(spatial_shape - span + 0.001, max=0) * torch.rand(3, device=dev)
+        coords -= lo[cluster_of]
+        assert coords.shape.numel() == ((coords >= 0) * (coords < spatial_shape)).sum()
+        vox = torch.cat([cluster_of.view(-1, 1), coords.long()], 1).contiguous()
+
+        n_prop = int(clusters_offset.numel()) - 1          # == int(clusters_idx[-1,0]) + 1
+        out_coords, inp_map, out_map = ops.voxelization_idx(vox, n_prop)
+        out_feats = ops.voxelization(feats, out_map)
+        t = spconv.SparseConvTensor(out_feats, out_coords.int(), [spatial_shape] * 3, n_prop)
+        return t, inp_map
+
+    @force_fp32(apply_to=('x'))
+    def global_pool(self, x, expand=False):
+        ids = x.indices[:, 0]
+        counts = torch.bincount(ids.long(), minlength=x.batch_size)
+        offsets = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
+        pooled = ops.global_avg_pool(x.features.contiguous(), offsets)
+        if not expand:
+            return pooled
+        x.features = torch.cat((x.features, pooled[ids.long()]), dim=1)
+        return x
+
+    def forward_instance(self, inst_feats, inst_map):
+        feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
+        inst_map = inst_map.long()
+        mask_scores = self.mask_linear(feats.features)[inst_map]
+        instance_batch_idxs = feats.indices[:, 0][inst_map]
+        pooled = self.global_pool(feats)
+        return instance_batch_idxs, self.cls_linear(pooled), self.iou_score_linear(pooled), mask_scores
+
+    # ------------------------------------------------------------------ results
+    @force_fp32(apply_to=('semantic_preds', 'offset_preds'))
+    def get_point_wise_results(self, coords_float, color_feats, semantic_preds, offset_preds,
+                               offset_labels, v2p_map, lvl_fusion):
+        if lvl_fusion:
+            semantic_preds = semantic_preds[v2p_map.long()]
+            offset_preds = offset_preds[v2p_map.long()]
+        return dict(coords_float=coords_float.cpu().numpy(), color_feats=color_feats.cpu().numpy(),
+                    semantic_preds=semantic_preds.cpu().numpy(),
+                    offset_preds=offset_preds.cpu().numpy(),
+                    offset_labels=offset_labels.cpu().numpy())
+
+    @force_fp32(apply_to=('semantic_scores', 'cls_scores', 'iou_scores', 'mask_scores'))
+    def get_instances(self, scan_id, proposals_idx, semantic_scores, cls_scores, iou_scores,
+                      mask_scores, v2p_map=None, lvl_fusion=False):
+        """Same instances, order and RLE strings as the reference (softgroup.py:537-604).  For
+        instance class i a proposal survives iff cls_score > cls_score_thr and its mask
+        (mask_score > mask_score_thr) has >= min_npoint points; masks are encoded from sorted
+        (proposal, point) pairs -- no dense [nProposal, N] matrix is built."""
+        if proposals_idx.size(0) == 0:
+            return []
+        tcfg = self.test_cfg
+        dev = cls_scores.device
+        n_inst, n_pts = cls_scores.size(0), semantic_scores.size(0)
+        n_out = v2p_map.numel() if lvl_fusion else n_pts
+        cls_prob = cls_scores.softmax(1)
+        sem_pred = semantic_scores.max(1)[1]
+        prop, pt = proposals_idx[:, 0].long().to(dev), proposals_idx[:, 1].long().to(dev)
+        if lvl_fusion:
+            # every voxel stands for the points mapped to it: expand pairs voxel -> points
+            order = torch.argsort(v2p_map.long(), stable=True)
+            vcount = torch.bincount(v2p_map.long(), minlength=n_pts)
+            vstart = torch.cumsum(vcount, 0) - vcount
+        cls_all, score_all, runs = [], [], []
+        for i in range(self.instance_classes):
+            if i in self.sem2ins_classes:
+                m = (sem_pred == i)
+                if lvl_fusion:
+                    m = m[v2p_map.long()]
+                cls_all.append(torch.tensor([i + 1], dtype=torch.long))
+                score_all.append(torch.tensor([1.], dtype=torch.float32))
+                runs.append(_runs_of_pairs(torch.zeros_like(m.nonzero().view(-1)),
+                                           m.nonzero().view(-1), 1))
+                continue
+            score = cls_prob[:, i] * iou_scores[:, i].clamp(0, 1)
+            on = mask_scores[:, i] > _cfg(tcfg, 'mask_score_thr')
+            p_on, q_on = prop[on], pt[on]
+            if lvl_fusion:
+                rep = vcount[q_on]
+                p_on = torch.repeat_interleave(p_on, rep)
+                base = torch.repeat_interleave(vstart[q_on], rep)
+                within = torch.arange(p_on.numel(), device=dev) - torch.repeat_interleave(
+                    torch.cumsum(rep, 0) - rep, rep)
+                q_on = order[base + within]
+            # a (proposal, point) pair can repeat only if the proposal lists a point twice: it cannot
+            npoint = torch.bincount(p_on, minlength=n_inst)
+            keep = (cls_prob[:, i] > _cfg(tcfg, 'cls_score_thr')) & (npoint >= _cfg(tcfg, 'min_npoint'))
+            kept = keep.nonzero().view(-1)
+            new_id = torch.full((n_inst, ), -1, dtype=torch.long, device=dev)
+            new_id[kept] = torch.arange(kept.numel(), device=dev)
+            sel = new_id[p_on] >= 0
+            cls_all.append(torch.full((kept.numel(), ), i + 1, dtype=torch.long))
+            score_all.append(score[kept].cpu())
+            runs.append(_runs_of_pairs(new_id[p_on[sel]], q_on[sel], kept.numel()))
+        cls_pred = torch.cat(cls_all).numpy()
+        score_pred = torch.cat(score_all).numpy()
+        instances, k = [], 0
+        for starts, lens, bounds in runs:
+            for j in range(len(bounds) - 1):
+                a, b = bounds[j], bounds[j + 1]
+                instances.append(dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
+                                      pred_mask=rle_encode_runs(n_out, starts[a:b], lens[a:b])))
+                k += 1
+        return instances
+
+    def panoptic_fusion(self, semantic_preds, instance_preds):
+        """paste instances by descending confidence (reference softgroup.py:606-639)"""
+        cls_offset = self.semantic_classes - self.instance_classes - 1
+        panoptic_cls = semantic_preds.copy().astype(np.uint32)
+        panoptic_ids = np.zeros_like(semantic_preds).astype(np.uint32)
+        taken = np.zeros_like(semantic_preds, dtype=bool)
+        next_id = 1
+        for i in np.argsort([x['conf'] for x in instance_preds])[::-1]:
+            inst = instance_preds[i]
+            mask = rle_decode(inst['pred_mask']).astype(bool)
+            overlap = (mask * taken).sum()
+            if overlap / (mask.sum() + 1e-5) > _cfg(self.test_cfg, 'panoptic_skip_iou'):
+                continue
+            paste = mask * (~taken)
+            panoptic_cls[paste] = inst['label_id'] + cls_offset
+            panoptic_ids[paste] = next_id
+            taken[paste] = 1
+            next_id += 1
+        ignore = (panoptic_cls >= 11) & (panoptic_ids == 0)     # thing classes without an id
+        out = (panoptic_cls & 0xFFFF) | (panoptic_ids << 16)
+        out[ignore] = self.semantic_classes
+        return out.astype(np.uint32)
+
+    def get_gt_instances(self, semantic_labels, instance_labels):
+        """ScanNet encoding sem*1000 + inst, 0 = ignore (reference softgroup.py:641-653)"""
+        shift = self.semantic_classes - self.instance_classes
+        sem = semantic_labels - shift + 1
+        sem[sem < 0] = 0
+        instance_labels += 1
+        gt = sem * 1000 + instance_labels
+        gt[instance_labels < 0] = 0
+        return gt.cpu().numpy()
+
+    # ------------------------------------------------------------------ training
+    @cuda_cast
+    def forward_train(self, batch_idxs, voxel_coords, p2v_map, v2p_map, coords_float, feats,
+                      semantic_labels, instance_labels, instance_pointnum, instance_cls,
+                      pt_offset_labels, spatial_shape, batch_size, **kwargs):
+        losses = {}
+        if self.with_coords:
+            feats = torch.cat((feats, coords_float), 1)
+        voxel_feats = ops.voxelization(feats, p2v_map)
+        x = spconv.SparseConvTensor(voxel_feats, voxel_coords.int(), spatial_shape, batch_size)
+        semantic_scores, pt_offsets, output_feats = self.forward_backbone(x, v2p_map)
+        losses.update(self.point_wise_loss(semantic_scores, pt_offsets, semantic_labels,
+                                           instance_labels, pt_offset_labels))
+        if not self.semantic_only:
+            with torch.no_grad():
+                proposals_idx, proposals_offset = self.forward_grouping(
+                    semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float,
+                    self.grouping_cfg)
+            max_prop = _cfg(self.train_cfg, 'max_proposal_num')
+            if proposals_offset.shape[0] > max_prop:
+                proposals_offset = proposals_offset[:max_prop + 1]
+                proposals_idx = proposals_idx[:int(proposals_offset[-1])]
+                assert proposals_idx.shape[0] == proposals_offset[-1]
+            inst_feats, inst_map = self.clusters_voxelization(
+                proposals_idx, proposals_offset, output_feats, coords_float, rand_quantize=True,
+                **self.instance_voxel_cfg)
+            instance_batch_idxs, cls_scores, iou_scores, mask_scores = self.forward_instance(
+                inst_feats, inst_map)
+            losses.update(self.instance_loss(cls_scores, mask_scores, iou_scores, proposals_idx,
+                                             proposals_offset, instance_labels, instance_pointnum,
+                                             instance_cls, instance_batch_idxs))
+        return self.parse_losses(losses)
+
+    def point_wise_loss(self, semantic_scores, pt_offsets, semantic_labels, instance_labels,
+                        pt_offset_labels):
+        weight = None
+        if self.semantic_weight:
+            weight = torch.tensor(self.semantic_weight, dtype=torch.float, device=semantic_scores.device)
+        losses = dict(semantic_loss=F.cross_entropy(semantic_scores, semantic_labels, weight=weight,
+                                                    ignore_index=self.ignore_label))
+        pos = instance_labels != self.ignore_label
+        if pos.sum() == 0:
+            losses['offset_loss'] = 0 * pt_offsets.sum()
+        else:
+            losses['offset_loss'] = F.l1_loss(pt_offsets[pos], pt_offset_labels[pos],
+                                              reduction='sum') / pos.sum()
+        return losses
+
+    @force_fp32(apply_to=('cls_scores', 'mask_scores', 'iou_scores'))
+    def instance_loss(self, cls_scores, mask_scores, iou_scores, proposals_idx, proposals_offset,
+                      instance_labels, instance_pointnum, instance_cls, instance_batch_idxs):
+        if proposals_idx.size(0) == 0 or (instance_cls != self.ignore_label).sum() == 0:
+            zero = mask_scores.sum() * 0
+            return dict(cls_loss=cls_scores.sum() * 0, mask_loss=zero,
+                        iou_score_loss=iou_scores.sum() * 0, num_pos=zero, num_neg=zero)
+        dev = cls_scores.device
+        tc = self.train_cfg
+        pidx = proposals_idx[:, 1].int().to(dev).contiguous()
+        poff = proposals_offset.to(dev).int().contiguous()
+        instance_pointnum = instance_pointnum.int().contiguous()
+        ious_on_cluster = ops.get_mask_iou_on_cluster(pidx, poff, instance_labels, instance_pointnum)
+
+        fg = instance_cls != self.ignore_label                 # drop background GT columns
+        fg_cls = instance_cls[fg]
+        fg_ious = ious_on_cluster[:, fg]
+        n_prop, n_gt = fg_ious.shape
+        assigned = fg_ious.new_full((n_prop, ), -1, dtype=torch.long)
+        max_iou, argmax_iou = fg_ious.max(1)
+        pos = max_iou >= _cfg(tc, 'pos_iou_thr')
+        assigned[pos] = argmax_iou[pos]
+        if _cfg(tc, 'match_low_quality', False):               # best proposal of each GT is positive
+            gt_max, gt_arg = fg_ious.max(0)
+            min_pos = _cfg(tc, 'min_pos_thr', 0)
+            for g in range(n_gt):
+                if gt_max[g] >= min_pos:
+                    assigned[gt_arg[g]] = g
+
+        # classification: 0..K-1 foreground, K background
+        labels = fg_cls.new_full((n_prop, ), self.instance_classes)
+        pos = assigned >= 0
+        labels[pos] = fg_cls[assigned[pos]]
+        losses = dict(cls_loss=F.cross_entropy(cls_scores, labels))
+
+        # mask loss on the score slice of the assigned class
+        per_point_cls = labels[instance_batch_idxs.long()]
+        rows = torch.arange(per_point_cls.size(0), device=dev)
+        mask_sig = mask_scores.sigmoid()[rows, per_point_cls]
+        mask_label = ops.get_mask_label(pidx, poff, instance_labels, instance_cls, instance_pointnum,
+                                        ious_on_cluster, _cfg(tc, 'pos_iou_thr'))
+        weight = (mask_label != -1).float()
+        mask_label[mask_label == -1.] = 0.5                    # ignored points: value irrelevant
+        mask_loss = F.binary_cross_entropy(mask_sig, mask_label, weight=weight, reduction='sum')
+        losses['mask_loss'] = mask_loss / (weight.sum() + 1)
+
+        # IoU-score regression against the IoU of the predicted mask
+        ious = ops.get_mask_iou_on_pred(pidx, poff, instance_labels, instance_pointnum,
+                                        mask_sig.detach().contiguous())
+        gt_ious, _ = ious[:, fg].max(1)
+        rows = torch.arange(labels.size(0), device=dev)
+        w = (labels < self.instance_classes).float()
+        iou_loss = F.mse_loss(iou_scores[rows, labels], gt_ious, reduction='none')
+        losses['iou_score_loss'] = (iou_loss * w).sum() / (w.sum() + 1)
+        losses['num_pos'] = (labels < self.instance_classes).sum().float()
+        losses['num_neg'] = (labels >= self.instance_classes).sum().float()
+        return losses
+
+    def parse_losses(self, losses):
+        """-> (total loss, dict of python floats averaged over ranks).  The reference issues one
+        all-reduce per scalar plus one for the key count (softgroup.py:281-295); here the key count
+        and all scalars travel in ONE packed all-reduce over RCCL."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        packed = torch.stack([v.detach().float() for v in log_vars.values()] +
+                             [loss.new_tensor(float(len(log_vars)))])
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size()
+            dist.all_reduce(packed)
+            assert int(packed[-1].item()) == len(log_vars) * world, \
+                (f'loss log variables are different across GPUs!\nrank {dist.get_rank()} '
+                 f'len(log_vars): {len(log_vars)} keys: ' + ','.join(log_vars.keys()))
+            packed = packed / world
+        vals = packed[:-1].tolist()
+        return loss, OrderedDict((k, vals[i]) for i, k in enumerate(log_vars.keys()))
+
+
+# ------------------------------------------------------------------------------------------------
+def _take_rows(feats, index):
+    """feats[index] through the HIP row-gather (devoxelize, softgroup.py:374,677-678); keeps
+    autograd by falling back to torch indexing only when a gradient is required."""
+    if feats.requires_grad and torch.is_grad_enabled():
+        return feats[index.long()]
+    from .. import _lib as L
+    feats = feats.contiguous()
+    if feats.dtype != torch.float32 or not feats.is_cuda:
+        return feats[index.long()]
+    index = index.contiguous()
+    out = torch.empty((index.numel(), feats.shape[1]), dtype=torch.float32, device=feats.device)
+    fn = L.lib().sg_gather_rows_i64idx_f32 if index.dtype == torch.int64 else L.lib().sg_gather_rows_f32
+    if index.dtype not in (torch.int64, torch.int32):
+        index = index.int()
+    L.check(fn(L.ptr(feats), L.ptr(index), index.numel(), feats.shape[1], L.ptr(out), L.stream()),
+            'sg_gather_rows')
+    return out
+
+
+def _runs_of_pairs(group, point, n_groups):
+    """(group, point) pairs -> runs of consecutive points per group.
+    Returns numpy (starts, lengths, bounds) with runs of group g in [bounds[g], bounds[g+1])."""
+    if group.numel() == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(n_groups + 1, np.int64)
+    big = int(point.max().item()) + 2
+    key, _ = torch.sort(group * big + point)
+    g, p = key // big, key % big
+    new_run = torch.ones_like(key, dtype=torch.bool)
+    new_run[1:] = (key[1:] != key[:-1] + 1) | (g[1:] != g[:-1])
+    first = new_run.nonzero().view(-1)
+    starts = p[first]
+    ends = torch.cat([first[1:], first.new_tensor([key.numel()])])
+    lens = ends - first
+    run_group = g[first]
+    bounds = torch.searchsorted(run_group, torch.arange(n_groups + 1, device=group.device))
+    return starts.cpu().numpy(), lens.cpu().numpy(), bounds.cpu().numpy()

@@ -1,0 +1,134 @@
+"""Deterministic synthetic inputs of the shapes BASELINE.json names (no datasets offline).
+
+S1  BASELINE config 1: 20k uniform points in a 2.56 m cube, 0.02 m voxels
+S2  BASELINE config 2 proxy: 150k-point "room shell" (SURVEY App. D), ScanNet-like
+G1  grouping-head input: 40 Gaussian blobs + uniform noise, 50k points
+
+``make_batch`` assembles the batch dictionary exactly as the reference's ``collate_fn`` does
+(softgroup/data/custom.py:196-256), including the CPU ``voxelization_idx`` call.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+SCANNET_MODEL_CFG = dict(
+    channels=32, num_blocks=7, semantic_classes=20, instance_classes=18, sem2ins_classes=[],
+    semantic_only=False, ignore_label=-100,
+    grouping_cfg=dict(score_thr=0.2, radius=0.04, mean_active=300,
+                      class_numpoint_mean=[-1., -1., 3917., 12056., 2303., 8331., 3948., 3166.,
+                                           5629., 11719., 1003., 3317., 4912., 10221., 3889., 4136.,
+                                           2120., 945., 3967., 2589.],
+                      npoint_thr=0.05, ignore_classes=[0, 1]),
+    instance_voxel_cfg=dict(scale=50, spatial_shape=20),
+    train_cfg=dict(max_proposal_num=200, pos_iou_thr=0.5),
+    test_cfg=dict(x4_split=False, cls_score_thr=0.001, mask_score_thr=-0.5, min_npoint=100,
+                  eval_tasks=['semantic', 'instance']),
+    fixed_modules=['input_conv', 'unet', 'output_layer', 'semantic_linear', 'offset_linear'])
+"""configs/softgroup/softgroup_scannet.yaml `model:` section (reference), verbatim values."""
+
+
+def _shell(n, size, rng):
+    """n points on the 6 faces of an axis-aligned box"""
+    size = np.array(size, dtype=np.float64)
+    area = np.array([size[1] * size[2]] * 2 + [size[0] * size[2]] * 2 + [size[0] * size[1]] * 2)
+    face = rng.choice(6, size=n, p=area / area.sum())
+    p = rng.random((n, 3)) * size
+    p[np.arange(n), face // 2] = (face % 2) * size[face // 2]
+    return p
+
+
+def scene_s1(seed=0, n=20000):
+    rng = np.random.default_rng(seed)
+    xyz = (rng.random((n, 3)) * 2.56).astype(np.float32)
+    rgb = rng.standard_normal((n, 3)).astype(np.float32)
+    return xyz, rgb
+
+
+def scene_s2(seed=1, n=150000, room_scale=1.0):
+    """room shell + 12 box-shaped objects; returns xyz, rgb and a synthetic instance labelling.
+    ``room_scale`` shrinks the room so that smaller test scenes keep the ScanNet-like surface
+    density (~900 pts/m^2 at n=150k, scale 1) that makes the 4 cm neighbour graph connected."""
+    rng = np.random.default_rng(seed)
+    n_room = int(n * 0.6)
+    per_obj = (n - n_room) // 12
+    room = np.array([6, 5, 2.7]) * room_scale
+    parts = [_shell(n_room, room, rng)]
+    inst = [np.full(n_room, -100, np.int64)]
+    for i in range(12):
+        sz = rng.uniform(0.4, 1.5, 3) * room_scale
+        sz[2] = rng.uniform(0.4, 1.0) * room_scale
+        origin = np.array([rng.uniform(0, room[0] - sz[0]), rng.uniform(0, room[1] - sz[1]), 0])
+        parts.append(_shell(per_obj, sz, rng) + origin)
+        inst.append(np.full(per_obj, i, np.int64))
+    xyz = np.concatenate(parts)
+    xyz = (xyz + rng.normal(0, 0.003, xyz.shape)).astype(np.float32)
+    rgb = rng.uniform(-1, 1, xyz.shape).astype(np.float32)
+    return xyz, rgb, np.concatenate(inst)
+
+
+def scene_g1(seed=2, blobs=40, per_blob=1000, noise=10000, sigma=0.03):
+    rng = np.random.default_rng(seed)
+    ext = np.array([6, 5, 2.7])
+    ctr = rng.random((blobs, 3)) * ext
+    pts = [ctr[i] + rng.normal(0, sigma, (per_blob, 3)) for i in range(blobs)]
+    pts.append(rng.random((noise, 3)) * ext)
+    xyz = np.concatenate(pts).astype(np.float32)
+    return xyz[rng.permutation(len(xyz))]
+
+
+def make_batch(xyz, rgb, scale=50, min_spatial=128, instance_labels=None, semantic_labels=None,
+               scan_id='synthetic_0000'):
+    """One-scene batch dict with the keys/dtypes of collate_fn (data/custom.py:240-256)."""
+    n = xyz.shape[0]
+    xyz64 = xyz.astype(np.float64)
+    coord = torch.from_numpy(np.floor((xyz64 - xyz64.min(0)) * scale).astype(np.int64))
+    coords = torch.cat([torch.zeros(n, 1, dtype=torch.int64), coord], 1)          # [N,4] batch 0
+    spatial_shape = np.clip((coords.max(0)[0][1:] + 1).numpy(), min_spatial, None)
+    voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(coords.contiguous(), 1)
+    if instance_labels is None:
+        instance_labels = np.full(n, -100, np.int64)
+    if semantic_labels is None:
+        semantic_labels = np.where(instance_labels >= 0, 2 + instance_labels % 18, 0).astype(np.int64)
+    inst_ids = np.unique(instance_labels[instance_labels >= 0])
+    pointnum = np.array([(instance_labels == i).sum() for i in inst_ids], np.int32)
+    inst_cls = np.array([semantic_labels[instance_labels == i][0] - 2 for i in inst_ids], np.int64)
+    center = np.zeros((n, 3), np.float32)
+    for i in inst_ids:
+        m = instance_labels == i
+        center[m] = xyz[m].mean(0)
+    pt_offset_labels = np.where((instance_labels >= 0)[:, None], center - xyz, 0).astype(np.float32)
+    return dict(
+        scan_ids=[scan_id], coords=coords, batch_idxs=coords[:, 0].int(), voxel_coords=voxel_coords,
+        p2v_map=p2v_map, v2p_map=v2p_map, coords_float=torch.from_numpy(xyz),
+        feats=torch.from_numpy(rgb), semantic_labels=torch.from_numpy(semantic_labels),
+        instance_labels=torch.from_numpy(instance_labels),
+        instance_pointnum=torch.from_numpy(pointnum), instance_cls=torch.from_numpy(inst_cls),
+        pt_offset_labels=torch.from_numpy(pt_offset_labels), spatial_shape=spatial_shape,
+        batch_size=1)
+
+
+def build_model(cfg=None, seed=0, device='cuda', head_std=20.0):
+    """Random-init SoftGroup (reference init scheme) with non-trivial eval-mode BatchNorm
+    statistics (running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5)).
+
+    The reference initialises the last layer of the semantic head with std 0.01
+    (blocks.py:26), which on untrained weights gives a uniform softmax (1/20 < score_thr = 0.2)
+    and therefore NO grouping work.  ``head_std`` re-draws that one layer with std 20 (logit std ~8) so the
+    untrained network produces peaky, spatially varying scores and the grouping head, proposal
+    voxelisation and tiny U-Net see a realistic load.  Pass ``head_std=None`` for the untouched
+    reference init."""
+    from .model import SoftGroup
+    torch.manual_seed(seed)
+    cfg = dict(SCANNET_MODEL_CFG if cfg is None else cfg)
+    model = SoftGroup(**cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+        if head_std is not None:
+            w = model.semantic_linear[-1].weight
+            w.copy_(torch.randn(w.shape, generator=g) * head_std)
+    return model.to(device).eval()

@@ -1,0 +1,112 @@
+"""Stage-wise parity of the HIP-hosted SoftGroup forward against the CPU restatement of the
+reference model (oracle/model.py), same weights (state_dict) and same synthetic scene.
+
+Float features within 1e-4 (north-star tolerance); integer products bit-exact when both sides
+are fed identical inputs -- each stage therefore takes the GPU's output of the previous stage as
+its input on both sides (a 1e-6 difference in a softmax score may otherwise flip a point across
+score_thr and change cluster membership on one side only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.model import OracleSoftGroup, SparseT
+from softgroup_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+@pytest.fixture(scope='module')
+def setup():
+    xyz, rgb, inst = synthetic.scene_s2(seed=3, n=30000, room_scale=0.45)
+    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    model = synthetic.build_model(seed=0)
+    ora = OracleSoftGroup(model.state_dict(), synthetic.SCANNET_MODEL_CFG)
+    return batch, model, ora
+
+
+def _gpu_stages(model, batch):
+    with torch.no_grad():
+        b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        from softgroup_amd import ops
+        import softgroup_amd.spconv.pytorch as spconv
+        feats = torch.cat((b['feats'], b['coords_float']), 1)
+        vf = ops.voxelization(feats, b['p2v_map'])
+        x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], 1)
+        sem, off, out_feats = model.forward_backbone(x, b['v2p_map'])
+        pidx, poff = model.forward_grouping(sem, off, b['batch_idxs'], b['coords_float'],
+                                            model.grouping_cfg)
+        inst, inst_map = model.clusters_voxelization(pidx, poff, out_feats, b['coords_float'],
+                                                     **model.instance_voxel_cfg)
+        _, cls_s, iou_s, mask_s = model.forward_instance(inst, inst_map)
+        preds = model.get_instances('s', pidx, sem, cls_s, iou_s, mask_s)
+    return dict(sem=sem, off=off, feats=out_feats, pidx=pidx, poff=poff, inst=inst,
+                inst_map=inst_map, cls=cls_s, iou=iou_s, mask=mask_s, preds=preds)
+
+
+def test_stagewise_parity(setup):
+    batch, model, ora = setup
+    g = _gpu_stages(model, batch)
+    n = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+    # (1) backbone + point-wise heads: fp32 tolerance
+    sem, off, feats = ora.point_wise(batch)
+    np.testing.assert_allclose(n(g['feats']), feats, **TOL)
+    np.testing.assert_allclose(n(g['sem']), sem, **TOL)
+    np.testing.assert_allclose(n(g['off']), off, **TOL)
+
+    # (2) grouping from the SAME scores/offsets: bit-exact proposals (membership and order)
+    pidx, poff = ora.grouping(n(g['sem']), n(g['off']), batch['batch_idxs'], batch['coords_float'])
+    assert pidx.shape[0] > 1000 and len(poff) > 3, 'scene must exercise the grouping head'
+    assert np.array_equal(n(g['pidx']), pidx)
+    assert np.array_equal(n(g['poff']), poff)
+
+    # (3) proposal voxelisation from the same proposals/features: indices exact, features 1e-4
+    inst, inst_map = ora.clusters_voxelization(pidx, poff, n(g['feats']), batch['coords_float'])
+    assert np.array_equal(n(g['inst'].indices), inst.indices)
+    assert np.array_equal(n(g['inst_map']), inst_map)
+    np.testing.assert_allclose(n(g['inst'].features), inst.features, **TOL)
+
+    # (4) tiny U-Net + heads on the GPU's voxel features
+    inst_same = SparseT(n(g['inst'].features), inst.indices, inst.spatial_shape, inst.batch_size)
+    cls_s, iou_s, mask_s = ora.instance_heads(inst_same, inst_map)
+    np.testing.assert_allclose(n(g['cls']), cls_s, **TOL)
+    np.testing.assert_allclose(n(g['iou']), iou_s, **TOL)
+    np.testing.assert_allclose(n(g['mask']), mask_s, **TOL)
+
+    # (5) instance extraction + RLE from identical scores: identical labels and masks
+    ref = ora.get_instances('s', pidx, n(g['sem']), n(g['cls']), n(g['iou']), n(g['mask']))
+    got = g['preds']
+    assert len(got) == len(ref) and len(ref) > 0
+    for a, b in zip(got, ref):
+        assert a['label_id'] == b['label_id'] and a['pred_mask'] == b['pred_mask']
+        assert abs(float(a['conf']) - float(b['conf'])) < 1e-6
+
+
+def test_forward_test_entry_and_determinism(setup):
+    batch, model, _ = setup
+    with torch.no_grad():
+        r1 = model(batch)
+        r2 = model(batch)
+    assert r1['scan_id'] == 'synthetic_0000'
+    assert {'semantic_preds', 'offset_preds', 'pred_instances', 'gt_instances'} <= set(r1)
+    assert len(r1['pred_instances']) == len(r2['pred_instances'])
+    for a, b in zip(r1['pred_instances'], r2['pred_instances']):
+        assert a['pred_mask'] == b['pred_mask'] and a['conf'] == b['conf']
+    assert np.array_equal(r1['semantic_preds'], r2['semantic_preds'])
+
+
+def test_state_dict_contract():
+    """parameter names/shapes of SURVEY App. A (what reference checkpoints contain)"""
+    model = synthetic.build_model(device='cpu')
+    sd = model.state_dict()
+    assert sd['input_conv.0.weight'].shape == (32, 3, 3, 3, 6)
+    assert sd['unet.blocks.block0.conv_branch.2.weight'].shape == (32, 3, 3, 3, 32)
+    assert sd['unet.conv.2.weight'].shape == (64, 2, 2, 2, 32)
+    assert sd['unet.deconv.2.weight'].shape == (32, 2, 2, 2, 64)
+    assert sd['unet.blocks_tail.block0.i_branch.0.weight'].shape == (32, 1, 1, 1, 64)
+    assert sd['unet.u.u.u.u.u.u.blocks.block1.conv_branch.5.weight'].shape == (224, 3, 3, 3, 224)
+    assert sd['tiny_unet.blocks.block0.conv_branch.0.weight'].shape == (32,)
+    assert sd['mask_linear.2.weight'].shape == (19, 32) and sd['iou_score_linear.weight'].shape == (19, 32)
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == 30839600, n_params
