@@ -227,11 +227,14 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
  * 32-row MFMA tile only visits kernel offsets some row of the tile really has.
  *   order[M_out]      : permutation (row ids sorted by their K-bit neighbour mask)
  *   tile_mask[ceil(M_out/32)] : OR of the masks of the tile's rows
+ *   tile_order[ceil(M_out/32)]: tiles by descending number of offsets (heaviest first), so the
+ *                       dispatcher spreads heavy and light tiles evenly over the SIMDs
  * Row order behind the API is untouched: tile t computes rows order[32t .. 32t+31] and stores
  * them back at their own row index. */
 size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
 int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
-                   uint32_t *tile_mask, void *ws, size_t ws_bytes, sg_stream_t stream);
+                   uint32_t *tile_mask, int32_t *tile_order, void *ws, size_t ws_bytes,
+                   sg_stream_t stream);
 
 /* weight re-layout [Cout, K, Cin] (spconv "OKKKI", tools/convert_checkpoint.py:17-19) -> [K, Cin, Cout] */
 int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, float *w_kio,
@@ -240,14 +243,18 @@ int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, fl
 /* out[j,:] = (residual ? residual[j,:] : 0) + sum_k W[k] . act(in[nbr[j,k],:])
  *   act(x) = relu(x * bn_scale + bn_shift) when bn_scale != NULL (fused eval-mode BatchNorm1d +
  *   ReLU that precede every conv in blocks.py:57-70,99-119), identity otherwise.
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 32 == 0 for the MFMA
- * path; other shapes take the scalar path of the same kernel family. order/tile_mask from
- * sg_spconv_plan (NULL = natural order, all offsets). */
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 32 == 0 takes the MFMA
+ * path; other shapes the scalar path of the same operator.  order/tile_mask from sg_spconv_plan
+ * (NULL = natural order, all offsets).  Layers too small to fill the chip split the kernel
+ * offsets over several waves and reduce partial sums from `ws` in a fixed order; pass
+ * ws >= sg_spconv_conv_workspace_bytes(num_out_rows, cout) (ws = NULL disables the split). */
+size_t sg_spconv_conv_workspace_bytes(int num_out_rows, int cout);
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr,
                               int num_out_rows, int kvol, int cin, int cout, const float *w_kio,
                               const float *bn_scale, const float *bn_shift,
                               const float *residual, const int32_t *order,
-                              const uint32_t *tile_mask, float *out, sg_stream_t stream);
+                              const uint32_t *tile_mask, const int32_t *tile_order, float *out,
+                              void *ws, size_t ws_bytes, sg_stream_t stream);
 
 /* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):
  * out = relu(x*scale + shift) (relu optional). */
@@ -259,6 +266,17 @@ int sg_gather_rows_f32(const float *in, const int32_t *index, int64_t num_out_ro
                        float *out, sg_stream_t stream);
 int sg_gather_rows_i64idx_f32(const float *in, const int64_t *index, int64_t num_out_rows,
                               int channels, float *out, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Instance-mask run-length strings in the reference's wire format (softgroup/util/rle.py:5-19,
+ * called per instance from softgroup.py:595-603): "start len start len ..." with 1-based starts.
+ * runs of instance g = [bounds[g], bounds[g+1]) of (starts, lens), all host int64.
+ * Call with out = NULL to size (fills out_offsets[n_groups+1], byte offsets without terminators),
+ * then with a buffer of out_offsets[n_groups] bytes.
+ * ---------------------------------------------------------------------------------------- */
+int sg_rle_format_host(const int64_t *starts_host, const int64_t *lens_host,
+                       const int64_t *bounds_host, int n_groups, char *out_host,
+                       int64_t *out_offsets_host);
 
 #ifdef __cplusplus
 }

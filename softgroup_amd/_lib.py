@@ -52,10 +52,12 @@ SIGNATURES = {
     'sg_spconv_down_fill': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_inverse_rulebook': (_i, [_vp, _vp, _i, _vp, _vp]),
     'sg_spconv_plan_workspace_bytes': (_sz, [_i]),
-    'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_weight_to_kio': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),
     'sg_spconv_gather_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _vp]),
+                                       _vp, _vp, _vp, _sz, _vp]),
+    'sg_rle_format_host': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'sg_gather_rows_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'sg_gather_rows_i64idx_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
@@ -70,6 +72,9 @@ def lib():
     """The loaded library.  Raises if it has not been built (python -m softgroup_amd.build)."""
     global _lib
     if _lib is None:
+        # torch first: both link libamdhip64.so.7 and the process must end up with ONE HIP runtime
+        # (the one torch ships), otherwise streams/pointers cross runtimes.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise SoftGroupHipError(
                 f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/softgroup_hip.h"
@@ -157,6 +158,70 @@ int sg_octree_build_host(const float *points, const float *xyzwhl, int num_point
     fill[l + 1] += fill[l];
   }
   for (int i = 0; i < num_points; ++i) pt_inds[fill[leaf_of[i]]++] = i;
+  return SG_OK;
+}
+
+
+// Run-length strings of instance masks in the reference's wire format (util/rle.py:5-19:
+// "start len start len ..." with 1-based starts), for all instances of a scan at once.
+// runs of instance g are [bounds[g], bounds[g+1]) in (starts, lens).  Two calls: with out == NULL
+// it only fills out_offsets[n_groups+1] (byte offset of every string, no terminators); with a
+// buffer of out_offsets[n_groups] bytes it writes the text.  Multi-threaded: the reference does
+// this with a Python loop per instance (softgroup.py:595-603).
+static inline int dec_len(int64_t v) {
+  int n = 1;
+  while (v >= 10) { v /= 10; ++n; }
+  return n;
+}
+static inline char *put_dec(char *p, int64_t v) {
+  char tmp[24];
+  int n = 0;
+  do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t *bounds,
+                       int n_groups, char *out, int64_t *out_offsets) {
+  if (n_groups < 0 || !bounds || !out_offsets) {
+    sg::set_error("sg_rle_format_host: bad arguments");
+    return SG_ERR_ARG;
+  }
+  const int hw = static_cast<int>(std::thread::hardware_concurrency());
+  const int n_thr = std::max(1, std::min({hw > 0 ? hw : 1, 32, n_groups / 8 + 1}));
+  auto parallel = [&](auto &&fn) {
+    if (n_thr == 1) { fn(0, n_groups); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) {
+      const int lo = static_cast<int>(static_cast<int64_t>(n_groups) * t / n_thr);
+      const int hi = static_cast<int>(static_cast<int64_t>(n_groups) * (t + 1) / n_thr);
+      pool.emplace_back(fn, lo, hi);
+    }
+    for (auto &th : pool) th.join();
+  };
+  if (out == nullptr) {
+    parallel([&](int lo, int hi) {
+      for (int g = lo; g < hi; ++g) {
+        int64_t bytes = 0;
+        for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r)
+          bytes += dec_len(starts[r] + 1) + dec_len(lens[r]) + 2;
+        out_offsets[g + 1] = bytes > 0 ? bytes - 1 : 0;  // no trailing space
+      }
+    });
+    out_offsets[0] = 0;
+    for (int g = 0; g < n_groups; ++g) out_offsets[g + 1] += out_offsets[g];
+    return SG_OK;
+  }
+  parallel([&](int lo, int hi) {
+    for (int g = lo; g < hi; ++g) {
+      char *p = out + out_offsets[g];
+      for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r) {
+        if (r != bounds[g]) *p++ = ' ';
+        p = put_dec(p, starts[r] + 1);
+        *p++ = ' ';
+        p = put_dec(p, lens[r]);
+      }
+    }
+  });
   return SG_OK;
 }
 

@@ -6,17 +6,24 @@
 //
 //   out[j,:] = residual[j,:] + sum_k  act(in[nbr[j,k],:]) . W[k]        act = relu(x*s + b) | id
 //
-// MI355X mapping
-//   * a wave owns a tile of 32 output rows (rows taken in neighbour-mask-sorted order, so the
-//     tile skips kernel offsets none of its rows has) and ALL Cout columns: Cout/32 accumulators
-//     of v_mfma_f32_32x32x2_f32 (exact fp32 = fmaf chain; 64 FLOP/clk/SIMD, the fp32 peak);
-//   * a workgroup = 4 waves = 4 adjacent tiles shares each W[k] chunk through LDS;
-//   * gathered rows are fetched as whole 128-B lines (8 lanes x 16 B per row, 8 rows per load
-//     instruction), get the fused BatchNorm+ReLU on the way, and are staged in LDS with a +1
-//     padded stride so the MFMA A-operand column reads are bank-conflict free;
-//   * every output row is written exactly once, 128 B per half-wave (residual add fused).
-// HBM traffic per layer ~ P*Cin*4 (gathered lines) + M*Cout*4 (stores) + index tables, i.e. the
-// "gather/scatter" bytes B_gs of SURVEY 8(d); the weights (<= 8 MB) stay in L2/MALL.
+// MI355X mapping (v2: wave-private register pipeline, no LDS staging of operands, no barriers
+// in the main loop -- sparse tiles have ragged depth, so lock-stepping waves wastes the machine)
+//   * work unit = one wave = (tile of 32 output rows in neighbour-mask-sorted order) x (up to NBW
+//     32-column blocks of Cout) x (a slice of the kernel offsets when the layer is too small to
+//     fill 256 CUs otherwise).  The tile's 27-bit mask says which offsets exist at all.
+//   * v_mfma_f32_32x32x2_f32 (exact fp32 = fmaf chain, 64 FLOP/clk/SIMD).  The reduction index
+//     of a 16-channel slice is permuted so that lane (h, i) owns channels c0+8h .. c0+8h+7 of
+//     gathered row i: its A operands for 8 MFMA steps are ONE contiguous 32-B read of that row
+//     (two dwordx4), and its B operands are coalesced 128-B reads of W[k][c][32 cols].
+//   * operands for slice t+1 are loaded into a second register set while slice t's MFMAs issue
+//     (an fp32 MFMA occupies the SIMD for 64 cycles, so one wave-wide load per MFMA is cheap);
+//     several waves per SIMD interleave freely because nothing synchronises them.
+//   * fused eval-BatchNorm+ReLU on the gathered rows (scale/shift broadcast from LDS), fused
+//     residual add, every output row written once, 128 B per half-wave.
+//   * tiny layers (deep U-Net levels: 18..800 rows) split the kernel offsets over several waves;
+//     partial sums go to a workspace and are reduced in a fixed order (deterministic).
+// HBM traffic per layer ~ P*Cin*4 (gathered rows) + M*Cout*4 (stores) + index tables, i.e. the
+// gather/scatter bytes B_gs of SURVEY 8(d); the weights (<= 8 MB) are served from L2/MALL.
 #include "common.h"
 
 namespace sg {
@@ -25,142 +32,204 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTileRows = 32;
 constexpr int kWavesPerWg = 4;
-constexpr int kChunk = 32;            // Cin slice per staging step
-constexpr int kAStride = kChunk + 1;  // padded LDS row stride (floats)
+constexpr int kCk = 16;        // channels per pipeline slice (8 per half-wave)
+constexpr int kMaxK = 27;
 
-template <int NB>
-__global__ void __launch_bounds__(256) gather_conv_mfma_kernel(
-    const float *__restrict__ in, const int32_t *__restrict__ nbr, int M_out, int K, int Cin,
-    const float *__restrict__ w_kio, const float *__restrict__ bn_scale,
-    const float *__restrict__ bn_shift, const float *__restrict__ residual,
-    const int32_t *__restrict__ order, const uint32_t *__restrict__ tile_mask,
-    float *__restrict__ out) {
-  constexpr int Cout = NB * 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *w_lds = smem;                                  // [kChunk][Cout]
-  float *a_lds_all = smem + kChunk * Cout;              // [4][32][kAStride]
-  int32_t *rows_all = reinterpret_cast<int32_t *>(a_lds_all + kWavesPerWg * kTileRows * kAStride);
-  int32_t *src_all = rows_all + kWavesPerWg * kTileRows;  // [4][32] gathered row for the current k
+struct ConvArgs {
+  const float *in;
+  const int32_t *nbr;
+  const float *w;         // [K][Cin][Cout]
+  const float *bn_scale;  // [Cin] or null
+  const float *bn_shift;
+  const float *residual;  // [M_out][Cout] or null (ignored when writing partials)
+  const int32_t *order;   // [M_out] or null
+  const uint32_t *tile_mask;
+  const int32_t *tile_order;  // [num_tiles] heaviest-first permutation or null
+  float *out;             // [M_out][Cout], or partials [ksplit][M_out][Cout]
+  int M_out, K, Cin, Cout;
+  int col_units;          // wave units along Cout
+  int blocks_per_unit;    // 32-col blocks per unit (last unit may have fewer)
+  int ksplit;             // slices of the kernel-offset range
+  int k_per_split;
+};
 
+template <int NBW, bool VEC>
+__global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // LDS: per-wave neighbour table [32][K] + bn scale/shift [2][CinPad]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float *a_lds = a_lds_all + wave * kTileRows * kAStride;
-  int32_t *rows = rows_all + wave * kTileRows;
-  int32_t *src = src_all + wave * kTileRows;
+  const int cin_pad = (p.Cin + kCk - 1) / kCk * kCk;
+  float *bn_lds = reinterpret_cast<float *>(smem_raw);            // [2][cin_pad]
+  int32_t *nbr_lds = reinterpret_cast<int32_t *>(bn_lds + 2 * cin_pad) + wave * kTileRows * kMaxK;
 
-  const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
-  const int tile = blockIdx.x * kWavesPerWg + wave;
-  const bool tile_valid = tile < num_tiles;
-
-  // output rows of this tile
-  if (lane < kTileRows) {
-    const int pos = tile * kTileRows + lane;
-    rows[lane] = (tile_valid && pos < M_out) ? (order ? order[pos] : pos) : -1;
+  if (p.bn_scale) {
+    for (int c = threadIdx.x; c < cin_pad; c += 256) {
+      bn_lds[c] = c < p.Cin ? p.bn_scale[c] : 0.f;
+      bn_lds[cin_pad + c] = c < p.Cin ? p.bn_shift[c] : 0.f;
+    }
   }
-  const uint32_t full = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
-  uint32_t my_mask = tile_valid ? (tile_mask ? tile_mask[tile] : full) : 0u;
-  // workgroup-wide union decides which W[k] chunks get staged
-  __shared__ uint32_t wg_mask_s[kWavesPerWg];
-  if (lane == 0) wg_mask_s[wave] = my_mask;
-  __syncthreads();
-  const uint32_t wg_mask = wg_mask_s[0] | wg_mask_s[1] | wg_mask_s[2] | wg_mask_s[3];
 
-  f32x16 acc[NB];
+  const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
+  const int units_per_tile = p.col_units * p.ksplit;
+  const long long unit = static_cast<long long>(blockIdx.x) * kWavesPerWg + wave;
+  const bool valid = unit < static_cast<long long>(num_tiles) * units_per_tile;
+  int tile = valid ? static_cast<int>(unit / units_per_tile) : 0;
+  if (valid && p.tile_order) tile = p.tile_order[tile];
+  const int sub = valid ? static_cast<int>(unit % units_per_tile) : 0;
+  const int cu = sub % p.col_units, ks = sub / p.col_units;
+  const int nb0 = cu * p.blocks_per_unit;
+  const int nbw = valid ? min(p.blocks_per_unit, p.Cout / 32 - nb0) : 0;
+  const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
+
+  const int arow = lane & 31, ahalf = lane >> 5;
+  // my output row (both halves hold the same rows) and the tile's neighbour table
+  int my_row = -1;
+  if (valid) {
+    const int pos = tile * kTileRows + arow;
+    if (pos < p.M_out) my_row = p.order ? p.order[pos] : pos;
+  }
+  if (valid) {
+    for (int e = lane; e < kTileRows * p.K; e += 64) {
+      const int r = e / p.K, k = e - r * p.K;
+      const int row = __shfl(my_row, r, 64);
+      nbr_lds[r * kMaxK + k] = row >= 0 ? p.nbr[static_cast<long long>(row) * p.K + k] : -1;
+    }
+  }
+  __syncthreads();  // bn_lds + nbr_lds visible (only barrier of the kernel)
+  if (!valid) return;
+
+  uint32_t mask = p.tile_mask ? p.tile_mask[tile] : 0xffffffffu;
+  mask &= (k_hi >= 32 ? 0xffffffffu : ((1u << k_hi) - 1u)) & ~((1u << k_lo) - 1u);
+
+  f32x16 acc[NBW];
 #pragma unroll
-  for (int n = 0; n < NB; ++n)
+  for (int n = 0; n < NBW; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  const int arow = lane & 31, ahalf = lane >> 5;
-  const bool cin_vec = (Cin % kChunk) == 0;
+  const int n_slices = cin_pad / kCk;
+  const int col = nb0 * 32 + arow;
 
-  for (int k = 0; k < K; ++k) {
-    if (!((wg_mask >> k) & 1u)) continue;
-    const bool mine = (my_mask >> k) & 1u;
-    if (mine && lane < kTileRows) {
-      const int r = rows[lane];
-      src[lane] = r >= 0 ? nbr[static_cast<int64_t>(r) * K + k] : -1;
+  // Column offsets of this unit's blocks; surplus blocks (n >= nbw) re-read the last real one so
+  // that every load below is unconditional (hipcc branches around predicated loads).  All element
+  // offsets are 32-bit (host checks the tensors are < 2^31 elements).
+  int coff[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) coff[n] = col + min(n, nbw - 1) * 32;
+
+  // raw loads of slice (k, s): A = 8 consecutive channels of the gathered row, B = 8 x NBW weights
+  auto load_raw = [&](int k, int s, float (&a)[8], float (&b)[NBW][8], bool &present) {
+    const int c = s * kCk + ahalf * 8;
+    const int src = nbr_lds[arow * kMaxK + k];
+    present = src >= 0;
+    const float *row = p.in + static_cast<unsigned>((present ? src : 0) * p.Cin + c);
+    if (VEC) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(row);
+      const float4 v1 = *reinterpret_cast<const float4 *>(row + 4);
+      a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+      a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = row[max(0, min(j, p.Cin - 1 - c))];
     }
-    for (int c0 = 0; c0 < Cin; c0 += kChunk) {
-      __syncthreads();  // previous chunk fully consumed (W and A), src[] visible
-      // ---- stage W[k][c0 .. c0+32) x Cout
-      {
-        const float *wsrc = w_kio + (static_cast<int64_t>(k) * Cin + c0) * Cout;
-        const int valid_rows = min(kChunk, Cin - c0);
-        for (int e = threadIdx.x * 4; e < kChunk * Cout; e += 256 * 4) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e / Cout < valid_rows) v = *reinterpret_cast<const float4 *>(wsrc + e);
-          *reinterpret_cast<float4 *>(w_lds + e) = v;
-        }
-      }
-      // ---- gather A: 32 rows x 32 channels of this wave's tile
-      if (mine) {
-        if (cin_vec) {
-          const int q = lane & 7;  // 16-B piece of the 128-B line
+    const int wbase = (k * p.Cin + c) * p.Cout;
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (lane >> 3);
-            const int s = src[r];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s >= 0) {
-              v = *reinterpret_cast<const float4 *>(in + static_cast<int64_t>(s) * Cin + c0 + q * 4);
-              if (bn_scale) {
-                const float4 sc = *reinterpret_cast<const float4 *>(bn_scale + c0 + q * 4);
-                const float4 sh = *reinterpret_cast<const float4 *>(bn_shift + c0 + q * 4);
-                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-                v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-                v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-              }
-            }
-            float *d = a_lds + r * kAStride + q * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-          }
-        } else {
-          const int c = lane & 31;
-#pragma unroll 4
-          for (int it = 0; it < 16; ++it) {
-            const int r = it * 2 + (lane >> 5);
-            const int s = src[r];
-            float v = 0.f;
-            if (s >= 0 && c0 + c < Cin) {
-              v = in[static_cast<int64_t>(s) * Cin + c0 + c];
-              if (bn_scale) v = fmaxf(fmaf(v, bn_scale[c0 + c], bn_shift[c0 + c]), 0.f);
-            }
-            a_lds[r * kAStride + c] = v;
-          }
-        }
-      }
-      __syncthreads();
-      // ---- 16 MFMA steps (K=2 each) over the chunk
-      if (mine) {
-#pragma unroll 4
-        for (int kk = 0; kk < kChunk; kk += 2) {
-          const float a = a_lds[arow * kAStride + kk + ahalf];
-          const float *wrow = w_lds + (kk + ahalf) * Cout + arow;
+    for (int j = 0; j < 8; ++j) {
+      const int wrow = VEC ? wbase + j * p.Cout : (k * p.Cin + min(c + j, p.Cin - 1)) * p.Cout;
 #pragma unroll
-          for (int n = 0; n < NB; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[n * 32], acc[n], 0, 0, 0);
-        }
+      for (int n = 0; n < NBW; ++n) b[n][j] = p.w[static_cast<unsigned>(wrow + coff[n])];
+    }
+  };
+  // fused BatchNorm+ReLU and zeroing of absent neighbours / padded channels, applied when the
+  // slice becomes current (so the wait for its loads sits AFTER the previous MFMA block)
+  auto finish = [&](int s, const float (&raw)[8], bool present, float (&a)[8]) {
+    const int c = s * kCk + ahalf * 8;
+    if (p.bn_scale) {
+      const float4 s0 = *reinterpret_cast<const float4 *>(bn_lds + c);
+      const float4 s1 = *reinterpret_cast<const float4 *>(bn_lds + c + 4);
+      const float4 h0 = *reinterpret_cast<const float4 *>(bn_lds + cin_pad + c);
+      const float4 h1 = *reinterpret_cast<const float4 *>(bn_lds + cin_pad + c + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaxf(fmaf(raw[j], sc[j], sh[j]), 0.f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = raw[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (present && (VEC || c + j < p.Cin)) ? a[j] : 0.f;
+  };
+
+  float a_cur[8], a_nxt[8];
+  float b_cur[NBW][8], b_nxt[NBW][8];
+  bool pres_nxt = false;
+
+  // flattened iteration space: (offset k in mask) x (slice s)
+  int k = mask ? __builtin_ctz(mask) : -1;
+  int s = 0;
+  if (k >= 0) load_raw(k, 0, a_nxt, b_nxt, pres_nxt);
+  while (k >= 0) {
+    finish(s, a_nxt, pres_nxt, a_cur);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) b_cur[n][j] = b_nxt[n][j];
+    // next (k, s) and its prefetch
+    int k2 = k, s2 = s + 1;
+    if (s2 == n_slices) {
+      s2 = 0;
+      const uint32_t rest = mask & ~((2u << k) - 1u);
+      k2 = rest ? __builtin_ctz(rest) : -1;
+    }
+    if (k2 >= 0) load_raw(k2, s2, a_nxt, b_nxt, pres_nxt);
+    __builtin_amdgcn_sched_barrier(0);   // loads are in flight ...
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b_cur[n][j], acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // ... while this block issues; consume them only after
+    k = k2;
+    s = s2;
+  }
+
+  // ---- epilogue: acc[n][reg] -> row (reg&3)+8*(reg>>2)+4*half, column nb0*32 + n*32 + arow
+  float *out = p.out + (p.ksplit > 1 ? static_cast<long long>(ks) * p.M_out * p.Cout : 0);
+  const bool add_res = p.residual != nullptr && p.ksplit == 1;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
+    const int row = __shfl(my_row, r, 64);
+    if (row < 0) continue;
+    const long long off = static_cast<long long>(row) * p.Cout + col;
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      if (n < nbw) {
+        float v = acc[n][reg];
+        if (add_res) v += p.residual[off + n * 32];
+        out[off + n * 32] = v;
       }
     }
   }
+}
 
-  // ---- epilogue: acc[n][reg] -> out[row (reg&3)+8*(reg>>2)+4*half][n*32 + col]
-  if (tile_valid) {
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
-      const int row = rows[r];
-      if (row < 0) continue;
-      float *o = out + static_cast<int64_t>(row) * Cout + arow;
-      const float *res = residual ? residual + static_cast<int64_t>(row) * Cout + arow : nullptr;
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        float v = acc[n][reg];
-        if (res) v += res[n * 32];
-        o[n * 32] = v;
-      }
+// fixed-order reduction of the offset-split partial sums (+ residual)
+__global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restrict__ partial,
+                                                         const float4 *__restrict__ residual,
+                                                         int ksplit, long long n4,
+                                                         float4 *__restrict__ out) {
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n4; t += gridDim.x * 256LL) {
+    float4 a = partial[t];
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 b = partial[s * n4 + t];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
+    if (residual) {
+      const float4 r = residual[t];
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    out[t] = a;
   }
 }
 
@@ -191,19 +260,12 @@ __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
   }
 }
 
-template <int NB>
-static int launch_mfma(const float *in, const int32_t *nbr, int M_out, int K, int Cin,
-                       const float *w_kio, const float *bn_scale, const float *bn_shift,
-                       const float *residual, const int32_t *order, const uint32_t *tile_mask,
-                       float *out, hipStream_t stream) {
-  constexpr int Cout = NB * 32;
-  const size_t lds = (kChunk * Cout + kWavesPerWg * kTileRows * kAStride) * sizeof(float) +
-                     2 * kWavesPerWg * kTileRows * sizeof(int32_t);
-  const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
-  const int grid = (num_tiles + kWavesPerWg - 1) / kWavesPerWg;
-  gather_conv_mfma_kernel<NB><<<grid, 256, lds, stream>>>(in, nbr, M_out, K, Cin, w_kio, bn_scale,
-                                                          bn_shift, residual, order, tile_mask, out);
-  return check_launch("sg_spconv_gather_conv_f32");
+template <int NBW>
+static void launch_v2(const ConvArgs &a, int grid, size_t lds, bool vec, hipStream_t stream) {
+  if (vec)
+    gather_conv_v2_kernel<NBW, true><<<grid, 256, lds, stream>>>(a);
+  else
+    gather_conv_v2_kernel<NBW, false><<<grid, 256, lds, stream>>>(a);
 }
 
 }  // namespace sg
@@ -212,32 +274,74 @@ using namespace sg;
 
 extern "C" {
 
+// workspace for the offset-split path: ksplit_max * M_out * Cout floats
+size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
+  const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
+  if (num_tiles * ((Cout + 31) / 32) >= 1024) return 256;   // big layers never split
+  return static_cast<size_t>(kMaxK) * M_out * Cout * sizeof(float) + 256;
+}
+
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
                               int K, int Cin, int Cout, const float *w_kio, const float *bn_scale,
                               const float *bn_shift, const float *residual, const int32_t *order,
-                              const uint32_t *tile_mask, float *out, sg_stream_t stream_) {
+                              const uint32_t *tile_mask, const int32_t *tile_order, float *out,
+                              void *ws, size_t ws_bytes, sg_stream_t stream_) {
   (void)num_in_rows;
-  SG_REQUIRE(M_out >= 0 && K >= 1 && K <= 32 && Cin >= 1 && Cout >= 1,
+  SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
              "sg_spconv_gather_conv_f32: bad arguments (M_out=%d K=%d Cin=%d Cout=%d)", M_out, K,
              Cin, Cout);
   SG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr),
              "sg_spconv_gather_conv_f32: bn_scale and bn_shift must come together");
   if (M_out == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
-  if (Cout % 32 == 0 && Cout <= 256) {
-    switch (Cout / 32) {
-#define SG_CASE(NB)                                                                              \
-  case NB:                                                                                       \
-    return launch_mfma<NB>(in, nbr, M_out, K, Cin, w_kio, bn_scale, bn_shift, residual, order,   \
-                           tile_mask, out, stream);
-      SG_CASE(1) SG_CASE(2) SG_CASE(3) SG_CASE(4) SG_CASE(5) SG_CASE(6) SG_CASE(7) SG_CASE(8)
-#undef SG_CASE
-    }
+  if (Cout % 32 != 0) {
+    gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
+                                stream>>>(in, nbr, M_out, K, Cin, Cout, w_kio, bn_scale, bn_shift,
+                                          residual, out);
+    return check_launch("sg_spconv_gather_conv_f32(scalar)");
   }
-  gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
-                              stream>>>(in, nbr, M_out, K, Cin, Cout, w_kio, bn_scale, bn_shift,
-                                        residual, out);
-  return check_launch("sg_spconv_gather_conv_f32(scalar)");
+  const int NB = Cout / 32;
+  const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
+  // ---- decomposition: aim at >= ~2048 waves; widest column block that still fills the chip
+  const int target = 2048;
+  int bpu = NB <= 4 ? NB : (NB + 1) / 2;          // blocks per unit (<= 4)
+  while (bpu > 1 && static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) < target) --bpu;
+  int col_units = (NB + bpu - 1) / bpu;
+  int ksplit = 1;
+  long long waves = static_cast<long long>(num_tiles) * col_units;
+  if (waves < target / 2) {
+    { long long want = (target / 2 + waves - 1) / waves; ksplit = static_cast<int>(want < K ? want : K); }
+    const size_t need = static_cast<size_t>(ksplit) * M_out * Cout * sizeof(float);
+    if (ksplit > 1 && (ws == nullptr || ws_bytes < need)) ksplit = 1;   // no scratch: stay exact
+  }
+  const int k_per_split = (K + ksplit - 1) / ksplit;
+  ksplit = (K + k_per_split - 1) / k_per_split;
+
+  ConvArgs a;
+  a.in = in; a.nbr = nbr; a.w = w_kio; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+  a.residual = residual; a.order = order; a.tile_mask = tile_mask; a.tile_order = tile_order;
+  a.out = ksplit > 1 ? static_cast<float *>(ws) : out;
+  a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
+  a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
+
+  const int cin_pad = (Cin + kCk - 1) / kCk * kCk;
+  const size_t lds = 2 * cin_pad * sizeof(float) + kWavesPerWg * kTileRows * kMaxK * sizeof(int32_t);
+  const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
+  const int grid = static_cast<int>((units + kWavesPerWg - 1) / kWavesPerWg);
+  const bool vec = (Cin % kCk) == 0;
+  switch (bpu) {
+    case 1: launch_v2<1>(a, grid, lds, vec, stream); break;
+    case 2: launch_v2<2>(a, grid, lds, vec, stream); break;
+    case 3: launch_v2<3>(a, grid, lds, vec, stream); break;
+    default: launch_v2<4>(a, grid, lds, vec, stream); break;
+  }
+  if (ksplit > 1) {
+    const long long n4 = static_cast<long long>(M_out) * Cout / 4;
+    conv_reduce_kernel<<<grid_for(n4, 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4 *>(ws), reinterpret_cast<const float4 *>(residual), ksplit, n4,
+        reinterpret_cast<float4 *>(out));
+  }
+  return check_launch("sg_spconv_gather_conv_f32");
 }
 
 }  // extern "C"

@@ -181,6 +181,28 @@ __global__ void __launch_bounds__(256) plan_tiles_kernel(const uint32_t *__restr
   if ((threadIdx.x & 31) == 0 && j < M) tile_mask[j >> 5] = m;
 }
 
+// tiles in descending order of work (number of kernel offsets present): with the heaviest
+// tiles dispatched first and workgroups handed to CUs round-robin, every SIMD ends up with a mix
+// of heavy and light waves instead of a tail of heavy ones (longest-processing-time-first).
+__global__ void __launch_bounds__(1024) plan_tile_order_kernel(const uint32_t *__restrict__ tile_mask,
+                                                              int num_tiles,
+                                                              int32_t *__restrict__ tile_order) {
+  // one workgroup: counting sort of the tiles by popcount, descending (order inside a bucket is
+  // irrelevant for load balance, so positions come from LDS atomics)
+  __shared__ int hist[33], base[33];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&hist[__popc(tile_mask[t])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 32; b >= 0; --b) { base[b] = run; run += hist[b]; }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < num_tiles; t += 1024)
+    tile_order[atomicAdd(&base[__popc(tile_mask[t])], 1)] = t;
+}
+
 __global__ void __launch_bounds__(256) weight_kio_kernel(const float *__restrict__ w, int cout, int K,
                                                         int cin, float *__restrict__ out) {
   const int64_t total = static_cast<int64_t>(cout) * K * cin;
@@ -289,8 +311,8 @@ size_t sg_spconv_plan_workspace_bytes(int M) {
   return 2 * align_up(nn * 4) + radix_sort_workspace_bytes(M) + 256;
 }
 
-int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *tile_mask, void *ws,
-                   size_t ws_bytes, sg_stream_t stream_) {
+int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *tile_mask,
+                   int32_t *tile_order, void *ws, size_t ws_bytes, sg_stream_t stream_) {
   SG_REQUIRE(M >= 0 && K >= 1 && K <= 32, "sg_spconv_plan: bad arguments (M=%d K=%d)", M, K);
   if (M == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
@@ -310,6 +332,8 @@ int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *t
   int rc = radix_sort_pairs(mask, row, M, K, rs_ws, rs_bytes, stream, &ms, &rs);
   if (rc != SG_OK) return rc;
   plan_tiles_kernel<<<grid, 256, 0, stream>>>(ms, rs, M, order, tile_mask);
+  if (tile_order)
+    plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tile_mask, (M + 31) / 32, tile_order);
   return check_launch("sg_spconv_plan");
 }
 

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..spconv import pytorch as spconv
-from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_runs
+from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs
 from .blocks import MLP, ResidualBlock, UBlock
 
 
@@ -425,8 +425,30 @@ class SoftGroup(nn.Module):
         n_inst, n_pts = cls_scores.size(0), semantic_scores.size(0)
         n_out = v2p_map.numel() if lvl_fusion else n_pts
         cls_prob = cls_scores.softmax(1)
-        sem_pred = semantic_scores.max(1)[1]
         prop, pt = proposals_idx[:, 0].long().to(dev), proposals_idx[:, 1].long().to(dev)
+        if not lvl_fusion and not self.sem2ins_classes:
+            # all instance classes in one pass: one sort, two host round trips
+            nc = self.instance_classes
+            on = mask_scores[:, :nc] > _cfg(tcfg, 'mask_score_thr')                 # [S, nc]
+            npoint = torch.zeros((n_inst, nc), dtype=torch.int32, device=dev)
+            npoint.index_add_(0, prop, on.int())
+            keep = (cls_prob[:, :nc] > _cfg(tcfg, 'cls_score_thr')) & \
+                (npoint >= _cfg(tcfg, 'min_npoint'))                                # [n_inst, nc]
+            kept = keep.t().nonzero()                       # (class, proposal), class-major order
+            n_kept = kept.size(0)
+            if n_kept == 0:
+                return []
+            idmap = torch.full((nc, n_inst), -1, dtype=torch.long, device=dev)
+            idmap[kept[:, 0], kept[:, 1]] = torch.arange(n_kept, device=dev)
+            e, c = (on & keep[prop]).nonzero(as_tuple=True)
+            starts, lens, bounds = _runs_of_pairs(idmap[c, prop[e]], pt[e], n_kept)
+            score = (cls_prob[:, :nc] * iou_scores[:, :nc].clamp(0, 1))[kept[:, 1], kept[:, 0]]
+            cls_pred = (kept[:, 0] + 1).cpu().numpy()
+            score_pred = score.cpu().numpy()
+            masks = rle_encode_many(n_out, starts, lens, bounds)
+            return [dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
+                         pred_mask=masks[k]) for k in range(n_kept)]
+        sem_pred = semantic_scores.max(1)[1]
         if lvl_fusion:
             # every voxel stands for the points mapped to it: expand pairs voxel -> points
             order = torch.argsort(v2p_map.long(), stable=True)

@@ -67,19 +67,22 @@ class SparseConvTensor:
 # ------------------------------------------------------------------------------------------------
 class _Plan:
     """gather table + mask-sorted tile plan for the implicit-GEMM kernel"""
-    __slots__ = ('nbr', 'order', 'tile_mask', 'num_out', 'kvol')
+    __slots__ = ('nbr', 'order', 'tile_mask', 'tile_order', 'num_out', 'kvol', '_pairs')
 
     def __init__(self, nbr, num_out, kvol):
         lib = L.lib()
         dev = nbr.device
         self.nbr, self.num_out, self.kvol = nbr, num_out, kvol
+        self._pairs = None
         self.order = torch.empty(num_out, dtype=torch.int32, device=dev)
         self.tile_mask = torch.empty((num_out + 31) // 32, dtype=torch.int32, device=dev)
+        self.tile_order = torch.empty((num_out + 31) // 32, dtype=torch.int32, device=dev)
         if num_out:
             nb = lib.sg_spconv_plan_workspace_bytes(num_out)
             ws = L.workspace(nb, dev)
             L.check(lib.sg_spconv_plan(L.ptr(nbr), num_out, kvol, L.ptr(self.order),
-                                       L.ptr(self.tile_mask), L.ptr(ws), nb, L.stream()),
+                                       L.ptr(self.tile_mask), L.ptr(self.tile_order), L.ptr(ws), nb,
+                                       L.stream()),
                     'sg_spconv_plan')
 
 
@@ -144,18 +147,56 @@ class DownRule:
 # ------------------------------------------------------------------------------------------------
 # the conv operator
 # ------------------------------------------------------------------------------------------------
+class ConvProfiler:
+    """Optional per-launch timing of the conv kernel with HIP events on the launch stream, plus the
+    algorithmic byte/flop counts of SURVEY 8(d):  B_gs = P*Cin*4 + M_out*Cout*4 + 8*P,
+    flops = 2*P*Cin*Cout  (P = active (in,out) pairs of the layer).  Used by bench.py."""
+
+    def __init__(self):
+        self.records = []      # (start_event, end_event, bytes, flops, tag)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _, _, _ in self.records)
+        return dict(launches=len(self.records), ms=ms,
+                    bytes=sum(r[2] for r in self.records), flops=sum(r[3] for r in self.records))
+
+
+PROFILER = None      # set to a ConvProfiler to record
+
+
+def _plan_pairs(plan):
+    if getattr(plan, '_pairs', None) is None:
+        plan._pairs = int((plan.nbr >= 0).sum().item())
+    return plan._pairs
+
+
 def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, residual=None):
     """out[j] = residual[j] + sum_k act(features[nbr[j,k]]) @ w_kio[k]   (fp32, HIP)"""
     lib = L.lib()
+    prof = PROFILER
+    if prof is not None:
+        P = _plan_pairs(plan)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
     cin = features.shape[1]
     out = torch.empty((plan.num_out, cout), dtype=torch.float32, device=features.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
+    nb = lib.sg_spconv_conv_workspace_bytes(plan.num_out, cout)
+    ws = L.workspace(nb, features.device) if nb > 256 else None
+    if prof is not None:
+        ev0.record()
     L.check(lib.sg_spconv_gather_conv_f32(
         L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
         L.ptr(w_kio), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(residual), L.ptr(plan.order),
-        L.ptr(plan.tile_mask), L.ptr(out), L.stream()), 'sg_spconv_gather_conv_f32')
+        L.ptr(plan.tile_mask), L.ptr(plan.tile_order), L.ptr(out), L.ptr(ws),
+        nb if ws is not None else 0, L.stream()),
+        'sg_spconv_gather_conv_f32')
+    if prof is not None:
+        ev1.record()
+        prof.records.append((ev0, ev1, P * cin * 4 + plan.num_out * cout * 4 + 8 * P,
+                             2 * P * cin * cout, (plan.kvol, cin, cout, plan.num_out)))
     return out
 
 
