@@ -32,7 +32,8 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 #define SG_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 struct BfsWs {
-  int32_t *parent, *lab, *label, *size, *cid, *coff, *owner, *seeds, *ebase, *wcnt, *asym_nodes;
+  int32_t *parent, *lab, *size, *cid, *coff, *owner, *seeds, *ebase, *wcnt, *asym_nodes;
+  int2 *label;  // (label, local slot)
   int32_t *counters;  // [0] #asym source nodes  [1] changed flag  [2] nCluster  [3] sumNPoint
   void *scan_ws;
   size_t scan_bytes;
@@ -43,7 +44,7 @@ static bool bfs_carve(void *ws, size_t ws_bytes, int n, BfsWs *w) {
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
   w->parent = a.take<int32_t>(nn);
   w->lab = a.take<int32_t>(nn);
-  w->label = a.take<int32_t>(nn);
+  w->label = a.take<int2>(nn);
   w->size = a.take<int32_t>(nn);
   w->cid = a.take<int32_t>(nn);
   w->coff = a.take<int32_t>(nn);
@@ -187,12 +188,13 @@ __global__ void __launch_bounds__(256) bfs_propagate_kernel(const int32_t *__res
 // ---------------------------------------------------------------- C. sizes / kept clusters
 __global__ void __launch_bounds__(256) bfs_label_kernel(int n, const int32_t *__restrict__ root_of,
                                                        const int32_t *__restrict__ lab,
-                                                       int32_t *__restrict__ label, int32_t *size) {
+                                                       int2 *__restrict__ label_lid, int32_t *size) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int l = lab[root_of[i]];
-  label[i] = l;
-  atomicAdd(&size[l], 1);
+  // (cluster label, slot of the point inside its cluster): the slot indexes the cluster's
+  // visited/claim array when that array lives in LDS during the ordered emission
+  label_lid[i] = make_int2(l, atomicAdd(&size[l], 1));
 }
 
 __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size) {
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size
 }
 
 // emit: cluster_offsets[cid+1] and the seed list
-__global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int32_t *__restrict__ label,
+__global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int2 *__restrict__ label,
                                                       const int32_t *__restrict__ size,
                                                       const int32_t *__restrict__ cid,
                                                       const int32_t *__restrict__ coff,
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int32_t *__r
                                                       int32_t *__restrict__ cluster_offsets) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) cluster_offsets[0] = 0;
-  if (i >= n || label[i] != i) return;
+  if (i >= n || label[i].x != i) return;
   const float thr = seg_thr[seg_of_point ? seg_of_point[i] : 0];
   if (static_cast<float>(size[i]) >= thr) {
     seeds[cid[i]] = i;
@@ -238,115 +240,154 @@ __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
   return carry + incl - v;
 }
 
+constexpr int kOwnCap = 16384;   // cluster sizes up to this keep their claim array in LDS (64 KB)
+constexpr int kFrontChunk = 2048;  // frontier nodes staged per chunk (st, len, edge base, winners)
+
+// One workgroup per kept cluster.  The output segment doubles as the FIFO queue (column 1 of
+// cluster_idxs).  Per BFS level:
+//   claim   every edge (frontier node rank, list position) proposes pos to its unvisited target
+//           with atomicMin -- on an LDS array indexed by the target's slot when the cluster has
+//           <= kOwnCap points, else on the global owner[] array;
+//   count   winners per frontier node (ballot + popcount), prefix over nodes;
+//   append  winners in edge order to the queue and mark them visited (-1).
+// Frontier nodes are processed in chunks of kFrontChunk whose (start, len, edge base) live in LDS.
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
-    const int32_t *__restrict__ label, const int32_t *__restrict__ seeds,
-    const int32_t *__restrict__ cluster_offsets, int n_cluster, int32_t *owner, int32_t *ebase,
-    int32_t *wcnt, int32_t *cluster_idxs) {
-  __shared__ int lds[kEmitWaves];
+    const int2 *__restrict__ label_lid, const int32_t *__restrict__ seeds,
+    const int32_t *__restrict__ cluster_offsets, int n_cluster, int32_t *owner_g,
+    int32_t *cluster_idxs) {
+  __shared__ int lds_scan[kEmitWaves];
+  __shared__ int own_lds[kOwnCap];
+  __shared__ int f_st[kFrontChunk], f_ln[kFrontChunk], f_eb[kFrontChunk], f_wc[kFrontChunk];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int c = blockIdx.x; c < n_cluster; c += gridDim.x) {
     const int seed = seeds[c];
     const int off = cluster_offsets[c];
+    const int size = cluster_offsets[c + 1] - off;
+    const bool own_in_lds = size <= kOwnCap;
     int32_t *Q = cluster_idxs + 2LL * off;  // pairs (cluster id, point); queue = column 1
-    int32_t *eb = ebase + off, *wc = wcnt + off;
+    if (own_in_lds)
+      for (int i = threadIdx.x; i < size; i += kEmitThreads) own_lds[i] = 0x7fffffff;
+    __syncthreads();
     if (threadIdx.x == 0) {
       SG_ST(&Q[0], c);
       SG_ST(&Q[1], seed);
-      SG_ST(&owner[seed], -1);
+      if (own_in_lds) own_lds[label_lid[seed].y] = -1; else SG_ST(&owner_g[seed], -1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    auto claim = [&](int v, int pos) {   // propose `pos` to an unvisited node of this cluster
+      const int2 ll = label_lid[v];
+      if (ll.x != seed) return;
+      if (own_in_lds) { if (own_lds[ll.y] > pos) atomicMin(&own_lds[ll.y], pos); }
+      else if (SG_LD(&owner_g[v]) > pos) atomicMin(&owner_g[v], pos);
+    };
+    auto owner_of = [&](int v) -> int {
+      const int2 ll = label_lid[v];
+      if (ll.x != seed) return -2;
+      return own_in_lds ? own_lds[ll.y] : SG_LD(&owner_g[v]);
+    };
+    auto mark_done = [&](int v) {
+      if (own_in_lds) own_lds[label_lid[v].y] = -1; else SG_ST(&owner_g[v], -1);
+    };
     int head = 0, tail = 1;
     while (head < tail) {
       const int L = tail - head;
-      // (1) edge base of every frontier node = exclusive prefix of list lengths
+      // stage chunk `ch` of the frontier: list start/len into LDS, edge base = carry + prefix
+      auto stage = [&](int ch, int carry_in) -> int {
+        const int q0 = ch * kFrontChunk, cnt = min(kFrontChunk, L - q0);
+        int carry = carry_in;
+        for (int b0 = 0; b0 < cnt; b0 += kEmitThreads) {
+          const int q = b0 + threadIdx.x;
+          int ln = 0;
+          if (q < cnt) {
+            const int u = SG_LD(&Q[2 * (head + q0 + q) + 1]);
+            f_st[q] = start_len[2 * u];
+            ln = start_len[2 * u + 1];
+            f_ln[q] = ln;
+          }
+          int tot;
+          const int ex = wg_excl_scan(ln, lds_scan, &tot);
+          if (q < cnt) f_eb[q] = carry + ex;
+          carry += tot;
+        }
+        __syncthreads();
+        return carry;
+      };
+      const int n_chunks = (L + kFrontChunk - 1) / kFrontChunk;
+      // ---- pass 1: claims
       int carry = 0;
-      for (int q0 = 0; q0 < L; q0 += kEmitThreads) {
-        const int q = q0 + threadIdx.x;
-        int ln = 0;
-        if (q < L) ln = start_len[2 * SG_LD(&Q[2 * (head + q) + 1]) + 1];
-        int tot;
-        const int ex = wg_excl_scan(ln, lds, &tot);
-        if (q < L) SG_ST(&eb[head + q], carry + ex);
-        carry += tot;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // (2) claim: every edge proposes its position to its (still unvisited) target
-      for (int q = head + wave; q < tail; q += kEmitWaves) {
-        const int u = SG_LD(&Q[2 * q + 1]);
-        const int st = start_len[2 * u], ln = start_len[2 * u + 1];
-        const int base = SG_LD(&eb[q]);
-        for (int p = lane; p < ln; p += 64) {
-          const int v = idx[st + p];
-          if (label[v] == seed && SG_LD(&owner[v]) > base + p) atomicMin(&owner[v], base + p);
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        carry = stage(ch, carry);
+        const int cnt = min(kFrontChunk, L - ch * kFrontChunk);
+        for (int q = wave; q < cnt; q += kEmitWaves) {
+          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          for (int p = lane; p < ln; p += 64) claim(idx[st + p], base + p);
         }
+        __syncthreads();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      // (3) winners per frontier node
-      for (int q = head + wave; q < tail; q += kEmitWaves) {
-        const int u = SG_LD(&Q[2 * q + 1]);
-        const int st = start_len[2 * u], ln = start_len[2 * u + 1];
-        const int base = SG_LD(&eb[q]);
-        int cnt = 0;
-        for (int p0 = 0; p0 < ln; p0 += 64) {
-          const int p = p0 + lane;
-          const bool win = p < ln && SG_LD(&owner[idx[st + p]]) == base + p;
-          cnt += __popcll(__ballot(win));
-        }
-        if (lane == 0) SG_ST(&wc[q], cnt);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // (4) output base of every frontier node (prefix of winner counts); reuse eb for it
+      // ---- pass 2: winners -> queue (chunks in order; `appended` is the running output base)
+      int appended = 0;
       carry = 0;
-      int total_new = 0;
-      for (int q0 = 0; q0 < L; q0 += kEmitThreads) {
-        const int q = q0 + threadIdx.x;
-        const int cnt = q < L ? SG_LD(&wc[head + q]) : 0;
-        int tot;
-        const int ex = wg_excl_scan(cnt, lds, &tot);
-        if (q < L) SG_ST(&wc[head + q], carry + ex);
-        carry += tot;
-      }
-      total_new = carry;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // (5) append the winners in edge order; mark them visited
-      for (int q = head + wave; q < tail; q += kEmitWaves) {
-        const int u = SG_LD(&Q[2 * q + 1]);
-        const int st = start_len[2 * u], ln = start_len[2 * u + 1];
-        const int base = SG_LD(&eb[q]);
-        int obase = tail + SG_LD(&wc[q]);
-        for (int p0 = 0; p0 < ln; p0 += 64) {
-          const int p = p0 + lane;
-          int v = 0;
-          bool win = false;
-          if (p < ln) {
-            v = idx[st + p];
-            win = SG_LD(&owner[v]) == base + p;
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        carry = stage(ch, carry);
+        const int cnt = min(kFrontChunk, L - ch * kFrontChunk);
+        for (int q = wave; q < cnt; q += kEmitWaves) {
+          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          int wins = 0;
+          for (int p0 = 0; p0 < ln; p0 += 64) {
+            const int p = p0 + lane;
+            wins += __popcll(__ballot(p < ln && owner_of(idx[st + p]) == base + p));
           }
-          const uint64_t bal = __ballot(win);
-          if (win) {
-            const int o = obase + mask_prefix(bal);
-            SG_ST(&Q[2 * o], c);
-            SG_ST(&Q[2 * o + 1], v);
-          }
-          obase += __popcll(bal);
+          if (lane == 0) f_wc[q] = wins;
         }
+        __syncthreads();
+        int chunk_new = 0;
+        for (int b0 = 0; b0 < cnt; b0 += kEmitThreads) {   // prefix of winner counts
+          const int q = b0 + threadIdx.x;
+          const int w_ = q < cnt ? f_wc[q] : 0;
+          int tot;
+          const int ex = wg_excl_scan(w_, lds_scan, &tot);
+          if (q < cnt) f_wc[q] = chunk_new + ex;
+          chunk_new += tot;
+        }
+        __syncthreads();
+        for (int q = wave; q < cnt; q += kEmitWaves) {
+          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          int obase = tail + appended + f_wc[q];
+          for (int p0 = 0; p0 < ln; p0 += 64) {
+            const int p = p0 + lane;
+            int v = 0;
+            bool win = false;
+            if (p < ln) {
+              v = idx[st + p];
+              win = owner_of(v) == base + p;
+            }
+            const uint64_t bal = __ballot(win);
+            if (win) {
+              const int o = obase + mask_prefix(bal);
+              SG_ST(&Q[2 * o], c);
+              SG_ST(&Q[2 * o + 1], v);
+            }
+            obase += __popcll(bal);
+          }
+        }
+        appended += chunk_new;
+        __syncthreads();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       // winners become visited only after every edge of the level has been examined
-      for (int o = tail + threadIdx.x; o < tail + total_new; o += kEmitThreads)
-        SG_ST(&owner[SG_LD(&Q[2 * o + 1])], -1);
+      for (int o = tail + threadIdx.x; o < tail + appended; o += kEmitThreads)
+        mark_done(SG_LD(&Q[2 * o + 1]));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       head = tail;
-      tail += total_new;
+      tail += appended;
     }
+    __syncthreads();
   }
 }
 
@@ -359,7 +400,7 @@ extern "C" {
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges) {
   (void)n_edges;
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
-  return 11 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) + 256;
+  return 12 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) + 256;
 }
 
 // Synchronises `stream` (the cluster count decides the size of the outputs).
@@ -406,10 +447,11 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
     }
     bfs_label_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab, w.label, w.size);
     // kept-cluster ids and offsets: two prefix sums over the seeds in index order
-    const int32_t *label = w.label, *size = w.size;
+    const int2 *label = w.label;
+    const int32_t *size = w.size;
     int32_t *cid = w.cid, *coff = w.coff;
     auto keep = [label, size, seg_of_point, seg_thr] __device__(int64_t i) -> int {
-      if (label[i] != static_cast<int32_t>(i)) return 0;
+      if (label[i].x != static_cast<int32_t>(i)) return 0;
       const float thr = seg_thr[seg_of_point ? seg_of_point[i] : 0];
       return static_cast<float>(size[i]) >= thr ? 1 : 0;  // bfs_cluster.cpp:73-81
     };
@@ -448,8 +490,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
                                                        seg_of_point, seg_thr, w.seeds,
                                                        cluster_offsets);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
-      bq_idxs, start_len, w.label, w.seeds, cluster_offsets, n_cluster, w.owner, w.ebase, w.wcnt,
-      cluster_idxs);
+      bq_idxs, start_len, w.label, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs);
   return check_launch("sg_bfs_cluster_emit");
 }
 

@@ -156,9 +156,58 @@ def main():
     out['inverse_out'] = inv           # rows on the dropped last plane are 0
     out.update(indices=idx, feats=f, W_subm=W, W_down=W2, W_inv=W3, shape=np.array([D, D, D]))
     np.savez_compressed(os.path.join(HERE, 'sparse_conv_dense.npz'), **out)
+    state_dict_contract()
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):
             print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, 'KiB')
+
+
+def state_dict_contract():
+    """Instantiate the REFERENCE's own SoftGroup class (softgroup/model/softgroup.py) on top of the
+    softgroup_amd.spconv / softgroup_amd.ops shims and record its state-dict keys and shapes: the
+    checkpoint contract our model must reproduce (tests/test_state_dict_contract.py)."""
+    import json
+    import types
+    import softgroup_amd.ops
+    import softgroup_amd.spconv
+    import softgroup_amd.spconv.pytorch
+    from softgroup_amd import synthetic
+    sys.modules['spconv'] = softgroup_amd.spconv
+    sys.modules['spconv.pytorch'] = softgroup_amd.spconv.pytorch
+    sys.modules['spconv.pytorch.modules'] = softgroup_amd.spconv.pytorch.modules
+    tb = types.ModuleType('tensorboardX')
+    tb.SummaryWriter = object
+    sys.modules['tensorboardX'] = tb
+    pkg = types.ModuleType('softgroup')
+    pkg.__path__ = ['/root/reference/softgroup']
+    sys.modules['softgroup'] = pkg
+    sys.modules['softgroup.ops'] = softgroup_amd.ops
+    from softgroup.model.softgroup import SoftGroup as RefSoftGroup
+
+    class NS(dict):
+        __getattr__ = dict.get
+
+    out = {}
+    variants = {
+        'scannet': dict(synthetic.SCANNET_MODEL_CFG),
+        'semantic_only_kitti_like': dict(synthetic.SCANNET_MODEL_CFG, in_channels=1, with_coords=False,
+                                         semantic_only=True, fixed_modules=[]),
+        'stpls3d_like': dict(synthetic.SCANNET_MODEL_CFG, channels=16, semantic_classes=15,
+                             instance_classes=14, fixed_modules=[]),
+    }
+    for name, cfg in variants.items():
+        if name == 'stpls3d_like':
+            cfg['grouping_cfg'] = dict(cfg['grouping_cfg'], class_numpoint_mean=[-1.] * 15)
+        c = dict(cfg)
+        for k in ('grouping_cfg', 'instance_voxel_cfg', 'train_cfg', 'test_cfg'):
+            c[k] = NS(c[k])
+        torch.manual_seed(0)
+        ref = RefSoftGroup(**c)
+        sd = ref.state_dict()
+        out[name] = dict(cfg={k: v for k, v in cfg.items()},
+                         keys=[[k, list(v.shape)] for k, v in sd.items()],
+                         checksum=float(sum(v.double().abs().sum() for v in sd.values())))
+    json.dump(out, open(os.path.join(HERE, 'state_dict_contract.json'), 'w'))
 
 
 if __name__ == '__main__':
