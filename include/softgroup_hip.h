@@ -225,15 +225,16 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
 
 /* Tile plan for the implicit-GEMM kernel: rows are processed in mask-sorted order so that a
  * 32-row MFMA tile only visits kernel offsets some row of the tile really has.
- *   order[M_out]      : permutation (row ids sorted by their K-bit neighbour mask)
- *   tile_mask[ceil(M_out/32)] : OR of the masks of the tile's rows
- *   tile_order[ceil(M_out/32)]: tiles by descending number of offsets (heaviest first), so the
- *                       dispatcher spreads heavy and light tiles evenly over the SIMDs
- * Row order behind the API is untouched: tile t computes rows order[32t .. 32t+31] and stores
+ * T = ceil(M_out/32) tiles, emitted heaviest first (descending number of offsets) so that the
+ * dispatcher spreads heavy and light tiles over the chip (longest-processing-time-first):
+ *   order[T*32]       : row ids of every tile (rows sorted by neighbour mask), -1 padding
+ *   tile_mask[T]      : OR of the masks of the tile's rows
+ *   nbr_tiles[T*32*K] : the tile's gather-table rows copied contiguously (-1 for padding rows)
+ * Row order behind the API is untouched: a tile computes rows order[32t .. 32t+31] and stores
  * them back at their own row index. */
 size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
 int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
-                   uint32_t *tile_mask, int32_t *tile_order, void *ws, size_t ws_bytes,
+                   uint32_t *tile_mask, int32_t *nbr_tiles, void *ws, size_t ws_bytes,
                    sg_stream_t stream);
 
 /* weight re-layout [Cout, K, Cin] (spconv "OKKKI", tools/convert_checkpoint.py:17-19) -> [K, Cin, Cout] */
@@ -244,8 +245,8 @@ int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, fl
  *   act(x) = relu(x * bn_scale + bn_shift) when bn_scale != NULL (fused eval-mode BatchNorm1d +
  *   ReLU that precede every conv in blocks.py:57-70,99-119), identity otherwise.
  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 32 == 0 takes the MFMA
- * path; other shapes the scalar path of the same operator.  order/tile_mask from sg_spconv_plan
- * (NULL = natural order, all offsets).  Layers too small to fill the chip split the kernel
+ * path; other shapes the scalar path of the same operator.  order/tile_mask/nbr_tiles from
+ * sg_spconv_plan (all NULL = natural order, all offsets, slower generic kernel).  Layers too small to fill the chip split the kernel
  * offsets over several waves and reduce partial sums from `ws` in a fixed order; pass
  * ws >= sg_spconv_conv_workspace_bytes(num_out_rows, cout) (ws = NULL disables the split). */
 size_t sg_spconv_conv_workspace_bytes(int num_out_rows, int cout);
@@ -253,7 +254,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                               int num_out_rows, int kvol, int cin, int cout, const float *w_kio,
                               const float *bn_scale, const float *bn_shift,
                               const float *residual, const int32_t *order,
-                              const uint32_t *tile_mask, const int32_t *tile_order, float *out,
+                              const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);
 
 /* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):

@@ -24,6 +24,8 @@
 //     partial sums go to a workspace and are reduced in a fixed order (deterministic).
 // HBM traffic per layer ~ P*Cin*4 (gathered rows) + M*Cout*4 (stores) + index tables, i.e. the
 // gather/scatter bytes B_gs of SURVEY 8(d); the weights (<= 8 MB) are served from L2/MALL.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sg {
@@ -44,7 +46,7 @@ struct ConvArgs {
   const float *residual;  // [M_out][Cout] or null (ignored when writing partials)
   const int32_t *order;   // [M_out] or null
   const uint32_t *tile_mask;
-  const int32_t *tile_order;  // [num_tiles] heaviest-first permutation or null
+  const int32_t *nbr_tiles;   // [num_tiles][32][K] gather rows in plan order, or null
   float *out;             // [M_out][Cout], or partials [ksplit][M_out][Cout]
   int M_out, K, Cin, Cout;
   int col_units;          // wave units along Cout
@@ -74,7 +76,6 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   const long long unit = static_cast<long long>(blockIdx.x) * kWavesPerWg + wave;
   const bool valid = unit < static_cast<long long>(num_tiles) * units_per_tile;
   int tile = valid ? static_cast<int>(unit / units_per_tile) : 0;
-  if (valid && p.tile_order) tile = p.tile_order[tile];
   const int sub = valid ? static_cast<int>(unit % units_per_tile) : 0;
   const int cu = sub % p.col_units, ks = sub / p.col_units;
   const int nb0 = cu * p.blocks_per_unit;
@@ -86,7 +87,8 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   int my_row = -1;
   if (valid) {
     const int pos = tile * kTileRows + arow;
-    if (pos < p.M_out) my_row = p.order ? p.order[pos] : pos;
+    if (p.order) my_row = p.order[pos];       // plan order: padded with -1 to whole tiles
+    else if (pos < p.M_out) my_row = pos;
   }
   if (valid) {
     for (int e = lane; e < kTileRows * p.K; e += 64) {
@@ -214,6 +216,199 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3 main loop for Cin % 32 == 0: 32-channel slices (16 MFMA steps x NBW per iteration), operands
+// fetched with buffer loads whose per-lane offsets are loop invariants (all per-iteration address
+// arithmetic is scalar), two register sets used alternately (no copies), the prefetch of slice
+// t+1 is issued before slice t's MFMA block so that its latency hides under >= 1024 cycles of
+// matrix work.
+// ---------------------------------------------------------------------------------------------
+
+template <int NBW, int CK>
+__global__ void __launch_bounds__(256) gather_conv_v3_kernel(ConvArgs p, unsigned in_bytes,
+                                                            unsigned w_bytes) {
+  constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
+  constexpr int NQ = HC / 4;   // dwordx4 loads per lane per slice
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // wave id through readfirstlane: everything derived from it is then provably wave-uniform, so
+  // buffer-load scalar offsets stay in SGPRs (no waterfall loops)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float *red = reinterpret_cast<float *>(smem_raw);                      // [4][NBW][16][64]
+  float *bn_lds = red + kWavesPerWg * NBW * 16 * 64;                      // [2][Cin]
+  int32_t *nbr_lds = reinterpret_cast<int32_t *>(bn_lds + 2 * p.Cin);     // [32][kMaxK]
+  int32_t *rows_lds = nbr_lds + kTileRows * kMaxK;                        // [32]
+  if (p.bn_scale) {
+    for (int c = threadIdx.x; c < p.Cin; c += 256) {
+      bn_lds[c] = p.bn_scale[c];
+      bn_lds[p.Cin + c] = p.bn_shift[c];
+    }
+  }
+  // workgroup = (tile, column unit, offset range); its 4 waves split the tile's offsets
+  const int units_per_tile = p.col_units * p.ksplit;
+  int tile = blockIdx.x / units_per_tile;
+  const int sub = blockIdx.x % units_per_tile;
+  const int cu = sub % p.col_units, ks = sub / p.col_units;
+  const int nb0 = cu * p.blocks_per_unit;
+  const int nbw = min(p.blocks_per_unit, p.Cout / 32 - nb0);
+  const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
+  const int arow = lane & 31, ahalf = lane >> 5;
+  // plan layout: rows and gather-table block of the tile are contiguous, independent loads
+  if (threadIdx.x < kTileRows) rows_lds[threadIdx.x] = p.order[tile * kTileRows + threadIdx.x];
+  {
+    const int32_t *src = p.nbr_tiles + static_cast<long long>(tile) * kTileRows * p.K;
+    for (int e = threadIdx.x; e < kTileRows * p.K; e += 256) {
+      const int r = e / p.K, k = e - r * p.K;
+      nbr_lds[r * kMaxK + k] = src[e];
+    }
+  }
+  __syncthreads();
+
+  uint32_t wg_mask = p.tile_mask ? p.tile_mask[tile] : 0xffffffffu;
+  wg_mask &= (k_hi >= 32 ? 0xffffffffu : ((1u << k_hi) - 1u)) & ~((1u << k_lo) - 1u);
+  // offsets are dealt to the 4 waves round-robin by their rank among the set bits
+  uint32_t mask = 0;
+  {
+    uint32_t m = wg_mask;
+    int rank = 0;
+    while (m) {
+      const uint32_t low = m & (0u - m);
+      if ((rank & (kWavesPerWg - 1)) == wave) mask |= low;
+      m ^= low;
+      ++rank;
+    }
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  const int n_slices = p.Cin / CK;
+  const int col = nb0 * 32 + arow;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, w_bytes, 0x00020000);
+  // loop-invariant per-lane byte offsets of the weight reads (surplus blocks repeat the last one)
+  int v_w[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) v_w[n] = ((ahalf * HC) * p.Cout + col + min(n, nbw - 1) * 32) * 4;
+  const int row_stride = p.Cout * 4;
+
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  struct Slice {
+    f4 a[NQ];         // HC channels of the gathered row
+    float b[NBW][HC];
+    bool present;
+  };
+  Slice S0, S1;
+
+  auto load = [&](int k, int s, Slice &S) {
+    const int src = nbr_lds[arow * kMaxK + k];
+    S.present = src >= 0;
+    const int v_a = ((S.present ? src : 0) * p.Cin + ahalf * HC) * 4;
+    const int s_a = s * (CK * 4);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, 0));
+    const int s_w = (k * p.Cin + s * CK) * row_stride;
+#pragma unroll
+    for (int j = 0; j < HC; ++j)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        S.b[n][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, v_w[n], s_w + j * row_stride, 0));
+  };
+  auto compute = [&](int s, Slice &S) {
+    float a[HC];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { a[4 * q] = S.a[q][0]; a[4 * q + 1] = S.a[q][1]; a[4 * q + 2] = S.a[q][2]; a[4 * q + 3] = S.a[q][3]; }
+    if (p.bn_scale) {
+      const int c = s * CK + ahalf * HC;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 sc = *reinterpret_cast<const float4 *>(bn_lds + c + 4 * q);
+        const float4 sh = *reinterpret_cast<const float4 *>(bn_lds + p.Cin + c + 4 * q);
+        a[4 * q] = fmaxf(fmaf(a[4 * q], sc.x, sh.x), 0.f);
+        a[4 * q + 1] = fmaxf(fmaf(a[4 * q + 1], sc.y, sh.y), 0.f);
+        a[4 * q + 2] = fmaxf(fmaf(a[4 * q + 2], sc.z, sh.z), 0.f);
+        a[4 * q + 3] = fmaxf(fmaf(a[4 * q + 3], sc.w, sh.w), 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HC; ++j) a[j] = S.present ? a[j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < HC; ++j)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], S.b[n][j], acc[n], 0, 0, 0);
+  };
+  auto advance = [&](int &k, int &s) {
+    if (++s == n_slices) {
+      s = 0;
+      const uint32_t rest = mask & ~((2u << k) - 1u);
+      k = rest ? __builtin_ctz(rest) : -1;
+    }
+  };
+
+  // Every load below is issued unconditionally (past the end the current slice is re-read and
+  // dropped): with no branch between a prefetch and the MFMA block that precedes its use, hipcc's
+  // wait-count insertion keeps exact counts (vmcnt(20*NBW-ish) instead of draining the prefetch).
+  int k = mask ? __builtin_ctz(mask) : -1, s = 0;
+  if (k >= 0) {
+    load(k, s, S0);
+    while (true) {
+      int k1 = k, s1 = s;
+      advance(k1, s1);
+      const bool more1 = k1 >= 0;
+      load(more1 ? k1 : k, more1 ? s1 : s, S1);
+      __builtin_amdgcn_sched_barrier(0);   // prefetch of the next slice is in flight ...
+      compute(s, S0);
+      __builtin_amdgcn_sched_barrier(0);   // ... and is only consumed after this MFMA block
+      if (!more1) break;
+      int k2 = k1, s2 = s1;
+      advance(k2, s2);
+      const bool more2 = k2 >= 0;
+      load(more2 ? k2 : k1, more2 ? s2 : s1, S0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(s1, S1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!more2) break;
+      k = k2;
+      s = s2;
+    }
+  }
+
+  // ---- cross-wave reduction through LDS in a fixed order (w0+w1+w2+w3), then each wave stores
+  //      4 of the 16 accumulator rows-groups: reg -> row (reg&3)+8*(reg>>2)+4*half
+#pragma unroll
+  for (int n = 0; n < NBW; ++n)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[((wave * NBW + n) * 16 + reg) * 64 + lane] = acc[n][reg];
+  __syncthreads();
+  float *out = p.out + (p.ksplit > 1 ? static_cast<long long>(ks) * p.M_out * p.Cout : 0);
+  const bool add_res = p.residual != nullptr && p.ksplit == 1;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int reg = wave * 4 + rr;
+    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
+    const int row = rows_lds[r];
+    if (row < 0) continue;
+    const long long off = static_cast<long long>(row) * p.Cout + col;
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      if (n < nbw) {
+        float v = red[((0 * NBW + n) * 16 + reg) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kWavesPerWg; ++w) v += red[((w * NBW + n) * 16 + reg) * 64 + lane];
+        if (add_res) v += p.residual[off + n * 32];
+        out[off + n * 32] = v;
+      }
+    }
+  }
+}
+
 // fixed-order reduction of the offset-split partial sums (+ residual)
 __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restrict__ partial,
                                                          const float4 *__restrict__ residual,
@@ -284,9 +479,8 @@ size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
                               int K, int Cin, int Cout, const float *w_kio, const float *bn_scale,
                               const float *bn_shift, const float *residual, const int32_t *order,
-                              const uint32_t *tile_mask, const int32_t *tile_order, float *out,
+                              const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream_) {
-  (void)num_in_rows;
   SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
              "sg_spconv_gather_conv_f32: bad arguments (M_out=%d K=%d Cin=%d Cout=%d)", M_out, K,
              Cin, Cout);
@@ -304,11 +498,20 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
   // ---- decomposition: aim at >= ~2048 waves; widest column block that still fills the chip
   const int target = 2048;
-  int bpu = NB <= 4 ? NB : (NB + 1) / 2;          // blocks per unit (<= 4)
-  while (bpu > 1 && static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) < target) --bpu;
+  const long long in_bytes_ll = static_cast<long long>(num_in_rows) * Cin * 4;
+  const long long w_bytes_ll = static_cast<long long>(K) * Cin * Cout * 4;
+  const bool use_v3 = Cin % 32 == 0 && in_bytes_ll < (1LL << 31) && num_in_rows > 0 &&
+                      order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr;
+  const int waves_per_unit = use_v3 ? kWavesPerWg : 1;   // v3: a workgroup's 4 waves share a tile
+  static const int bpu_env = getenv("SG_CONV_BPU") ? atoi(getenv("SG_CONV_BPU")) : 0;
+  int bpu = 1;                                    // 32-column blocks per unit
+  if (bpu_env) bpu = bpu_env < NB ? bpu_env : NB;
+  while (bpu > 1 &&
+         static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) * waves_per_unit < target)
+    --bpu;
   int col_units = (NB + bpu - 1) / bpu;
   int ksplit = 1;
-  long long waves = static_cast<long long>(num_tiles) * col_units;
+  long long waves = static_cast<long long>(num_tiles) * col_units * waves_per_unit;
   if (waves < target / 2) {
     { long long want = (target / 2 + waves - 1) / waves; ksplit = static_cast<int>(want < K ? want : K); }
     const size_t need = static_cast<size_t>(ksplit) * M_out * Cout * sizeof(float);
@@ -319,7 +522,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
 
   ConvArgs a;
   a.in = in; a.nbr = nbr; a.w = w_kio; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
-  a.residual = residual; a.order = order; a.tile_mask = tile_mask; a.tile_order = tile_order;
+  a.residual = residual; a.order = order; a.tile_mask = tile_mask; a.nbr_tiles = nbr_tiles;
   a.out = ksplit > 1 ? static_cast<float *>(ws) : out;
   a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
@@ -329,6 +532,18 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
   const int grid = static_cast<int>((units + kWavesPerWg - 1) / kWavesPerWg);
   const bool vec = (Cin % kCk) == 0;
+  if (use_v3 && bpu <= 2) {
+    const size_t lds3 = (static_cast<size_t>(kWavesPerWg) * bpu * 16 * 64 + 2 * Cin) * sizeof(float) +
+                        (kTileRows * kMaxK + kTileRows) * sizeof(int32_t);
+    const unsigned ib = static_cast<unsigned>(in_bytes_ll), wb = static_cast<unsigned>(w_bytes_ll);
+    static const int ck_env = getenv("SG_CONV_CK") ? atoi(getenv("SG_CONV_CK")) : 0;
+    const int ck = ck_env ? ck_env : 16;
+    const int grid3 = static_cast<int>(units);      // one workgroup per unit
+    if (bpu == 1 && ck == 16) gather_conv_v3_kernel<1, 16><<<grid3, 256, lds3, stream>>>(a, ib, wb);
+    else if (bpu == 1) gather_conv_v3_kernel<1, 32><<<grid3, 256, lds3, stream>>>(a, ib, wb);
+    else if (ck == 16) gather_conv_v3_kernel<2, 16><<<grid3, 256, lds3, stream>>>(a, ib, wb);
+    else gather_conv_v3_kernel<2, 32><<<grid3, 256, lds3, stream>>>(a, ib, wb);
+  } else
   switch (bpu) {
     case 1: launch_v2<1>(a, grid, lds, vec, stream); break;
     case 2: launch_v2<2>(a, grid, lds, vec, stream); break;

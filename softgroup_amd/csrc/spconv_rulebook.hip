@@ -169,12 +169,9 @@ __global__ void __launch_bounds__(256) plan_mask_kernel(const int32_t *__restric
   row[j] = j;
 }
 __global__ void __launch_bounds__(256) plan_tiles_kernel(const uint32_t *__restrict__ mask_sorted,
-                                                        const int32_t *__restrict__ row_sorted, int M,
-                                                        int32_t *__restrict__ order,
-                                                        uint32_t *__restrict__ tile_mask) {
+                                                        int M, uint32_t *__restrict__ tile_mask) {
   const int j = blockIdx.x * 256 + threadIdx.x;  // 256 rows = 8 tiles of 32 per block
   uint32_t m = j < M ? mask_sorted[j] : 0u;
-  if (j < M) order[j] = row_sorted[j];
   // OR over each aligned group of 32 lanes
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
@@ -201,6 +198,33 @@ __global__ void __launch_bounds__(1024) plan_tile_order_kernel(const uint32_t *_
   __syncthreads();
   for (int t = threadIdx.x; t < num_tiles; t += 1024)
     tile_order[atomicAdd(&base[__popc(tile_mask[t])], 1)] = t;
+}
+
+// final layout, tile t' = tile_order[t'] of the mask-sorted sequence: rows of the tile (-1 pad),
+// its mask, and its gather-table rows copied contiguously (the conv kernel then reads one
+// linear 32*K block per tile instead of chasing order[] -> nbr[]).
+__global__ void __launch_bounds__(256) plan_emit_kernel(const int32_t *__restrict__ nbr, int M, int K,
+                                                       const int32_t *__restrict__ row_sorted,
+                                                       const uint32_t *__restrict__ tile_mask_sorted,
+                                                       const int32_t *__restrict__ tile_order,
+                                                       int num_tiles, int32_t *__restrict__ order,
+                                                       uint32_t *__restrict__ tile_mask,
+                                                       int32_t *__restrict__ nbr_tiles) {
+  const int per_tile = 32 * K;
+  for (int t2 = blockIdx.x; t2 < num_tiles; t2 += gridDim.x) {
+    const int t = tile_order[t2];
+    if (threadIdx.x == 0) tile_mask[t2] = tile_mask_sorted[t];
+    if (threadIdx.x < 32) {
+      const int pos = t * 32 + threadIdx.x;
+      order[t2 * 32 + threadIdx.x] = pos < M ? row_sorted[pos] : -1;
+    }
+    for (int e = threadIdx.x; e < per_tile; e += 256) {
+      const int r = e / K, k = e - r * K;
+      const int pos = t * 32 + r;
+      nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
+          pos < M ? nbr[static_cast<int64_t>(row_sorted[pos]) * K + k] : -1;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) weight_kio_kernel(const float *__restrict__ w, int cout, int K,
@@ -308,17 +332,21 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
 
 size_t sg_spconv_plan_workspace_bytes(int M) {
   const size_t nn = static_cast<size_t>(M > 0 ? M : 1);
-  return 2 * align_up(nn * 4) + radix_sort_workspace_bytes(M) + 256;
+  const size_t nt = (nn + 31) / 32;
+  return 2 * align_up(nn * 4) + 2 * align_up(nt * 4) + radix_sort_workspace_bytes(M) + 256;
 }
 
 int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *tile_mask,
-                   int32_t *tile_order, void *ws, size_t ws_bytes, sg_stream_t stream_) {
+                   int32_t *nbr_tiles, void *ws, size_t ws_bytes, sg_stream_t stream_) {
   SG_REQUIRE(M >= 0 && K >= 1 && K <= 32, "sg_spconv_plan: bad arguments (M=%d K=%d)", M, K);
   if (M == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
+  const int num_tiles = (M + 31) / 32;
   Workspace a(ws, ws_bytes);
   uint32_t *mask = a.take<uint32_t>(M);
   int32_t *row = a.take<int32_t>(M);
+  uint32_t *tmask = a.take<uint32_t>(num_tiles);
+  int32_t *torder = a.take<int32_t>(num_tiles);
   const size_t rs_bytes = radix_sort_workspace_bytes(M);
   void *rs_ws = a.take<char>(rs_bytes);
   if (!rs_ws) {
@@ -331,9 +359,10 @@ int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *t
   int32_t *rs;
   int rc = radix_sort_pairs(mask, row, M, K, rs_ws, rs_bytes, stream, &ms, &rs);
   if (rc != SG_OK) return rc;
-  plan_tiles_kernel<<<grid, 256, 0, stream>>>(ms, rs, M, order, tile_mask);
-  if (tile_order)
-    plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tile_mask, (M + 31) / 32, tile_order);
+  plan_tiles_kernel<<<grid, 256, 0, stream>>>(ms, M, tmask);
+  plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tmask, num_tiles, torder);
+  plan_emit_kernel<<<min(num_tiles, 4096), 256, 0, stream>>>(nbr, M, K, rs, tmask, torder, num_tiles,
+                                                            order, tile_mask, nbr_tiles);
   return check_launch("sg_spconv_plan");
 }
 

@@ -67,21 +67,22 @@ class SparseConvTensor:
 # ------------------------------------------------------------------------------------------------
 class _Plan:
     """gather table + mask-sorted tile plan for the implicit-GEMM kernel"""
-    __slots__ = ('nbr', 'order', 'tile_mask', 'tile_order', 'num_out', 'kvol', '_pairs')
+    __slots__ = ('nbr', 'order', 'tile_mask', 'nbr_tiles', 'num_out', 'kvol', '_pairs')
 
     def __init__(self, nbr, num_out, kvol):
         lib = L.lib()
         dev = nbr.device
         self.nbr, self.num_out, self.kvol = nbr, num_out, kvol
         self._pairs = None
-        self.order = torch.empty(num_out, dtype=torch.int32, device=dev)
-        self.tile_mask = torch.empty((num_out + 31) // 32, dtype=torch.int32, device=dev)
-        self.tile_order = torch.empty((num_out + 31) // 32, dtype=torch.int32, device=dev)
+        nt = (num_out + 31) // 32
+        self.order = torch.empty(nt * 32, dtype=torch.int32, device=dev)
+        self.tile_mask = torch.empty(nt, dtype=torch.int32, device=dev)
+        self.nbr_tiles = torch.empty(nt * 32 * kvol, dtype=torch.int32, device=dev)
         if num_out:
             nb = lib.sg_spconv_plan_workspace_bytes(num_out)
             ws = L.workspace(nb, dev)
             L.check(lib.sg_spconv_plan(L.ptr(nbr), num_out, kvol, L.ptr(self.order),
-                                       L.ptr(self.tile_mask), L.ptr(self.tile_order), L.ptr(ws), nb,
+                                       L.ptr(self.tile_mask), L.ptr(self.nbr_tiles), L.ptr(ws), nb,
                                        L.stream()),
                     'sg_spconv_plan')
 
@@ -190,7 +191,7 @@ def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, resid
     L.check(lib.sg_spconv_gather_conv_f32(
         L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
         L.ptr(w_kio), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(residual), L.ptr(plan.order),
-        L.ptr(plan.tile_mask), L.ptr(plan.tile_order), L.ptr(out), L.ptr(ws),
+        L.ptr(plan.tile_mask), L.ptr(plan.nbr_tiles), L.ptr(out), L.ptr(ws),
         nb if ws is not None else 0, L.stream()),
         'sg_spconv_gather_conv_f32')
     if prof is not None:

@@ -38,14 +38,26 @@ def test_subm_rulebook_and_plan_exact():
     rule = core.SubMRule(t(idx), shape)
     nbr = rule.plan.nbr.cpu().numpy()
     assert np.array_equal(nbr, oracle.subm_rulebook(idx, shape))
-    order = rule.plan.order.cpu().numpy()
-    assert np.array_equal(np.sort(order), np.arange(len(idx)))
+    # tile plan: T tiles of 32 rows (rows sorted by neighbour mask), tiles emitted heaviest first
+    M = len(idx)
+    T = (M + 31) // 32
+    order = rule.plan.order.cpu().numpy().reshape(T, 32)
+    valid = order >= 0
+    assert valid.sum() == M and np.array_equal(np.sort(order[valid]), np.arange(M))
     mask = ((nbr >= 0) << np.arange(27)).sum(1).astype(np.uint32)
-    assert (np.diff(mask[order].astype(np.int64)) >= 0).all()          # sorted by mask
+    row_mask = np.where(valid, mask[np.clip(order, 0, None)], 0).astype(np.uint32)
     tm = rule.plan.tile_mask.cpu().numpy().view(np.uint32)
-    pad = (-len(order)) % 32
-    exp = np.bitwise_or.reduce(np.concatenate([mask[order], np.zeros(pad, np.uint32)]).reshape(-1, 32), 1)
-    assert np.array_equal(tm, exp)
+    assert np.array_equal(tm, np.bitwise_or.reduce(row_mask, 1))
+    pop = np.array([bin(int(x)).count('1') for x in tm])
+    assert (np.diff(pop) <= 0).all()                                   # heaviest tiles first
+    # inside the mask-sorted sequence every tile is a contiguous run: per-tile mask ranges are disjoint-sorted
+    lo = np.where(valid, row_mask, np.uint32(0xffffffff)).min(1)
+    hi = row_mask.max(1)
+    o = np.argsort(lo, kind='stable')
+    assert (hi[o][:-1] <= lo[o][1:]).all()
+    nt = rule.plan.nbr_tiles.cpu().numpy().reshape(T, 32, 27)
+    exp = np.where(valid[:, :, None], nbr[np.clip(order, 0, None)], -1)
+    assert np.array_equal(nt, exp)
 
 
 def test_down_rulebook_exact_incl_odd_extent_drop():

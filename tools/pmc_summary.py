@@ -16,7 +16,7 @@ def main():
             k = row['Kernel_Name']
             if sub not in k:
                 continue
-            k = k[:60]
+            k = k[:60] + ' grid=' + row['Grid_Size']
             agg[k][row['Counter_Name']] += float(row['Counter_Value'])
             cnt[(k, row['Counter_Name'])] += 1
     for k, c in agg.items():
