@@ -272,12 +272,13 @@ int sg_gather_rows_i64idx_f32(const float *in, const int64_t *index, int64_t num
  * Instance-mask run-length strings in the reference's wire format (softgroup/util/rle.py:5-19,
  * called per instance from softgroup.py:595-603): "start len start len ..." with 1-based starts.
  * runs of instance g = [bounds[g], bounds[g+1]) of (starts, lens), all host int64.
- * Call with out = NULL to size (fills out_offsets[n_groups+1], byte offsets without terminators),
- * then with a buffer of out_offsets[n_groups] bytes.
+ * Text of instance g = out[out_offsets[g] .. out_offsets[g+1]) (no terminators);
+ * out_capacity >= sg_rle_format_bound(total_runs, digits of the largest number).
  * ---------------------------------------------------------------------------------------- */
+int64_t sg_rle_format_bound(int64_t total_runs, int digits);
 int sg_rle_format_host(const int64_t *starts_host, const int64_t *lens_host,
                        const int64_t *bounds_host, int n_groups, char *out_host,
-                       int64_t *out_offsets_host);
+                       int64_t out_capacity, int64_t *out_offsets_host);
 
 #ifdef __cplusplus
 }

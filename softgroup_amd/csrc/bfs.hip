@@ -33,7 +33,7 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 
 struct BfsWs {
   int32_t *parent, *lab, *size, *cid, *coff, *owner, *seeds, *ebase, *wcnt, *asym_nodes;
-  int2 *label;  // (label, local slot)
+  int4 *label;  // per point: (label, local slot, list start, list len)
   int32_t *counters;  // [0] #asym source nodes  [1] changed flag  [2] nCluster  [3] sumNPoint
   void *scan_ws;
   size_t scan_bytes;
@@ -44,7 +44,7 @@ static bool bfs_carve(void *ws, size_t ws_bytes, int n, BfsWs *w) {
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
   w->parent = a.take<int32_t>(nn);
   w->lab = a.take<int32_t>(nn);
-  w->label = a.take<int2>(nn);
+  w->label = a.take<int4>(nn);
   w->size = a.take<int32_t>(nn);
   w->cid = a.take<int32_t>(nn);
   w->coff = a.take<int32_t>(nn);
@@ -188,13 +188,15 @@ __global__ void __launch_bounds__(256) bfs_propagate_kernel(const int32_t *__res
 // ---------------------------------------------------------------- C. sizes / kept clusters
 __global__ void __launch_bounds__(256) bfs_label_kernel(int n, const int32_t *__restrict__ root_of,
                                                        const int32_t *__restrict__ lab,
-                                                       int2 *__restrict__ label_lid, int32_t *size) {
+                                                       const int32_t *__restrict__ start_len,
+                                                       int4 *__restrict__ node_rec, int32_t *size) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int l = lab[root_of[i]];
-  // (cluster label, slot of the point inside its cluster): the slot indexes the cluster's
-  // visited/claim array when that array lives in LDS during the ordered emission
-  label_lid[i] = make_int2(l, atomicAdd(&size[l], 1));
+  // (cluster label, slot of the point inside its cluster, list start, list length): one 16-B
+  // record per point so that the ordered emission fetches everything about a node in one load.
+  // The slot indexes the cluster's visited/claim array when that array lives in LDS.
+  node_rec[i] = make_int4(l, atomicAdd(&size[l], 1), start_len[2 * i], start_len[2 * i + 1]);
 }
 
 __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size) {
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size
 }
 
 // emit: cluster_offsets[cid+1] and the seed list
-__global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int2 *__restrict__ label,
+__global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int4 *__restrict__ label,
                                                       const int32_t *__restrict__ size,
                                                       const int32_t *__restrict__ cid,
                                                       const int32_t *__restrict__ coff,
@@ -240,8 +242,9 @@ __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
   return carry + incl - v;
 }
 
-constexpr int kOwnCap = 16384;   // cluster sizes up to this keep their claim array in LDS (64 KB)
+constexpr int kOwnCap = 16384;     // cluster sizes up to this keep their claim array in LDS (64 KB)
 constexpr int kFrontChunk = 2048;  // frontier nodes staged per chunk (st, len, edge base, winners)
+constexpr int kECap = 16384;       // edges of a level whose target slots are cached in LDS (32 KB)
 
 // One workgroup per kept cluster.  The output segment doubles as the FIFO queue (column 1 of
 // cluster_idxs).  Per BFS level:
@@ -250,15 +253,21 @@ constexpr int kFrontChunk = 2048;  // frontier nodes staged per chunk (st, len, 
 //           <= kOwnCap points, else on the global owner[] array;
 //   count   winners per frontier node (ballot + popcount), prefix over nodes;
 //   append  winners in edge order to the queue and mark them visited (-1).
-// Frontier nodes are processed in chunks of kFrontChunk whose (start, len, edge base) live in LDS.
+// FAST level (cluster claims in LDS, <= kFrontChunk frontier nodes, <= kECap edges): the frontier's
+// (start,len) stay in LDS from the previous level's append, target slots are cached in LDS by the
+// claim pass, so count needs no global access and append re-reads only the winners' ids: ~3 L2
+// round trips per level instead of ~10.  Anything larger takes the GENERIC path (chunked, all
+// state re-read from global), which typically means few, fat levels.
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
-    const int2 *__restrict__ label_lid, const int32_t *__restrict__ seeds,
+    const int4 *__restrict__ node_rec, const int32_t *__restrict__ seeds,
     const int32_t *__restrict__ cluster_offsets, int n_cluster, int32_t *owner_g,
     int32_t *cluster_idxs) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
-  __shared__ int f_st[kFrontChunk], f_ln[kFrontChunk], f_eb[kFrontChunk], f_wc[kFrontChunk];
+  __shared__ int f_st[2][kFrontChunk], f_ln[2][kFrontChunk];
+  __shared__ int f_eb[kFrontChunk], f_wc[kFrontChunk];
+  __shared__ unsigned short ebuf[kECap];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int c = blockIdx.x; c < n_cluster; c += gridDim.x) {
     const int seed = seeds[c];
@@ -270,29 +279,124 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       for (int i = threadIdx.x; i < size; i += kEmitThreads) own_lds[i] = 0x7fffffff;
     __syncthreads();
     if (threadIdx.x == 0) {
+      const int4 rec = node_rec[seed];
       SG_ST(&Q[0], c);
       SG_ST(&Q[1], seed);
-      if (own_in_lds) own_lds[label_lid[seed].y] = -1; else SG_ST(&owner_g[seed], -1);
+      if (own_in_lds) own_lds[rec.y] = -1; else SG_ST(&owner_g[seed], -1);
+      f_st[0][0] = rec.z;
+      f_ln[0][0] = rec.w;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    auto claim = [&](int v, int pos) {   // propose `pos` to an unvisited node of this cluster
-      const int2 ll = label_lid[v];
+    auto rec2 = [&](int v) -> int2 { return *reinterpret_cast<const int2 *>(node_rec + v); };
+    auto claim = [&](int v, int pos) {   // generic path: propose `pos` to an unvisited node
+      const int2 ll = rec2(v);
       if (ll.x != seed) return;
       if (own_in_lds) { if (own_lds[ll.y] > pos) atomicMin(&own_lds[ll.y], pos); }
       else if (SG_LD(&owner_g[v]) > pos) atomicMin(&owner_g[v], pos);
     };
     auto owner_of = [&](int v) -> int {
-      const int2 ll = label_lid[v];
+      const int2 ll = rec2(v);
       if (ll.x != seed) return -2;
       return own_in_lds ? own_lds[ll.y] : SG_LD(&owner_g[v]);
     };
     auto mark_done = [&](int v) {
-      if (own_in_lds) own_lds[label_lid[v].y] = -1; else SG_ST(&owner_g[v], -1);
+      if (own_in_lds) own_lds[rec2(v).y] = -1; else SG_ST(&owner_g[v], -1);
     };
     int head = 0, tail = 1;
+    int cur = 0;            // which f_st/f_ln buffer holds the current frontier (if any)
+    bool in_lds = true;     // frontier (start,len) of this level already in f_st/f_ln[cur]?
     while (head < tail) {
       const int L = tail - head;
+      // ---------------- FAST level ----------------
+      int E = -1;
+      if (own_in_lds && in_lds && L <= kFrontChunk) {
+        int carry = 0;
+        for (int b0 = 0; b0 < L; b0 += kEmitThreads) {
+          const int q = b0 + threadIdx.x;
+          const int ln = q < L ? f_ln[cur][q] : 0;
+          int tot;
+          const int ex = wg_excl_scan(ln, lds_scan, &tot);
+          if (q < L) f_eb[q] = carry + ex;
+          carry += tot;
+        }
+        __syncthreads();
+        E = carry;
+      }
+      if (E >= 0 && E <= kECap) {
+        for (int q = wave; q < L; q += kEmitWaves) {                  // claim
+          const int st = f_st[cur][q], ln = f_ln[cur][q], base = f_eb[q];
+          for (int p = lane; p < ln; p += 64) {
+            const int2 ll = rec2(idx[st + p]);
+            const unsigned short slot = ll.x == seed ? static_cast<unsigned short>(ll.y) : 0xffffu;
+            ebuf[base + p] = slot;
+            if (slot != 0xffffu && own_lds[slot] > base + p) atomicMin(&own_lds[slot], base + p);
+          }
+        }
+        __syncthreads();
+        for (int q = wave; q < L; q += kEmitWaves) {                  // count winners
+          const int ln = f_ln[cur][q], base = f_eb[q];
+          int wins = 0;
+          for (int p0 = 0; p0 < ln; p0 += 64) {
+            const int p = p0 + lane;
+            bool win = false;
+            if (p < ln) {
+              const unsigned short slot = ebuf[base + p];
+              win = slot != 0xffffu && own_lds[slot] == base + p;
+            }
+            wins += __popcll(__ballot(win));
+          }
+          if (lane == 0) f_wc[q] = wins;
+        }
+        __syncthreads();
+        int t_new = 0;
+        for (int b0 = 0; b0 < L; b0 += kEmitThreads) {                // prefix of winner counts
+          const int q = b0 + threadIdx.x;
+          const int w_ = q < L ? f_wc[q] : 0;
+          int tot;
+          const int ex = wg_excl_scan(w_, lds_scan, &tot);
+          if (q < L) f_wc[q] = t_new + ex;
+          t_new += tot;
+        }
+        __syncthreads();
+        const bool keep = t_new <= kFrontChunk;                      // next frontier fits in LDS
+        const int nxt = cur ^ 1;
+        for (int q = wave; q < L; q += kEmitWaves) {                  // append in edge order
+          const int st = f_st[cur][q], ln = f_ln[cur][q], base = f_eb[q];
+          int o = f_wc[q];
+          for (int p0 = 0; p0 < ln; p0 += 64) {
+            const int p = p0 + lane;
+            bool win = false;
+            unsigned short slot = 0xffffu;
+            if (p < ln) {
+              slot = ebuf[base + p];
+              win = slot != 0xffffu && own_lds[slot] == base + p;
+            }
+            const uint64_t bal = __ballot(win);
+            if (win) {
+              const int v = idx[st + p];
+              const int oo = o + mask_prefix(bal);
+              SG_ST(&Q[2 * (tail + oo)], c);
+              SG_ST(&Q[2 * (tail + oo) + 1], v);
+              if (keep) {
+                const int4 rec = node_rec[v];
+                f_st[nxt][oo] = rec.z;
+                f_ln[nxt][oo] = rec.w;
+              }
+              own_lds[slot] = -1;     // visited; only this edge can match pos, see header
+            }
+            o += __popcll(bal);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        head = tail;
+        tail += t_new;
+        cur = nxt;
+        in_lds = keep;
+        continue;
+      }
+      // ---------------- GENERIC level ----------------
       // stage chunk `ch` of the frontier: list start/len into LDS, edge base = carry + prefix
       auto stage = [&](int ch, int carry_in) -> int {
         const int q0 = ch * kFrontChunk, cnt = min(kFrontChunk, L - q0);
@@ -301,10 +405,10 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
           const int q = b0 + threadIdx.x;
           int ln = 0;
           if (q < cnt) {
-            const int u = SG_LD(&Q[2 * (head + q0 + q) + 1]);
-            f_st[q] = start_len[2 * u];
-            ln = start_len[2 * u + 1];
-            f_ln[q] = ln;
+            const int4 rec = node_rec[SG_LD(&Q[2 * (head + q0 + q) + 1])];
+            f_st[0][q] = rec.z;
+            ln = rec.w;
+            f_ln[0][q] = ln;
           }
           int tot;
           const int ex = wg_excl_scan(ln, lds_scan, &tot);
@@ -315,27 +419,25 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         return carry;
       };
       const int n_chunks = (L + kFrontChunk - 1) / kFrontChunk;
-      // ---- pass 1: claims
       int carry = 0;
-      for (int ch = 0; ch < n_chunks; ++ch) {
+      for (int ch = 0; ch < n_chunks; ++ch) {                         // pass 1: claims
         carry = stage(ch, carry);
         const int cnt = min(kFrontChunk, L - ch * kFrontChunk);
         for (int q = wave; q < cnt; q += kEmitWaves) {
-          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          const int st = f_st[0][q], ln = f_ln[0][q], base = f_eb[q];
           for (int p = lane; p < ln; p += 64) claim(idx[st + p], base + p);
         }
         __syncthreads();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      // ---- pass 2: winners -> queue (chunks in order; `appended` is the running output base)
       int appended = 0;
       carry = 0;
-      for (int ch = 0; ch < n_chunks; ++ch) {
+      for (int ch = 0; ch < n_chunks; ++ch) {                         // pass 2: winners -> queue
         carry = stage(ch, carry);
         const int cnt = min(kFrontChunk, L - ch * kFrontChunk);
         for (int q = wave; q < cnt; q += kEmitWaves) {
-          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          const int st = f_st[0][q], ln = f_ln[0][q], base = f_eb[q];
           int wins = 0;
           for (int p0 = 0; p0 < ln; p0 += 64) {
             const int p = p0 + lane;
@@ -345,7 +447,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         }
         __syncthreads();
         int chunk_new = 0;
-        for (int b0 = 0; b0 < cnt; b0 += kEmitThreads) {   // prefix of winner counts
+        for (int b0 = 0; b0 < cnt; b0 += kEmitThreads) {
           const int q = b0 + threadIdx.x;
           const int w_ = q < cnt ? f_wc[q] : 0;
           int tot;
@@ -355,7 +457,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         }
         __syncthreads();
         for (int q = wave; q < cnt; q += kEmitWaves) {
-          const int st = f_st[q], ln = f_ln[q], base = f_eb[q];
+          const int st = f_st[0][q], ln = f_ln[0][q], base = f_eb[q];
           int obase = tail + appended + f_wc[q];
           for (int p0 = 0; p0 < ln; p0 += 64) {
             const int p = p0 + lane;
@@ -382,10 +484,20 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       // winners become visited only after every edge of the level has been examined
       for (int o = tail + threadIdx.x; o < tail + appended; o += kEmitThreads)
         mark_done(SG_LD(&Q[2 * o + 1]));
+      // hand the next frontier to the fast path when it fits
+      const bool keep = own_in_lds && appended <= kFrontChunk;
+      if (keep)
+        for (int o = threadIdx.x; o < appended; o += kEmitThreads) {
+          const int4 rec = node_rec[SG_LD(&Q[2 * (tail + o) + 1])];
+          f_st[0][o] = rec.z;
+          f_ln[0][o] = rec.w;
+        }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       head = tail;
       tail += appended;
+      cur = 0;
+      in_lds = keep;
     }
     __syncthreads();
   }
@@ -400,7 +512,7 @@ extern "C" {
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges) {
   (void)n_edges;
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
-  return 12 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) + 256;
+  return 14 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) + 256;
 }
 
 // Synchronises `stream` (the cluster count decides the size of the outputs).
@@ -445,9 +557,9 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
       }
       bfs_zero_size_kernel<<<grid, 256, 0, stream>>>(n, w.size);
     }
-    bfs_label_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab, w.label, w.size);
+    bfs_label_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab, start_len, w.label, w.size);
     // kept-cluster ids and offsets: two prefix sums over the seeds in index order
-    const int2 *label = w.label;
+    const int4 *label = w.label;
     const int32_t *size = w.size;
     int32_t *cid = w.cid, *coff = w.coff;
     auto keep = [label, size, seg_of_point, seg_thr] __device__(int64_t i) -> int {

@@ -2,6 +2,7 @@
 // without a GPU context (DataLoader worker processes): voxel index build and octree export.
 // Native C++ (no torch, no HIP); the device variants live in voxelize_idx.hip / octree.hip.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -164,65 +165,111 @@ int sg_octree_build_host(const float *points, const float *xyzwhl, int num_point
 
 // Run-length strings of instance masks in the reference's wire format (util/rle.py:5-19:
 // "start len start len ..." with 1-based starts), for all instances of a scan at once.
-// runs of instance g are [bounds[g], bounds[g+1]) in (starts, lens).  Two calls: with out == NULL
-// it only fills out_offsets[n_groups+1] (byte offset of every string, no terminators); with a
-// buffer of out_offsets[n_groups] bytes it writes the text.  Multi-threaded: the reference does
+// runs of instance g are [bounds[g], bounds[g+1]) in (starts, lens); string g occupies
+// out[out_offsets[g] .. out_offsets[g+1]) (no terminators).  Multi-threaded: the reference does
 // this with a Python loop per instance (softgroup.py:595-603).
 static inline int dec_len(int64_t v) {
-  int n = 1;
-  while (v >= 10) { v /= 10; ++n; }
+  if (v < 10) return 1;
+  if (v < 100) return 2;
+  if (v < 1000) return 3;
+  if (v < 10000) return 4;
+  if (v < 100000) return 5;
+  if (v < 1000000) return 6;
+  if (v < 10000000) return 7;
+  int n = 8;
+  v /= 100000000;
+  while (v) { v /= 10; ++n; }
   return n;
 }
+static const char kDigitPairs[] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+    "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+    "8081828384858687888990919293949596979899";
 static inline char *put_dec(char *p, int64_t v) {
-  char tmp[24];
-  int n = 0;
-  do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
-  while (n) *p++ = tmp[--n];
-  return p;
+  const int n = dec_len(v);
+  char *e = p + n;
+  char *q = e;
+  uint64_t u = static_cast<uint64_t>(v);
+  while (u >= 100) {
+    const unsigned r = static_cast<unsigned>(u % 100);
+    u /= 100;
+    q -= 2;
+    q[0] = kDigitPairs[2 * r];
+    q[1] = kDigitPairs[2 * r + 1];
+  }
+  if (u >= 10) {
+    q -= 2;
+    q[0] = kDigitPairs[2 * u];
+    q[1] = kDigitPairs[2 * u + 1];
+  } else {
+    *--q = static_cast<char>('0' + u);
+  }
+  return e;
 }
 int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t *bounds,
-                       int n_groups, char *out, int64_t *out_offsets) {
-  if (n_groups < 0 || !bounds || !out_offsets) {
+                       int n_groups, char *out, int64_t out_capacity, int64_t *out_offsets) {
+  // One parallel region: every thread sizes its contiguous range of groups, the ranges' byte
+  // totals are prefix-summed after a rendezvous, then every thread writes its groups.
+  // out_capacity must be >= sg_rle_format_bound(total_runs); out_offsets[n_groups+1].
+  if (n_groups < 0 || !bounds || !out_offsets || !out) {
     sg::set_error("sg_rle_format_host: bad arguments");
     return SG_ERR_ARG;
   }
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
-  const int n_thr = std::max(1, std::min({hw > 0 ? hw : 1, 32, n_groups / 8 + 1}));
-  auto parallel = [&](auto &&fn) {
-    if (n_thr == 1) { fn(0, n_groups); return; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_thr; ++t) {
-      const int lo = static_cast<int>(static_cast<int64_t>(n_groups) * t / n_thr);
-      const int hi = static_cast<int>(static_cast<int64_t>(n_groups) * (t + 1) / n_thr);
-      pool.emplace_back(fn, lo, hi);
-    }
-    for (auto &th : pool) th.join();
-  };
-  if (out == nullptr) {
-    parallel([&](int lo, int hi) {
-      for (int g = lo; g < hi; ++g) {
-        int64_t bytes = 0;
-        for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r)
-          bytes += dec_len(starts[r] + 1) + dec_len(lens[r]) + 2;
-        out_offsets[g + 1] = bytes > 0 ? bytes - 1 : 0;  // no trailing space
-      }
-    });
-    out_offsets[0] = 0;
-    for (int g = 0; g < n_groups; ++g) out_offsets[g + 1] += out_offsets[g];
-    return SG_OK;
-  }
-  parallel([&](int lo, int hi) {
+  const int n_thr = std::max(1, std::min({hw > 0 ? hw : 1, 16, n_groups / 8 + 1}));
+  std::vector<int64_t> part(n_thr + 1, 0);
+  std::atomic<int> arrived{0};
+  std::atomic<bool> overflow{false};
+  auto body = [&](int t) {
+    const int lo = static_cast<int>(static_cast<int64_t>(n_groups) * t / n_thr);
+    const int hi = static_cast<int>(static_cast<int64_t>(n_groups) * (t + 1) / n_thr);
+    int64_t total = 0;
     for (int g = lo; g < hi; ++g) {
-      char *p = out + out_offsets[g];
+      int64_t bytes = 0;
+      for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r)
+        bytes += dec_len(starts[r] + 1) + dec_len(lens[r]) + 2;
+      bytes = bytes > 0 ? bytes - 1 : 0;  // no trailing space
+      out_offsets[g + 1] = bytes;          // local size, turned into an offset below
+      total += bytes;
+    }
+    part[t + 1] = total;
+    arrived.fetch_add(1, std::memory_order_acq_rel);
+    while (arrived.load(std::memory_order_acquire) < n_thr) std::this_thread::yield();
+    int64_t base = 0;
+    for (int i = 0; i < t; ++i) base += part[i + 1];
+    for (int g = lo; g < hi; ++g) {
+      const int64_t bytes = out_offsets[g + 1];
+      if (base + bytes > out_capacity) { overflow.store(true); return; }
+      char *p = out + base;
       for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r) {
         if (r != bounds[g]) *p++ = ' ';
         p = put_dec(p, starts[r] + 1);
         *p++ = ' ';
         p = put_dec(p, lens[r]);
       }
+      base += bytes;
+      out_offsets[g + 1] = base;           // end offset of group g
     }
-  });
+  };
+  if (n_thr == 1) {
+    body(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_thr; ++t) pool.emplace_back(body, t);
+    body(0);
+    for (auto &th : pool) th.join();
+  }
+  out_offsets[0] = 0;
+  if (overflow.load()) {
+    sg::set_error("sg_rle_format_host: output buffer too small");
+    return SG_ERR_WORKSPACE;
+  }
   return SG_OK;
+}
+
+// upper bound of the text size for `total_runs` runs whose numbers are < 10^digits
+int64_t sg_rle_format_bound(int64_t total_runs, int digits) {
+  return total_runs * 2 * (static_cast<int64_t>(digits) + 1) + 16;
 }
 
 }  // extern "C"

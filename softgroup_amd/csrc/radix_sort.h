@@ -17,12 +17,14 @@ constexpr int kRsBuckets = 256;
 inline size_t radix_sort_workspace_bytes(int64_t n) {
   const int64_t nblk = (n + kRsTile - 1) / kRsTile;
   const int64_t hist = nblk * kRsBuckets + 1;
-  return align_up(hist * 4) + align_up(scan_workspace_bytes(hist)) + 2 * align_up(n * 4) + 256;
+  return align_up(hist * 4) + align_up(scan_workspace_bytes(hist) + 4 * kRsBuckets * 4) +
+         2 * align_up(n * 4) + 256;
 }
 
 __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__restrict__ keys,
                                                           int64_t n, int shift, int nblk,
-                                                          int32_t *__restrict__ hist) {
+                                                          int32_t *__restrict__ hist,
+                                                          int32_t *totals) {
   __shared__ int h[kRsBuckets];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -34,18 +36,32 @@ __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__res
   }
   __syncthreads();
   hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x] = h[threadIdx.x];
+  if (totals && h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__restrict__ keys,
                                                              const int32_t *__restrict__ vals,
                                                              int64_t n, int shift, int nblk,
                                                              const int32_t *__restrict__ hist,
+                                                             const int32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ keys_out,
                                                              int32_t *__restrict__ vals_out) {
   __shared__ int base[kRsBuckets];
   __shared__ int wcnt[4][kRsBuckets];
+  __shared__ int lds4[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  base[threadIdx.x] = hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x];
+  if (totals) {
+    // small inputs: hist holds raw per-block counts; this block's base of digit d =
+    // (exclusive prefix of the digit totals) + (counts of d in the blocks before this one)
+    const int64_t row = static_cast<int64_t>(threadIdx.x) * nblk;
+    int before = 0;
+    for (int b = 0; b < static_cast<int>(blockIdx.x); ++b) before += hist[row + b];
+    const int tot = totals[threadIdx.x];
+    const int incl = block_incl_scan_256(tot, lds4, nullptr);
+    base[threadIdx.x] = incl - tot + before;
+  } else {
+    base[threadIdx.x] = hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x];
+  }
   const int64_t tile = static_cast<int64_t>(blockIdx.x) * kRsTile;
   for (int r = 0; r < kRsItems; ++r) {
 #pragma unroll
@@ -94,20 +110,33 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
   const int64_t hist_n = static_cast<int64_t>(nblk) * kRsBuckets;
   Workspace a(ws, ws_bytes);
   int32_t *hist = a.take<int32_t>(hist_n + 1);
-  const size_t sbytes = scan_workspace_bytes(hist_n);
+  const size_t sbytes = scan_workspace_bytes(hist_n) + 4 * kRsBuckets * 4;
   void *sws = a.take<char>(sbytes);
   uint32_t *k2 = a.take<uint32_t>(n);
   int32_t *v2 = a.take<int32_t>(n);
   uint32_t *kin = keys, *kout = k2;
   int32_t *vin = vals, *vout = v2;
-  for (int shift = 0; shift < num_bits; shift += 8) {
-    rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, hist);
-    int32_t *h = hist;
-    int rc = exclusive_scan([h] __device__(int64_t i) { return h[i]; },
-                            [h] __device__(int64_t i, int v) { h[i] = v; }, hist_n, nullptr, sws,
-                            sbytes, stream);
-    if (rc != SG_OK) return rc;
-    rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, hist, kout, vout);
+  const int n_pass = (num_bits + 7) / 8;
+  // up to 256 blocks (512k keys) the per-block bases are rebuilt inside the scatter kernel from
+  // raw counts + digit totals: 2 launches per pass instead of 5
+  const bool local_scan = nblk <= 256 && n_pass <= 4;
+  int32_t *totals = static_cast<int32_t *>(sws);    // [n_pass][256], lives in the scan scratch
+  if (local_scan) hipMemsetAsync(totals, 0, static_cast<size_t>(n_pass) * kRsBuckets * 4, stream);
+  for (int shift = 0, pass = 0; shift < num_bits; shift += 8, ++pass) {
+    if (local_scan) {
+      int32_t *t = totals + pass * kRsBuckets;
+      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, hist, t);
+      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, hist, t, kout, vout);
+    } else {
+      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, hist, nullptr);
+      int32_t *h = hist;
+      int rc = exclusive_scan([h] __device__(int64_t i) { return h[i]; },
+                              [h] __device__(int64_t i, int v) { h[i] = v; }, hist_n, nullptr, sws,
+                              sbytes, stream);
+      if (rc != SG_OK) return rc;
+      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, hist, nullptr, kout,
+                                                       vout);
+    }
     uint32_t *tk = kin; kin = kout; kout = tk;
     int32_t *tv = vin; vin = vout; vout = tv;
   }

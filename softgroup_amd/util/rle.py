@@ -42,12 +42,12 @@ def rle_encode_many(length, starts, lens, bounds):
     n = len(bounds) - 1
     offs = np.zeros(n + 1, dtype=np.int64)
     lib = L.lib()
+    cap = int(lib.sg_rle_format_bound(len(starts), len(str(int(length) + 1))))
+    buf = np.empty(cap, dtype=np.uint8)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
-    L.check(lib.sg_rle_format_host(vp(starts), vp(lens), vp(bounds), n, None, vp(offs)),
+    L.check(lib.sg_rle_format_host(vp(starts), vp(lens), vp(bounds), n, vp(buf), cap, vp(offs)),
             'sg_rle_format_host')
-    buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
-    L.check(lib.sg_rle_format_host(vp(starts), vp(lens), vp(bounds), n, vp(buf), vp(offs)),
-            'sg_rle_format_host')
-    raw = buf.tobytes()
+    mv = memoryview(buf)
     o = offs.tolist()
-    return [dict(length=int(length), counts=raw[o[g]:o[g + 1]].decode('ascii')) for g in range(n)]
+    length = int(length)
+    return [dict(length=length, counts=str(mv[o[g]:o[g + 1]], 'ascii')) for g in range(n)]
