@@ -114,18 +114,57 @@ class OracleSoftGroup:
         return self.bn(x.features, 'output_layer.0')
 
     # ---------------------------------------------------------------- forward_test stages
-    def point_wise(self, batch):
-        """softgroup.py:304-307,369-377 -> semantic_scores [N,K], pt_offsets [N,3], output_feats"""
-        feats = np.concatenate([_np(batch['feats']), _np(batch['coords_float'])], 1).astype(np.float32)
+    def _unet(self, voxel_feats, voxel_coords, spatial_shape, batch_size):
+        return self.backbone(voxel_feats, voxel_coords, spatial_shape, batch_size)
+
+    def point_wise(self, batch, x4_split=False, lvl_fusion=False):
+        """softgroup.py:303-307,363-409 -> semantic_scores, pt_offsets, output_feats (per point, or
+        per voxel with lvl_fusion)"""
+        feats = _np(batch['feats']).astype(np.float32)
+        if self.cfg.get('with_coords', True):
+            feats = np.concatenate([feats, _np(batch['coords_float'])], 1).astype(np.float32)
         voxel_feats = O.voxelization(feats, _np(batch['p2v_map']))
-        vfeat = self.backbone(voxel_feats, _np(batch['voxel_coords']).astype(np.int32),
-                              batch['spatial_shape'], batch['batch_size'])
-        output_feats = vfeat[_np(batch['v2p_map']).astype(np.int64)]
+        coords = _np(batch['voxel_coords']).astype(np.int32)
+        v2p = _np(batch['v2p_map']).astype(np.int64)
+        if x4_split:                                   # forward_4_parts + merge_4_parts
+            outs = []
+            for i in range(4):
+                inds = coords[:, 0] == i
+                c = coords[inds].copy()
+                c[:, 0] = 0
+                outs.append(self._unet(voxel_feats[inds], c, batch['spatial_shape'], 1))
+            output_feats = merge_4_parts(np.concatenate(outs, 0)[v2p])
+        else:
+            vfeat = self._unet(voxel_feats, coords, batch['spatial_shape'], batch['batch_size'])
+            output_feats = vfeat if lvl_fusion else vfeat[v2p]
         return (self.mlp(output_feats, 'semantic_linear'), self.mlp(output_feats, 'offset_linear'),
                 output_feats)
 
-    def grouping(self, semantic_scores, pt_offsets, batch_idxs, coords_float):
-        """softgroup.py:411-480 (no pyramid / octree): per-class loop, merged proposals"""
+    def get_level(self, num_points):
+        """softgroup.py:482-489"""
+        if num_points > 1000000:
+            return 3
+        return 2 if num_points > 100000 else 1
+
+    def pyramid_map(self, coords_float, pt_offsets, batch_idxs, level, base_size):
+        """softgroup.py:491-498"""
+        coords = (torch.from_numpy(coords_float) / (base_size * level)).long()
+        coords = torch.cat([torch.from_numpy(batch_idxs.astype(np.int64))[:, None], coords], 1).numpy()
+        vcoords, l2p_map, p2l_map = O.voxelization_idx(coords, int(batch_idxs[-1]) + 1)
+        return (O.voxelization(coords_float, p2l_map), O.voxelization(pt_offsets, p2l_map),
+                vcoords[:, 0].astype(np.int32), l2p_map)
+
+    def pyramid_inverse_map(self, proposals_idx, proposals_offset, num_points, l2p_map):
+        """softgroup.py:500-507 (dense [nProposal, n] int matrix)"""
+        proposals = np.zeros((proposals_offset.shape[0] - 1, num_points), np.int32)
+        proposals[proposals_idx[:, 0].astype(np.int64), proposals_idx[:, 1].astype(np.int64)] = 1
+        proposals = proposals[:, l2p_map.astype(np.int64)]
+        pidx = np.stack(np.nonzero(proposals), 1).astype(np.int32)
+        poff = np.concatenate([[0], np.cumsum(proposals.sum(1))]).astype(np.int32)
+        return pidx, poff
+
+    def grouping(self, semantic_scores, pt_offsets, batch_idxs, coords_float, lvl_fusion=False):
+        """softgroup.py:411-480: per-class loop (optional pyramid / octree), merged proposals"""
         g = self.cfg['grouping_cfg']
         tcfg = self.cfg['test_cfg']
         batch_idxs = _np(batch_idxs).astype(np.int32)
@@ -133,6 +172,9 @@ class OracleSoftGroup:
         batch_size = int(batch_idxs.max()) + 1
         scores = F.softmax(torch.from_numpy(semantic_scores), dim=-1).numpy()
         class_mean = np.asarray(g['class_numpoint_mean'], np.float32)
+        with_pyramid = g.get('with_pyramid', False)
+        with_octree = g.get('with_octree', False)
+        base_size = g.get('pyramid_base_size', 0.02)
         idx_list, off_list = [], []
         for class_id in range(self.cfg['semantic_classes']):
             if class_id in g['ignore_classes']:
@@ -141,12 +183,24 @@ class OracleSoftGroup:
             if object_idxs.shape[0] < tcfg['min_npoint']:
                 continue
             b_ = batch_idxs[object_idxs]
-            offs = np.zeros(batch_size + 1, np.int32)
-            for i in range(batch_size):
-                offs[i + 1] = offs[i] + (b_ == i).sum()
-            nbr, start_len = O.ballquery_batch_p(coords_float[object_idxs] + pt_offsets[object_idxs],
-                                                 b_, offs, g['radius'], g['mean_active'])
+            c_ = coords_float[object_idxs]
+            o_ = pt_offsets[object_idxs]
+            radius, level, l2p_map = g['radius'], 1, None
+            if with_pyramid:
+                level = self.get_level(c_.shape[0])
+                radius = g['radius'] * level
+                if level > 1 or not lvl_fusion:
+                    c_, o_, b_, l2p_map = self.pyramid_map(c_, o_, b_, level, base_size)
+            if with_octree:
+                nbr, start_len = O.octree_ball_query(c_ + o_, g['mean_active'], radius)
+            else:
+                offs = np.zeros(batch_size + 1, np.int32)
+                for i in range(batch_size):
+                    offs[i + 1] = offs[i] + (b_ == i).sum()
+                nbr, start_len = O.ballquery_batch_p(c_ + o_, b_, offs, radius, g['mean_active'])
             pidx, poff = O.bfs_cluster(class_mean, nbr, start_len, g['npoint_thr'], class_id)
+            if l2p_map is not None:
+                pidx, poff = self.pyramid_inverse_map(pidx, poff, c_.shape[0], l2p_map)
             pidx[:, 1] = object_idxs[pidx[:, 1].astype(np.int64)].astype(np.int32)
             if len(off_list) > 0:
                 pidx[:, 0] += sum(x.shape[0] for x in off_list) - 1
@@ -193,43 +247,120 @@ class OracleSoftGroup:
         return self.linear(pooled, 'cls_linear'), self.linear(pooled, 'iou_score_linear'), mask_scores
 
     def get_instances(self, scan_id, proposals_idx, semantic_scores, cls_scores, iou_scores,
-                      mask_scores):
+                      mask_scores, v2p_map=None, lvl_fusion=False):
         """softgroup.py:537-604 with dense [nProposal, N] masks and the reference's numpy RLE"""
         if proposals_idx.shape[0] == 0:
             return []
         tcfg = self.cfg['test_cfg']
         n_inst, n_pts = cls_scores.shape[0], semantic_scores.shape[0]
         cls_prob = F.softmax(torch.from_numpy(cls_scores), 1).numpy()
+        sem_pred = semantic_scores.argmax(1)
+        if v2p_map is not None:
+            v2p_map = _np(v2p_map).astype(np.int64)
         cls_l, score_l, mask_l = [], [], []
         for i in range(self.cfg['instance_classes']):
-            score = cls_prob[:, i] * np.clip(iou_scores[:, i], 0, 1)
-            mask = np.zeros((n_inst, n_pts), np.int32)
-            on = mask_scores[:, i] > tcfg['mask_score_thr']
-            cur = proposals_idx[on].astype(np.int64)
-            mask[cur[:, 0], cur[:, 1]] = 1
-            inds = cls_prob[:, i] > tcfg['cls_score_thr']
-            cls_pred = np.full(n_inst, i + 1, np.int64)[inds]
-            score, mask = score[inds], mask[inds]
-            inds = mask.sum(1) >= tcfg['min_npoint']
-            cls_l.append(cls_pred[inds])
-            score_l.append(score[inds])
-            mask_l.append(mask[inds])
+            if i in self.cfg.get('sem2ins_classes', []):
+                cls_pred = np.array([i + 1], np.int64)
+                score = np.array([1.], np.float32)
+                mask = (sem_pred == i)[None, :].astype(np.int32)
+                if lvl_fusion:
+                    mask = mask[:, v2p_map]
+            else:
+                score = cls_prob[:, i] * np.clip(iou_scores[:, i], 0, 1)
+                mask = np.zeros((n_inst, n_pts), np.int32)
+                on = mask_scores[:, i] > tcfg['mask_score_thr']
+                cur = proposals_idx[on].astype(np.int64)
+                mask[cur[:, 0], cur[:, 1]] = 1
+                inds = cls_prob[:, i] > tcfg['cls_score_thr']
+                cls_pred = np.full(n_inst, i + 1, np.int64)[inds]
+                score, mask = score[inds], mask[inds]
+                if lvl_fusion:
+                    mask = mask[:, v2p_map]
+                inds = mask.sum(1) >= tcfg['min_npoint']
+                cls_pred, score, mask = cls_pred[inds], score[inds], mask[inds]
+            cls_l.append(cls_pred)
+            score_l.append(score)
+            mask_l.append(mask)
         cls_pred, score_pred, mask_pred = np.concatenate(cls_l), np.concatenate(score_l), np.concatenate(mask_l)
         return [dict(scan_id=scan_id, label_id=cls_pred[i], conf=score_pred[i],
                      pred_mask=rle_encode(mask_pred[i])) for i in range(cls_pred.shape[0])]
 
+    def panoptic_fusion(self, semantic_preds, instance_preds):
+        """softgroup.py:606-639"""
+        sc, ic = self.cfg['semantic_classes'], self.cfg['instance_classes']
+        cls_offset = sc - ic - 1
+        panoptic_cls = semantic_preds.copy().astype(np.uint32)
+        panoptic_ids = np.zeros_like(semantic_preds).astype(np.uint32)
+        scores = [x['conf'] for x in instance_preds]
+        score_inds = np.argsort(scores)[::-1]
+        prev_paste = np.zeros_like(semantic_preds, dtype=bool)
+        panoptic_id = 1
+        for i in score_inds:
+            instance = instance_preds[i]
+            mask = rle_decode(instance['pred_mask']).astype(bool)
+            intersect = (mask * prev_paste).sum()
+            if intersect / (mask.sum() + 1e-5) > self.cfg['test_cfg']['panoptic_skip_iou']:
+                continue
+            paste = mask * (~prev_paste)
+            panoptic_cls[paste] = instance['label_id'] + cls_offset
+            panoptic_ids[paste] = panoptic_id
+            prev_paste[paste] = 1
+            panoptic_id += 1
+        ignore_inds = (panoptic_cls >= 11) & (panoptic_ids == 0)
+        panoptic_preds = (panoptic_cls & 0xFFFF) | (panoptic_ids << 16)
+        panoptic_preds[ignore_inds] = sc
+        return panoptic_preds.astype(np.uint32)
+
     def forward_test(self, batch):
-        sem, off, feats = self.point_wise(batch)
-        pidx, poff = self.grouping(sem, off, batch['batch_idxs'], batch['coords_float'])
+        """softgroup.py:299-361 (without the label bookkeeping)"""
+        tcfg = self.cfg['test_cfg']
+        lvl_fusion = tcfg.get('lvl_fusion', False)
+        x4 = tcfg.get('x4_split', False)
+        sem, off, feats = self.point_wise(batch, x4, lvl_fusion)
+        coords_float = _np(batch['coords_float']).astype(np.float32)
+        batch_idxs = _np(batch['batch_idxs'])
+        if x4:
+            coords_float = merge_4_parts(coords_float)
+        if lvl_fusion:
+            batch_idxs = _np(batch['voxel_coords'])[:, 0].astype(np.int32)
+            coords_float = O.voxelization(coords_float, _np(batch['p2v_map']))
+        pidx, poff = self.grouping(sem, off, batch_idxs, coords_float, lvl_fusion)
+        ret = dict(semantic_scores=sem, pt_offsets=off, proposals_idx=pidx, proposals_offset=poff,
+                   pred_instances=[])
         if pidx.shape[0] == 0:
-            return dict(semantic_scores=sem, pt_offsets=off, proposals_idx=pidx,
-                        proposals_offset=poff, pred_instances=[])
-        inst, inst_map = self.clusters_voxelization(pidx, poff, feats, batch['coords_float'])
+            return ret
+        inst, inst_map = self.clusters_voxelization(pidx, poff, feats, coords_float)
         cls_scores, iou_scores, mask_scores = self.instance_heads(inst, inst_map)
-        preds = self.get_instances(batch['scan_ids'][0], pidx, sem, cls_scores, iou_scores, mask_scores)
-        return dict(semantic_scores=sem, pt_offsets=off, proposals_idx=pidx, proposals_offset=poff,
-                    cls_scores=cls_scores, iou_scores=iou_scores, mask_scores=mask_scores,
-                    pred_instances=preds)
+        preds = self.get_instances(batch['scan_ids'][0], pidx, sem, cls_scores, iou_scores, mask_scores,
+                                   batch['v2p_map'], lvl_fusion)
+        ret.update(cls_scores=cls_scores, iou_scores=iou_scores, mask_scores=mask_scores,
+                   pred_instances=preds)
+        if 'panoptic' in tcfg['eval_tasks']:
+            ret['panoptic_preds'] = self.panoptic_fusion(sem.argmax(1), preds)
+        return ret
+
+
+def merge_4_parts(x):
+    """softgroup.py:397-409"""
+    inds = np.arange(x.shape[0])
+    ps = [inds[i::4] for i in range(4)]
+    out = np.zeros_like(x)
+    start = 0
+    for p in ps:
+        out[p] = x[start:start + len(p)]
+        start += len(p)
+    return out
+
+
+def rle_decode(rle):
+    """util/rle.py:22-41"""
+    s = rle['counts'].split()
+    starts = np.asarray(s[0::2], dtype=np.int32) - 1
+    nums = np.asarray(s[1::2], dtype=np.int32)
+    mask = np.zeros(rle['length'], dtype=np.uint8)
+    for lo, hi in zip(starts, starts + nums):
+        mask[lo:hi] = 1
+    return mask
 
 
 def rle_encode(mask):

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   const int sub = valid ? static_cast<int>(unit % units_per_tile) : 0;
   const int cu = sub % p.col_units, ks = sub / p.col_units;
   const int nb0 = cu * p.blocks_per_unit;
-  const int nbw = valid ? min(p.blocks_per_unit, p.Cout / 32 - nb0) : 0;
+  const int nbw = valid ? min(p.blocks_per_unit, (p.Cout + 31) / 32 - nb0) : 0;
   const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
 
   const int arow = lane & 31, ahalf = lane >> 5;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   // offsets are 32-bit (host checks the tensors are < 2^31 elements).
   int coff[NBW];
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) coff[n] = col + min(n, nbw - 1) * 32;
+  for (int n = 0; n < NBW; ++n) coff[n] = min(col + min(n, nbw - 1) * 32, p.Cout - 1);
 
   // raw loads of slice (k, s): A = 8 consecutive channels of the gathered row, B = 8 x NBW weights
   auto load_raw = [&](int k, int s, float (&a)[8], float (&b)[NBW][8], bool &present) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
     const long long off = static_cast<long long>(row) * p.Cout + col;
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-      if (n < nbw) {
+      if (n < nbw && col + n * 32 < p.Cout) {
         float v = acc[n][reg];
         if (add_res) v += p.residual[off + n * 32];
         out[off + n * 32] = v;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) gather_conv_v3_kernel(ConvArgs p, unsigne
   const int sub = blockIdx.x % units_per_tile;
   const int cu = sub % p.col_units, ks = sub / p.col_units;
   const int nb0 = cu * p.blocks_per_unit;
-  const int nbw = min(p.blocks_per_unit, p.Cout / 32 - nb0);
+  const int nbw = min(p.blocks_per_unit, (p.Cout + 31) / 32 - nb0);
   const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
   const int arow = lane & 31, ahalf = lane >> 5;
   // plan layout: rows and gather-table block of the tile are contiguous, independent loads
@@ -294,7 +294,8 @@ __global__ void __launch_bounds__(256) gather_conv_v3_kernel(ConvArgs p, unsigne
   // loop-invariant per-lane byte offsets of the weight reads (surplus blocks repeat the last one)
   int v_w[NBW];
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) v_w[n] = ((ahalf * HC) * p.Cout + col + min(n, nbw - 1) * 32) * 4;
+  for (int n = 0; n < NBW; ++n)
+    v_w[n] = ((ahalf * HC) * p.Cout + min(col + min(n, nbw - 1) * 32, p.Cout - 1)) * 4;
   const int row_stride = p.Cout * 4;
 
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(256) gather_conv_v3_kernel(ConvArgs p, unsigne
     const long long off = static_cast<long long>(row) * p.Cout + col;
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-      if (n < nbw) {
+      if (n < nbw && col + n * 32 < p.Cout) {
         float v = red[((0 * NBW + n) * 16 + reg) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < kWavesPerWg; ++w) v += red[((w * NBW + n) * 16 + reg) * 64 + lane];
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restri
 }
 
 // Scalar path of the same operator for channel counts the MFMA tiling does not cover
-// (Cout % 32 != 0).  One thread per (row, cout).
+// (Cout % 4 != 0).  One thread per (row, cout).
 __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
     const float *__restrict__ in, const int32_t *__restrict__ nbr, int M_out, int K, int Cin,
     int Cout, const float *__restrict__ w_kio, const float *__restrict__ bn_scale,
@@ -488,13 +489,13 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
              "sg_spconv_gather_conv_f32: bn_scale and bn_shift must come together");
   if (M_out == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
-  if (Cout % 32 != 0) {
+  if (Cout % 4 != 0) {
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
                                 stream>>>(in, nbr, M_out, K, Cin, Cout, w_kio, bn_scale, bn_shift,
                                           residual, out);
     return check_launch("sg_spconv_gather_conv_f32(scalar)");
   }
-  const int NB = Cout / 32;
+  const int NB = (Cout + 31) / 32;
   const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
   // ---- decomposition: aim at >= ~2048 waves; widest column block that still fills the chip
   const int target = 2048;

@@ -180,33 +180,35 @@ def bfs_cluster_segments(ball_query_idxs, start_len, seg_thr, seg_of_point=None,
     return cluster_idxs, cluster_offsets
 
 
-class BFSCluster(Function):
+def bfs_cluster(cluster_numpoint_mean, ball_query_idxs, start_len, threshold, class_id):
     """functions.py:278-308.  CPU tensors in -> CPU tensors out (reference contract);
-    CUDA tensors in -> CUDA tensors out."""
+    CUDA tensors in -> CUDA tensors out.  No gradient (like the reference)."""
+    assert cluster_numpoint_mean.is_contiguous()
+    assert ball_query_idxs.is_contiguous()
+    assert start_len.is_contiguous()
+    out_dev = ball_query_idxs.device
+    dev = _dev(ball_query_idxs, start_len)
+    # thr = threshold or threshold * mean, in fp32 (bfs_cluster.cpp:73-79)
+    mean = np.float32(cluster_numpoint_mean.detach().cpu().float()[class_id].item())
+    thr = np.float32(threshold) if mean == np.float32(-1) else np.float32(threshold) * mean
+    seg_thr = torch.tensor([float(thr)], dtype=torch.float32, device=dev)
+    flags = getattr(ball_query_idxs, '_sg_flags', None)     # set by our own ball queries
+    idxs = ball_query_idxs.detach().to(dev, torch.int32)
+    sl = start_len.detach().to(dev, torch.int32)
+    cluster_idxs, cluster_offsets = bfs_cluster_segments(idxs, sl, seg_thr, None, flags)
+    return cluster_idxs.to(out_dev), cluster_offsets.to(out_dev)
+
+
+class BFSCluster(Function):
+    """name kept for parity with functions.py:278 (``BFSCluster.apply`` == ``bfs_cluster``)"""
 
     @staticmethod
     def forward(ctx, cluster_numpoint_mean, ball_query_idxs, start_len, threshold, class_id):
-        assert cluster_numpoint_mean.is_contiguous()
-        assert ball_query_idxs.is_contiguous()
-        assert start_len.is_contiguous()
-        out_dev = ball_query_idxs.device
-        dev = _dev(ball_query_idxs, start_len)
-        # thr = threshold or threshold * mean, in fp32 (bfs_cluster.cpp:73-79)
-        mean = np.float32(cluster_numpoint_mean.detach().cpu().float()[class_id].item())
-        thr = np.float32(threshold) if mean == np.float32(-1) else np.float32(threshold) * mean
-        seg_thr = torch.tensor([float(thr)], dtype=torch.float32, device=dev)
-        srt = getattr(ball_query_idxs, '_sg_flags', None)
-        idxs = ball_query_idxs.to(dev, torch.int32)
-        sl = start_len.to(dev, torch.int32)
-        cluster_idxs, cluster_offsets = bfs_cluster_segments(idxs, sl, seg_thr, None, srt)
-        return cluster_idxs.to(out_dev), cluster_offsets.to(out_dev)
+        return bfs_cluster(cluster_numpoint_mean, ball_query_idxs, start_len, threshold, class_id)
 
     @staticmethod
     def backward(ctx, a=None):
         return None
-
-
-bfs_cluster = BFSCluster.apply
 
 
 # ---------------------------------------------------------------------------------------------

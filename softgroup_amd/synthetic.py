@@ -28,6 +28,52 @@ SCANNET_MODEL_CFG = dict(
 """configs/softgroup/softgroup_scannet.yaml `model:` section (reference), verbatim values."""
 
 
+STPLS3D_PP_MODEL_CFG = dict(
+    channels=16, num_blocks=7, semantic_classes=15, instance_classes=14, sem2ins_classes=[],
+    semantic_only=False,
+    semantic_weight=[1.0, 1.0, 44.0, 21.9, 1.8, 25.1, 31.5, 21.8, 24.0, 54.4, 114.4, 81.2, 43.6, 9.7,
+                     22.4],
+    ignore_label=-100, with_coords=False,
+    grouping_cfg=dict(with_pyramid=True, pyramid_base_size=0.3333, with_octree=True, score_thr=0.2,
+                      radius=0.9, mean_active=3,
+                      class_numpoint_mean=[-1., 10408., 58., 124., 1351., 162., 430., 1090., 451., 26.,
+                                           43., 61., 39., 109., 1239],
+                      npoint_thr=0.01, ignore_classes=[0]),
+    instance_voxel_cfg=dict(scale=3, spatial_shape=20),
+    train_cfg=dict(lvl_fusion=True, max_proposal_num=300, pos_iou_thr=0.5, match_low_quality=True,
+                   min_pos_thr=0.1),
+    test_cfg=dict(x4_split=False, cls_score_thr=0.001, mask_score_thr=-0.5, min_npoint=10,
+                  eval_tasks=['semantic', 'instance']),
+    fixed_modules=[])
+"""configs/softgroup++/softgroup++_stpls3d.yaml `model:` section (reference), verbatim values."""
+
+KITTI_MODEL_CFG = dict(
+    in_channels=1, channels=32, num_blocks=7, semantic_classes=19, instance_classes=8,
+    sem2ins_classes=[], semantic_only=False, ignore_label=-100, with_coords=False,
+    grouping_cfg=dict(score_thr=0.2, radius=0.1, mean_active=300, class_numpoint_mean=[-1.] * 19,
+                      npoint_thr=5, ignore_classes=list(range(11))),
+    instance_voxel_cfg=dict(scale=20, spatial_shape=20),
+    train_cfg=dict(max_proposal_num=200, pos_iou_thr=0.5),
+    test_cfg=dict(x4_split=False, cls_score_thr=0.1, mask_score_thr=-0.5, min_npoint=25,
+                  eval_tasks=['panoptic'], panoptic_skip_iou=0.5),
+    fixed_modules=[])
+"""configs/softgroup/softgroup_kitti.yaml `model:` section (reference), verbatim values."""
+
+S3DIS_MODEL_CFG = dict(
+    channels=32, num_blocks=7, semantic_classes=13, instance_classes=13, sem2ins_classes=[0, 1],
+    semantic_only=False, ignore_label=-100,
+    grouping_cfg=dict(score_thr=0.2, radius=0.04, mean_active=300,
+                      class_numpoint_mean=[34229, 39796, 12210, 7457, 5439, 10225, 6016, 1724, 5092,
+                                           7424, 5279, 6189, 1823],
+                      npoint_thr=0.05, ignore_classes=[0, 1]),
+    instance_voxel_cfg=dict(scale=50, spatial_shape=20),
+    train_cfg=dict(max_proposal_num=200, pos_iou_thr=0.5),
+    test_cfg=dict(x4_split=True, cls_score_thr=0.001, mask_score_thr=-0.5, min_npoint=100,
+                  eval_tasks=['semantic', 'instance']),
+    fixed_modules=['input_conv', 'unet', 'output_layer', 'semantic_linear', 'offset_linear'])
+"""configs/softgroup/softgroup_s3dis_fold5.yaml `model:` section (reference), verbatim values."""
+
+
 def _shell(n, size, rng):
     """n points on the 6 faces of an axis-aligned box"""
     size = np.array(size, dtype=np.float64)
@@ -78,14 +124,27 @@ def scene_g1(seed=2, blobs=40, per_blob=1000, noise=10000, sigma=0.03):
 
 
 def make_batch(xyz, rgb, scale=50, min_spatial=128, instance_labels=None, semantic_labels=None,
-               scan_id='synthetic_0000'):
-    """One-scene batch dict with the keys/dtypes of collate_fn (data/custom.py:240-256)."""
+               scan_id='synthetic_0000', x4_split=False):
+    """One-scene batch dict with the keys/dtypes of collate_fn (data/custom.py:240-256).
+    ``x4_split``: S3DIS test layout (data/s3dis.py:46-115): the scene is cut into 4 interleaved
+    sub-clouds (points i, i+4, ...) that become batch items 0..3, stored part-major."""
     n = xyz.shape[0]
+    if x4_split:
+        part = np.concatenate([np.arange(i, n, 4) for i in range(4)])
+        bidx = np.concatenate([np.full(len(range(i, n, 4)), i) for i in range(4)])
+        xyz, rgb = xyz[part], rgb[part]
+        if instance_labels is not None:
+            instance_labels = instance_labels[part]
+        if semantic_labels is not None:
+            semantic_labels = semantic_labels[part]
+    else:
+        bidx = np.zeros(n, np.int64)
     xyz64 = xyz.astype(np.float64)
     coord = torch.from_numpy(np.floor((xyz64 - xyz64.min(0)) * scale).astype(np.int64))
-    coords = torch.cat([torch.zeros(n, 1, dtype=torch.int64), coord], 1)          # [N,4] batch 0
+    coords = torch.cat([torch.from_numpy(bidx.astype(np.int64))[:, None], coord], 1)   # [N,4]
     spatial_shape = np.clip((coords.max(0)[0][1:] + 1).numpy(), min_spatial, None)
-    voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(coords.contiguous(), 1)
+    batch_size = 4 if x4_split else 1
+    voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(coords.contiguous(), batch_size)
     if instance_labels is None:
         instance_labels = np.full(n, -100, np.int64)
     if semantic_labels is None:
@@ -105,7 +164,7 @@ def make_batch(xyz, rgb, scale=50, min_spatial=128, instance_labels=None, semant
         instance_labels=torch.from_numpy(instance_labels),
         instance_pointnum=torch.from_numpy(pointnum), instance_cls=torch.from_numpy(inst_cls),
         pt_offset_labels=torch.from_numpy(pt_offset_labels), spatial_shape=spatial_shape,
-        batch_size=1)
+        batch_size=batch_size)
 
 
 def build_model(cfg=None, seed=0, device='cuda', head_std=20.0):
