@@ -244,7 +244,7 @@ int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, fl
 /* out[j,:] = (residual ? residual[j,:] : 0) + sum_k W[k] . act(in[nbr[j,k],:])
  *   act(x) = relu(x * bn_scale + bn_shift) when bn_scale != NULL (fused eval-mode BatchNorm1d +
  *   ReLU that precede every conv in blocks.py:57-70,99-119), identity otherwise.
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 32 == 0 takes the MFMA
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 4 == 0 takes the MFMA
  * path; other shapes the scalar path of the same operator.  order/tile_mask/nbr_tiles from
  * sg_spconv_plan (all NULL = natural order, all offsets, slower generic kernel).  Layers too small to fill the chip split the kernel
  * offsets over several waves and reduce partial sums from `ws` in a fixed order; pass
@@ -256,6 +256,13 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                               const float *residual, const int32_t *order,
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);
+
+/* Weight gradient of the same operator (training; spconv's backward reached through autograd,
+ * tools/train.py:58): dw_kio[k][ci][co] += sum_j in[nbr[j,k]][ci] * g_out[j][co].  dw_kio is
+ * [K][Cin][Cout], zero-filled by the caller.  The input gradient needs no extra entry point: it is
+ * sg_spconv_gather_conv_f32 on the transposed gather table with transposed weights. */
+int sg_spconv_wgrad_f32(const float *in, const float *g_out, const int32_t *nbr, int num_out_rows,
+                        int kvol, int cin, int cout, float *dw_kio, sg_stream_t stream);
 
 /* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):
  * out = relu(x*scale + shift) (relu optional). */

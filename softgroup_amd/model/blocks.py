@@ -70,7 +70,9 @@ class ResidualBlock(SparseModule):
 
     def forward(self, input):
         shortcut = self.i_branch(input).features
-        fuse = (not torch.is_grad_enabled() and shortcut.is_cuda and shortcut.dtype == torch.float32
+        needs_grad = torch.is_grad_enabled() and (
+            shortcut.requires_grad or any(p.requires_grad for p in self.conv_branch.parameters()))
+        fuse = (not needs_grad and shortcut.is_cuda and shortcut.dtype == torch.float32
                 and input.indices.shape[0] != 0)
         if fuse:
             return self.conv_branch(input, residual=shortcut.contiguous())

@@ -201,6 +201,39 @@ def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, resid
     return out
 
 
+class _GatherConvFn(torch.autograd.Function):
+    """Differentiable sparse conv: forward = gather_conv; input gradient = the same kernel on the
+    transposed gather table with transposed weights; weight gradient = sg_spconv_wgrad_f32."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, w_kio, plan, bwd_plan, flip_k):
+        ctx.save_for_backward(feats, weight)
+        ctx.plan, ctx.bwd_plan, ctx.flip_k = plan, bwd_plan, flip_k
+        return gather_conv(feats, plan, w_kio, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, weight = ctx.saved_tensors
+        plan, bwd_plan = ctx.plan, ctx.bwd_plan
+        cout, cin = weight.shape[0], weight.shape[-1]
+        kvol = plan.kvol
+        g = g.contiguous().float()
+        g_feats = g_weight = None
+        if ctx.needs_input_grad[0]:
+            # w_t[k'][co][ci] = W[co][k][ci] with k' = K-1-k for SubM (mirrored offset), k otherwise
+            w_t = weight.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
+            if ctx.flip_k:
+                w_t = w_t.flip(0)
+            g_feats = gather_conv(g, bwd_plan, w_t.contiguous(), cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((kvol, cin, cout), dtype=torch.float32, device=g.device)
+            L.check(L.lib().sg_spconv_wgrad_f32(L.ptr(feats), L.ptr(g), L.ptr(plan.nbr), plan.num_out,
+                                                kvol, cin, cout, L.ptr(dw), L.stream()),
+                    'sg_spconv_wgrad_f32')
+            g_weight = dw.permute(2, 0, 1).reshape(weight.shape).to(weight.dtype)
+        return g_feats, g_weight, None, None, None, None
+
+
 class SparseModule(nn.Module):
     """marker base class: SparseSequential hands these the SparseConvTensor itself"""
     pass
@@ -273,7 +306,7 @@ class SparseConvolution(SparseModule):
         return self._kio_cache[1]
 
     def _rule_and_plan(self, input):
-        """-> (plan, out_indices, out_spatial_shape)"""
+        """-> (plan, out_indices, out_spatial_shape, backward-plan getter, mirrored offsets?)"""
         key = self.indice_key
         if self.subm:
             rule = input.find_indice_pair(key)
@@ -281,21 +314,21 @@ class SparseConvolution(SparseModule):
                 rule = SubMRule(input.indices, input.spatial_shape)
                 if key is not None:
                     input.indice_dict[key] = rule
-            return rule.plan, input.indices, input.spatial_shape
+            return rule.plan, input.indices, input.spatial_shape, (lambda: rule.plan), True
         if self.inverse:
             rule = input.find_indice_pair(key)
             if not isinstance(rule, DownRule):
                 raise RuntimeError(f'SparseInverseConv3d: no SparseConv3d rulebook under indice_key '
                                    f'{key!r} (spconv requires the paired down conv to run first)')
             assert rule.num_out == input.indices.shape[0], 'inverse conv input does not match its pair'
-            return rule.inv_plan, rule.in_indices, rule.in_spatial_shape
+            return rule.inv_plan, rule.in_indices, rule.in_spatial_shape, (lambda: rule.plan), False
         rule = input.find_indice_pair(key)
         if (not isinstance(rule, DownRule) or rule.num_in != input.indices.shape[0]
                 or rule.in_indices.data_ptr() != input.indices.data_ptr()):
             rule = DownRule(input.indices, input.spatial_shape, input.batch_size)
             if key is not None:
                 input.indice_dict[key] = rule
-        return rule.plan, rule.out_indices, rule.out_spatial_shape
+        return rule.plan, rule.out_indices, rule.out_spatial_shape, (lambda: rule.inv_plan), False
 
     def forward(self, input, bn_scale=None, bn_shift=None, residual=None):
         assert isinstance(input, SparseConvTensor)
@@ -306,16 +339,17 @@ class SparseConvolution(SparseModule):
             if self.bias is not None:
                 out = out + self.bias
             return input.replace_feature(out)
+        plan, out_indices, out_shape, bwd_plan, flip_k = self._rule_and_plan(input)
+        x = (feats if feats.dtype == torch.float32 else feats.float()).contiguous()
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError(
-                'softgroup_amd.spconv: sparse-conv backward is not built yet (inference path only); '
-                'run under torch.no_grad()')
-        plan, out_indices, out_shape = self._rule_and_plan(input)
-        x = feats if feats.dtype == torch.float32 else feats.float()
-        out = gather_conv(x.contiguous(), plan, self.weight_kio(), self.out_channels, bn_scale,
-                          bn_shift, residual)
+            assert bn_scale is None and residual is None, 'fused prologue/epilogue is inference-only'
+            out = _GatherConvFn.apply(x, self.weight, self.weight_kio(), plan,
+                                      bwd_plan() if x.requires_grad else None, flip_k)
+        else:
+            out = gather_conv(x, plan, self.weight_kio(), self.out_channels, bn_scale, bn_shift,
+                              residual)
         if self.bias is not None:
-            out += self.bias.float()
+            out = out + self.bias.float()
         if out.dtype != feats.dtype:
             out = out.to(feats.dtype)
         return SparseConvTensor(out, out_indices, out_shape, input.batch_size, input.grid,
@@ -364,9 +398,13 @@ def _bn_affine(bn):
     return cache[1], cache[2]
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def _fusable_bn(m):
     return (isinstance(m, nn.BatchNorm1d) and not m.training and m.track_running_stats
-            and m.running_mean is not None)
+            and m.running_mean is not None and not _needs_grad(m.weight, m.bias))
 
 
 class SparseSequential(SparseModule):
@@ -416,12 +454,13 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             m = mods[i]
             sparse_in = isinstance(input, SparseConvTensor)
-            fast = (sparse_in and not torch.is_grad_enabled() and input.features.is_cuda
-                    and input.features.dtype == torch.float32 and input.indices.shape[0] != 0)
+            fast = (sparse_in and input.features.is_cuda and input.features.dtype == torch.float32
+                    and input.indices.shape[0] != 0 and not _needs_grad(input.features))
             if fast and _fusable_bn(m) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 scale, shift = _bn_affine(m)
                 nxt = mods[i + 2] if i + 2 < len(mods) else None
-                if isinstance(nxt, SparseConvolution) and not nxt.conv1x1:
+                if (isinstance(nxt, SparseConvolution) and not nxt.conv1x1
+                        and not _needs_grad(nxt.weight, nxt.bias)):
                     input = nxt(input, scale, shift, residual if i + 2 == last_conv else None)
                     i += 3
                     continue
