@@ -136,3 +136,38 @@ def test_forward_train_step(frozen):
     assert not torch.equal(before, watched)
     loss2, _ = model(batch, return_loss=True)
     assert torch.isfinite(loss2)
+
+
+def test_ddp_bf16_autocast_step():
+    """BASELINE config 3 shape at world_size 1: DistributedDataParallel over RCCL ('nccl' backend on
+    ROCm), bf16 autocast around the forward (tools/train.py:47 uses fp16 autocast + GradScaler; bf16
+    needs no scaler), frozen backbone as in softgroup_s3dis_fold5.yaml."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        cfg = copy.deepcopy(synthetic.S3DIS_MODEL_CFG)
+        cfg['test_cfg']['x4_split'] = False
+        torch.manual_seed(0)
+        model = SoftGroup(**cfg).to(DEV)
+        with torch.no_grad():
+            model.semantic_linear[-1].weight.normal_(0, 20.0)
+        model.train()
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=True)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        batch = _train_batch(20000)
+        batch['semantic_labels'] = batch['semantic_labels'].clamp(max=12)
+        batch['instance_cls'] = batch['instance_cls'].clamp(max=12)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss, log_vars = ddp(batch, return_loss=True)
+        assert torch.isfinite(loss)
+        opt.zero_grad()
+        loss.backward()
+        g = model.cls_linear.weight.grad
+        assert g is not None and torch.isfinite(g).all()
+        opt.step()
+    finally:
+        dist.destroy_process_group()
