@@ -237,22 +237,29 @@ int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *orde
                    uint32_t *tile_mask, int32_t *nbr_tiles, void *ws, size_t ws_bytes,
                    sg_stream_t stream);
 
-/* weight re-layout [Cout, K, Cin] (spconv "OKKKI", tools/convert_checkpoint.py:17-19) -> [K, Cin, Cout] */
-int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, float *w_kio,
-                            sg_stream_t stream);
+/* Weight packing for the conv kernel: src [Cout, K, Cin] (spconv "OKKKI", the checkpoint layout,
+ * tools/convert_checkpoint.py:17-19; src_is_kio = 0) or [K, Cin, Cout] (src_is_kio = 1) ->
+ * "k8" [K][ceil(Cin/8)][Cout][8], zero padded: the 8 reduction steps one lane feeds to 8 consecutive
+ * MFMAs are one 32-B read.  w_k8 holds sg_spconv_packed_weight_elems(kvol, cin, cout) floats. */
+size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout);
+int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
+                          sg_stream_t stream);
 
-/* out[j,:] = (residual ? residual[j,:] : 0) + sum_k W[k] . act(in[nbr[j,k],:])
- *   act(x) = relu(x * bn_scale + bn_shift) when bn_scale != NULL (fused eval-mode BatchNorm1d +
- *   ReLU that precede every conv in blocks.py:57-70,99-119), identity otherwise.
+/* out[j,:] = post( (residual ? residual[j,:] : 0) + sum_k W[k] . in[nbr[j,k],:] )
+ *   post(x) = relu(x * post_scale + post_shift) when post_scale != NULL, identity otherwise: the
+ *   eval-mode BatchNorm1d + ReLU that FOLLOWS this conv and precedes the next one in
+ *   blocks.py:57-70 (conv_branch: BN, ReLU, conv, BN, ReLU, conv), fused into the epilogue.  `in`
+ *   is taken as is (already activated by the producer's epilogue or by sg_bn_relu_f32).
  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 4 == 0 takes the MFMA
  * path; other shapes the scalar path of the same operator.  order/tile_mask/nbr_tiles from
- * sg_spconv_plan (all NULL = natural order, all offsets, slower generic kernel).  Layers too small to fill the chip split the kernel
- * offsets over several waves and reduce partial sums from `ws` in a fixed order; pass
+ * sg_spconv_plan (all NULL = natural order, all offsets, slower general kernel).  cin % 16 == 0 with
+ * a plan runs the persistent-workgroup kernel.  Layers too small to fill the chip split the kernel
+ * offsets over several units and reduce partial sums from `ws` in a fixed order; pass
  * ws >= sg_spconv_conv_workspace_bytes(num_out_rows, cout) (ws = NULL disables the split). */
 size_t sg_spconv_conv_workspace_bytes(int num_out_rows, int cout);
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr,
-                              int num_out_rows, int kvol, int cin, int cout, const float *w_kio,
-                              const float *bn_scale, const float *bn_shift,
+                              int num_out_rows, int kvol, int cin, int cout, const float *w_k8,
+                              const float *post_scale, const float *post_shift,
                               const float *residual, const int32_t *order,
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);

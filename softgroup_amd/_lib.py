@@ -53,7 +53,8 @@ SIGNATURES = {
     'sg_spconv_inverse_rulebook': (_i, [_vp, _vp, _i, _vp, _vp]),
     'sg_spconv_plan_workspace_bytes': (_sz, [_i]),
     'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'sg_spconv_weight_to_kio': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sg_spconv_packed_weight_elems': (_sz, [_i, _i, _i]),
+    'sg_spconv_pack_weight': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),
     'sg_spconv_gather_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _sz, _vp]),

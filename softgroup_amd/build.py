@@ -21,7 +21,7 @@ SOURCES = [
     ('octree.hip', ['-ffp-contract=off']),
     ('bfs.hip', ['-ffp-contract=off']),
     ('spconv_rulebook.hip', ['-ffp-contract=off']),
-    ('spconv_conv.hip', []),
+    ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('host_ops.cpp', ['-ffp-contract=off']),
 ]
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-function',

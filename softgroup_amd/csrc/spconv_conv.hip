@@ -1,75 +1,83 @@
 // spconv_conv.hip -- sparse convolution as an output-stationary implicit GEMM on fp32 MFMA.
 // Replaces the conv kernels of the un-vendored spconv 2.1 library for SubMConv3d /
 // SparseConv3d(k2,s2) / SparseInverseConv3d (reference call sites: softgroup/model/softgroup.py:61,
-// softgroup/model/blocks.py:57-70,101-119).  One kernel serves all three: it only sees a gather
-// table nbr[M_out, K] (spconv_rulebook.hip) and weights re-laid out as [K][Cin][Cout].
+// softgroup/model/blocks.py:57-70,101-119).  One operator serves all three: it only sees a gather
+// table nbr[M_out, K] (spconv_rulebook.hip) and packed weights.
 //
-//   out[j,:] = residual[j,:] + sum_k  act(in[nbr[j,k],:]) . W[k]        act = relu(x*s + b) | id
+//   out[j,:] = post( residual[j,:] + sum_k in[nbr[j,k],:] . W[k] ),   post = relu(x*s + b) | id
 //
-// MI355X mapping (v2: wave-private register pipeline, no LDS staging of operands, no barriers
-// in the main loop -- sparse tiles have ragged depth, so lock-stepping waves wastes the machine)
-//   * work unit = one wave = (tile of 32 output rows in neighbour-mask-sorted order) x (up to NBW
-//     32-column blocks of Cout) x (a slice of the kernel offsets when the layer is too small to
-//     fill 256 CUs otherwise).  The tile's 27-bit mask says which offsets exist at all.
-//   * v_mfma_f32_32x32x2_f32 (exact fp32 = fmaf chain, 64 FLOP/clk/SIMD).  The reduction index
-//     of a 16-channel slice is permuted so that lane (h, i) owns channels c0+8h .. c0+8h+7 of
-//     gathered row i: its A operands for 8 MFMA steps are ONE contiguous 32-B read of that row
-//     (two dwordx4), and its B operands are coalesced 128-B reads of W[k][c][32 cols].
-//   * operands for slice t+1 are loaded into a second register set while slice t's MFMAs issue
-//     (an fp32 MFMA occupies the SIMD for 64 cycles, so one wave-wide load per MFMA is cheap);
-//     several waves per SIMD interleave freely because nothing synchronises them.
-//   * fused eval-BatchNorm+ReLU on the gathered rows (scale/shift broadcast from LDS), fused
-//     residual add, every output row written once, 128 B per half-wave.
-//   * tiny layers (deep U-Net levels: 18..800 rows) split the kernel offsets over several waves;
+// `in` is already activated: the eval-mode BatchNorm1d+ReLU in front of every conv of the U-Net is
+// either the `post` epilogue of the conv that produced `in` or one elementwise pass (sg_bn_relu_f32).
+// An earlier version applied BN+ReLU to the gathered rows inside the matrix loop; per-wave phase
+// tracing showed the kernel was bound by instruction ISSUE, not by MFMA or memory (113 instructions
+// per 8 MFMAs, the SIMD issues ~1 per 4-5 cycles), so everything that is not load / MFMA moved out
+// of the loop: absent neighbours are buffer loads past the end (hardware returns 0, no select),
+// weights are packed so a lane's 8 B operands are one 32-B read, addresses are loop invariants.
+//
+// Weight layout "k8": [K][ceil(Cin/8)][Cout][8]  (zero padded): the 8 reduction steps a lane feeds
+// to 8 consecutive MFMAs are contiguous, a wave reads 2 x 1 KB fully coalesced per slice.
+//
+// MI355X mapping
+//   * v_mfma_f32_32x32x2_f32 (exact fp32 = fmaf chain, 64 FLOP/clk/SIMD).  Tile = 32 output rows in
+//     neighbour-mask-sorted order x one 32-column block; the tile's 27-bit mask says which kernel
+//     offsets exist at all.  The reduction index of a 16-channel slice is permuted so that lane
+//     (h, i) owns channels c0+8h .. c0+8h+7 of gathered row i: A = one 32-B read of that row.
+//   * main kernel (gather_conv_persistent_kernel, Cin % 16 == 0): persistent workgroups, see there.
+//   * general kernel (gather_conv_tile_kernel): any Cin, plan optional, wave-private tiles.
+//   * tiny layers (deep U-Net levels: 18..800 rows) split the kernel offsets over several units;
 //     partial sums go to a workspace and are reduced in a fixed order (deterministic).
 // HBM traffic per layer ~ P*Cin*4 (gathered rows) + M*Cout*4 (stores) + index tables, i.e. the
 // gather/scatter bytes B_gs of SURVEY 8(d); the weights (<= 8 MB) are served from L2/MALL.
 #include <stdlib.h>
+
+#include <cstdio>
+#include <vector>
 
 #include "common.h"
 
 namespace sg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTileRows = 32;
 constexpr int kWavesPerWg = 4;
 constexpr int kCk = 16;        // channels per pipeline slice (8 per half-wave)
 constexpr int kMaxK = 27;
+constexpr unsigned kOob = 0x80000000u;   // byte offset past every (< 2 GB) buffer: loads return 0
 
 struct ConvArgs {
   const float *in;
   const int32_t *nbr;
-  const float *w;         // [K][Cin][Cout]
-  const float *bn_scale;  // [Cin] or null
-  const float *bn_shift;
-  const float *residual;  // [M_out][Cout] or null (ignored when writing partials)
-  const int32_t *order;   // [M_out] or null
+  const float *w;            // k8 layout
+  const float *post_scale;   // [Cout] or null
+  const float *post_shift;
+  const float *residual;     // [M_out][Cout] or null
+  const int32_t *order;      // [num_tiles*32] or null
   const uint32_t *tile_mask;
-  const int32_t *nbr_tiles;   // [num_tiles][32][K] gather rows in plan order, or null
-  float *out;             // [M_out][Cout], or partials [ksplit][M_out][Cout]
+  const int32_t *nbr_tiles;  // [num_tiles][32][K] gather rows in plan order, or null
+  float *out;                // [M_out][Cout], or partials [ksplit][M_out][Cout]
   int M_out, K, Cin, Cout;
-  int col_units;          // wave units along Cout
-  int blocks_per_unit;    // 32-col blocks per unit (last unit may have fewer)
-  int ksplit;             // slices of the kernel-offset range
+  int col_units;             // units along Cout
+  int blocks_per_unit;       // 32-col blocks per unit (general kernel only)
+  int ksplit;                // slices of the kernel-offset range
   int k_per_split;
+  int num_units;
+  unsigned magic_upt, magic_cu, magic_nsl;   // reciprocals of units_per_tile, col_units, n_slices
+  unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
 };
 
+// ---------------------------------------------------------------------------------------------
+// General kernel: one wave = (tile, up to NBW column blocks, offset range).  No barriers after the
+// prologue; operands of slice t+1 are loaded while slice t's MFMAs issue.
+// ---------------------------------------------------------------------------------------------
 template <int NBW, bool VEC>
-__global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // LDS: per-wave neighbour table [32][K] + bn scale/shift [2][CinPad]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t *nbr_lds = reinterpret_cast<int32_t *>(smem_raw) + wave * kTileRows * kMaxK;
   const int cin_pad = (p.Cin + kCk - 1) / kCk * kCk;
-  float *bn_lds = reinterpret_cast<float *>(smem_raw);            // [2][cin_pad]
-  int32_t *nbr_lds = reinterpret_cast<int32_t *>(bn_lds + 2 * cin_pad) + wave * kTileRows * kMaxK;
-
-  if (p.bn_scale) {
-    for (int c = threadIdx.x; c < cin_pad; c += 256) {
-      bn_lds[c] = c < p.Cin ? p.bn_scale[c] : 0.f;
-      bn_lds[cin_pad + c] = c < p.Cin ? p.bn_shift[c] : 0.f;
-    }
-  }
+  const int c8 = (p.Cin + 7) / 8;
 
   const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
   const int units_per_tile = p.col_units * p.ksplit;
@@ -83,7 +91,6 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
 
   const int arow = lane & 31, ahalf = lane >> 5;
-  // my output row (both halves hold the same rows) and the tile's neighbour table
   int my_row = -1;
   if (valid) {
     const int pos = tile * kTileRows + arow;
@@ -97,7 +104,7 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
       nbr_lds[r * kMaxK + k] = row >= 0 ? p.nbr[static_cast<long long>(row) * p.K + k] : -1;
     }
   }
-  __syncthreads();  // bn_lds + nbr_lds visible (only barrier of the kernel)
+  __syncthreads();  // nbr_lds visible (only barrier of the kernel)
   if (!valid) return;
 
   uint32_t mask = p.tile_mask ? p.tile_mask[tile] : 0xffffffffu;
@@ -111,80 +118,64 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
 
   const int n_slices = cin_pad / kCk;
   const int col = nb0 * 32 + arow;
-
-  // Column offsets of this unit's blocks; surplus blocks (n >= nbw) re-read the last real one so
-  // that every load below is unconditional (hipcc branches around predicated loads).  All element
-  // offsets are 32-bit (host checks the tensors are < 2^31 elements).
+  // Column of this unit's blocks; surplus blocks (n >= nbw) re-read the last real one so that every
+  // load below is unconditional (hipcc branches around predicated loads).
   int coff[NBW];
 #pragma unroll
   for (int n = 0; n < NBW; ++n) coff[n] = min(col + min(n, nbw - 1) * 32, p.Cout - 1);
 
-  // raw loads of slice (k, s): A = 8 consecutive channels of the gathered row, B = 8 x NBW weights
-  auto load_raw = [&](int k, int s, float (&a)[8], float (&b)[NBW][8], bool &present) {
+  // loads of slice (k, s): A = 8 consecutive channels of the gathered row, B = 8 x NBW weights
+  auto load_raw = [&](int k, int s, float (&a)[8], float (&b)[NBW][8]) {
     const int c = s * kCk + ahalf * 8;
     const int src = nbr_lds[arow * kMaxK + k];
-    present = src >= 0;
+    const bool present = src >= 0;
     const float *row = p.in + static_cast<unsigned>((present ? src : 0) * p.Cin + c);
     if (VEC) {
       const float4 v0 = *reinterpret_cast<const float4 *>(row);
       const float4 v1 = *reinterpret_cast<const float4 *>(row + 4);
       a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
       a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = present ? a[j] : 0.f;
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = row[max(0, min(j, p.Cin - 1 - c))];
+      for (int j = 0; j < 8; ++j) {
+        const float v = row[max(0, min(j, p.Cin - 1 - c))];
+        a[j] = (present && c + j < p.Cin) ? v : 0.f;
+      }
     }
-    const int wbase = (k * p.Cin + c) * p.Cout;
+    const int blk = min(c >> 3, c8 - 1);       // padded slices re-read the last block (a == 0)
+    const unsigned wbase = static_cast<unsigned>((k * c8 + blk) * p.Cout) * 8u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int wrow = VEC ? wbase + j * p.Cout : (k * p.Cin + min(c + j, p.Cin - 1)) * p.Cout;
-#pragma unroll
-      for (int n = 0; n < NBW; ++n) b[n][j] = p.w[static_cast<unsigned>(wrow + coff[n])];
+    for (int n = 0; n < NBW; ++n) {
+      const float4 w0 = *reinterpret_cast<const float4 *>(p.w + wbase + coff[n] * 8);
+      const float4 w1 = *reinterpret_cast<const float4 *>(p.w + wbase + coff[n] * 8 + 4);
+      b[n][0] = w0.x; b[n][1] = w0.y; b[n][2] = w0.z; b[n][3] = w0.w;
+      b[n][4] = w1.x; b[n][5] = w1.y; b[n][6] = w1.z; b[n][7] = w1.w;
     }
-  };
-  // fused BatchNorm+ReLU and zeroing of absent neighbours / padded channels, applied when the
-  // slice becomes current (so the wait for its loads sits AFTER the previous MFMA block)
-  auto finish = [&](int s, const float (&raw)[8], bool present, float (&a)[8]) {
-    const int c = s * kCk + ahalf * 8;
-    if (p.bn_scale) {
-      const float4 s0 = *reinterpret_cast<const float4 *>(bn_lds + c);
-      const float4 s1 = *reinterpret_cast<const float4 *>(bn_lds + c + 4);
-      const float4 h0 = *reinterpret_cast<const float4 *>(bn_lds + cin_pad + c);
-      const float4 h1 = *reinterpret_cast<const float4 *>(bn_lds + cin_pad + c + 4);
-      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = fmaxf(fmaf(raw[j], sc[j], sh[j]), 0.f);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = raw[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (present && (VEC || c + j < p.Cin)) ? a[j] : 0.f;
   };
 
   float a_cur[8], a_nxt[8];
   float b_cur[NBW][8], b_nxt[NBW][8];
-  bool pres_nxt = false;
 
   // flattened iteration space: (offset k in mask) x (slice s)
   int k = mask ? __builtin_ctz(mask) : -1;
   int s = 0;
-  if (k >= 0) load_raw(k, 0, a_nxt, b_nxt, pres_nxt);
+  if (k >= 0) load_raw(k, 0, a_nxt, b_nxt);
   while (k >= 0) {
-    finish(s, a_nxt, pres_nxt, a_cur);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 8; ++j) {
+      a_cur[j] = a_nxt[j];
 #pragma unroll
       for (int n = 0; n < NBW; ++n) b_cur[n][j] = b_nxt[n][j];
-    // next (k, s) and its prefetch
+    }
     int k2 = k, s2 = s + 1;
     if (s2 == n_slices) {
       s2 = 0;
       const uint32_t rest = mask & ~((2u << k) - 1u);
       k2 = rest ? __builtin_ctz(rest) : -1;
     }
-    if (k2 >= 0) load_raw(k2, s2, a_nxt, b_nxt, pres_nxt);
+    if (k2 >= 0) load_raw(k2, s2, a_nxt, b_nxt);
     __builtin_amdgcn_sched_barrier(0);   // loads are in flight ...
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -197,8 +188,16 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
   }
 
   // ---- epilogue: acc[n][reg] -> row (reg&3)+8*(reg>>2)+4*half, column nb0*32 + n*32 + arow
-  float *out = p.out + (p.ksplit > 1 ? static_cast<long long>(ks) * p.M_out * p.Cout : 0);
-  const bool add_res = p.residual != nullptr && p.ksplit == 1;
+  const bool final_out = p.ksplit == 1;
+  float *out = p.out + (final_out ? 0 : static_cast<long long>(ks) * p.M_out * p.Cout);
+  const bool add_res = p.residual != nullptr && final_out;
+  const bool post = p.post_scale != nullptr && final_out;
+  float ps[NBW], pb[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) {
+    ps[n] = post ? p.post_scale[coff[n]] : 1.f;
+    pb[n] = post ? p.post_shift[coff[n]] : 0.f;
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
@@ -210,6 +209,7 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
       if (n < nbw && col + n * 32 < p.Cout) {
         float v = acc[n][reg];
         if (add_res) v += p.residual[off + n * 32];
+        if (post) v = fmaxf(fmaf(v, ps[n], pb[n]), 0.f);
         out[off + n * 32] = v;
       }
     }
@@ -217,196 +217,344 @@ __global__ void __launch_bounds__(256) gather_conv_v2_kernel(ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// v3 main loop for Cin % 32 == 0: 32-channel slices (16 MFMA steps x NBW per iteration), operands
-// fetched with buffer loads whose per-lane offsets are loop invariants (all per-iteration address
-// arithmetic is scalar), two register sets used alternately (no copies), the prefetch of slice
-// t+1 is issued before slice t's MFMA block so that its latency hides under >= 1024 cycles of
-// matrix work.
+// Main kernel: persistent workgroups (Cin % 16 == 0, plan present).
+//   * grid = resident workgroups only; workgroup b walks units b, 2G-1-b, 2G+b, ... of the
+//     heaviest-first unit list (snake), so every workgroup gets one unit of every weight band.
+//   * unit = (32-row tile, one 32-column block, offset range); its (offset, slice) items are
+//     split evenly over the 4 waves (imbalance <= 1 slice); partial sums meet in LDS and are added
+//     in a fixed order.
+//   * the matrix loop holds nothing but loads and MFMAs: 2 dwordx4 of the gathered row, 2 dwordx4
+//     of packed weights, 8 MFMAs per slice; lane offsets are loop invariants, per-slice address
+//     arithmetic is scalar; an absent neighbour is a load past the end of the buffer (returns 0).
+//   * all the metadata of the NEXT unit (gather-table block, rows, mask) is fetched while the
+//     current unit's matrix loop runs and is published to the other LDS buffer under the same
+//     barrier as the partial sums; the first operand loads and the residual rows of the next unit
+//     are requested before the current unit's stores are issued, so memory latency (1.5-2 us
+//     under load) is exposed once per workgroup, not three times per unit.
+//   * units whose column blocks share a tile run on the same XCD (unit u -> XCD u % 8), so the
+//     second column block finds the gathered rows in that XCD's L2.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMetaInts = kTileRows * kMaxK + kTileRows + 4;   // gather block, rows, mask
 
-template <int NBW, int CK>
-__global__ void __launch_bounds__(256) gather_conv_v3_kernel(ConvArgs p, unsigned in_bytes,
-                                                            unsigned w_bytes) {
+template <int CK, int DEPTH, int TRACE>
+__global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
+                                                                    unsigned w_bytes) {
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
-  constexpr int NQ = HC / 4;   // dwordx4 loads per lane per slice
+  constexpr int NQ = HC / 4;   // dwordx4 loads per lane per operand per slice
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // wave id through readfirstlane: everything derived from it is then provably wave-uniform, so
+  // wave id through readfirstlane: everything derived from it is provably wave-uniform, so
   // buffer-load scalar offsets stay in SGPRs (no waterfall loops)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float *red = reinterpret_cast<float *>(smem_raw);                      // [4][NBW][16][64]
-  float *bn_lds = red + kWavesPerWg * NBW * 16 * 64;                      // [2][Cin]
-  int32_t *nbr_lds = reinterpret_cast<int32_t *>(bn_lds + 2 * p.Cin);     // [32][kMaxK]
-  int32_t *rows_lds = nbr_lds + kTileRows * kMaxK;                        // [32]
-  if (p.bn_scale) {
-    for (int c = threadIdx.x; c < p.Cin; c += 256) {
-      bn_lds[c] = p.bn_scale[c];
-      bn_lds[p.Cin + c] = p.bn_shift[c];
-    }
-  }
-  // workgroup = (tile, column unit, offset range); its 4 waves split the tile's offsets
-  const int units_per_tile = p.col_units * p.ksplit;
-  int tile = blockIdx.x / units_per_tile;
-  const int sub = blockIdx.x % units_per_tile;
-  const int cu = sub % p.col_units, ks = sub / p.col_units;
-  const int nb0 = cu * p.blocks_per_unit;
-  const int nbw = min(p.blocks_per_unit, (p.Cout + 31) / 32 - nb0);
-  const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
   const int arow = lane & 31, ahalf = lane >> 5;
-  // plan layout: rows and gather-table block of the tile are contiguous, independent loads
-  if (threadIdx.x < kTileRows) rows_lds[threadIdx.x] = p.order[tile * kTileRows + threadIdx.x];
-  {
-    const int32_t *src = p.nbr_tiles + static_cast<long long>(tile) * kTileRows * p.K;
-    for (int e = threadIdx.x; e < kTileRows * p.K; e += 256) {
-      const int r = e / p.K, k = e - r * p.K;
-      nbr_lds[r * kMaxK + k] = src[e];
-    }
-  }
-  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem_raw);                  // [4 waves][16][64]
+  float *res_lds = red + kWavesPerWg * 16 * 64;                       // [16][64]
+  int32_t *meta_lds = reinterpret_cast<int32_t *>(res_lds + 16 * 64);   // [2][kMetaInts]
 
-  uint32_t wg_mask = p.tile_mask ? p.tile_mask[tile] : 0xffffffffu;
-  wg_mask &= (k_hi >= 32 ? 0xffffffffu : ((1u << k_hi) - 1u)) & ~((1u << k_lo) - 1u);
-  // offsets are dealt to the 4 waves round-robin by their rank among the set bits
-  uint32_t mask = 0;
-  {
-    uint32_t m = wg_mask;
-    int rank = 0;
-    while (m) {
-      const uint32_t low = m & (0u - m);
-      if ((rank & (kWavesPerWg - 1)) == wave) mask |= low;
-      m ^= low;
-      ++rank;
-    }
-  }
-  mask = __builtin_amdgcn_readfirstlane(mask);
-
-  f32x16 acc[NBW];
-#pragma unroll
-  for (int n = 0; n < NBW; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
+  const int G = gridDim.x;
+  const int units_per_tile = p.col_units * p.ksplit;
+  const int num_units = p.num_units;
   const int n_slices = p.Cin / CK;
-  const int col = nb0 * 32 + arow;
+  const int c8 = p.Cin / 8;
+  const int tileK = kTileRows * p.K;       // words of a tile's gather block (row-major, stride K)
+  const int nbr_base = arow * p.K;
+  const bool final_out = p.ksplit == 1;
+  const bool add_res = p.residual != nullptr && final_out;
+  const bool post = p.post_scale != nullptr && final_out;
+  const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
+  const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;
+
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, w_bytes, 0x00020000);
-  // loop-invariant per-lane byte offsets of the weight reads (surplus blocks repeat the last one)
-  int v_w[NBW];
-#pragma unroll
-  for (int n = 0; n < NBW; ++n)
-    v_w[n] = ((ahalf * HC) * p.Cout + min(col + min(n, nbw - 1) * 32, p.Cout - 1)) * 4;
-  const int row_stride = p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(add_res ? p.residual : p.in), 0, add_res ? out_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ps = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(post ? p.post_scale : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(post ? p.post_shift : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t *>(p.nbr_tiles), 0, static_cast<unsigned>(num_tiles) * tileK * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ord = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t *>(p.order), 0, static_cast<unsigned>(num_tiles) * kTileRows * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t *>(p.tile_mask), 0, static_cast<unsigned>(num_tiles) * 4u, 0x00020000);
 
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  struct Slice {
-    f4 a[NQ];         // HC channels of the gathered row
-    float b[NBW][HC];
-    bool present;
+  // x / d for the few small wave-uniform divisors of the unit arithmetic: one s_mul_hi with a
+  // host-made reciprocal (exact for x * d < 2^32; magic 0 means d == 1)
+  auto udiv = [](unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; };
+
+  // unit -> (tile, column block, offset range).  Full groups of 8 x units_per_tile units are laid
+  // out so that all units of a tile have the same u % 8 (same XCD).
+  const int group = 8 * units_per_tile;
+  const int full = num_units / group * group;
+  struct Unit { int tile, cu, ks; };
+  auto decode = [&](int u) {
+    Unit d;
+    int sub;
+    if (u < full) {
+      const int blk = udiv(u >> 3, p.magic_upt);
+      const int i = u - blk * group;
+      d.tile = blk * 8 + (i & 7);
+      sub = i >> 3;
+    } else {
+      d.tile = udiv(u, p.magic_upt);
+      sub = u - d.tile * units_per_tile;
+    }
+    d.ks = udiv(sub, p.magic_cu);
+    d.cu = sub - d.ks * p.col_units;
+    return d;
   };
-  Slice S0, S1;
 
-  auto load = [&](int k, int s, Slice &S) {
-    const int src = nbr_lds[arow * kMaxK + k];
-    S.present = src >= 0;
-    const int v_a = ((S.present ? src : 0) * p.Cin + ahalf * HC) * 4;
+  // ---- metadata of a unit: 4 gather-table words per thread, one row id, the tile mask.
+  //      Branch-free (out-of-range lanes read past the buffer) so that the loads stay in flight
+  //      across the matrix loop.
+  struct Meta { int nbr[4]; int row; int mask; };
+  auto fetch = [&](const Unit &d, Meta &m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = threadIdx.x + q * 256;
+      const unsigned off = e < tileK ? static_cast<unsigned>(d.tile * tileK + e) * 4u : kOob;
+      m.nbr[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, off, 0, 0);
+    }
+    m.row = __builtin_amdgcn_raw_buffer_load_b32(
+        rs_ord, threadIdx.x < kTileRows ? static_cast<unsigned>(d.tile * kTileRows + threadIdx.x) * 4u : kOob, 0, 0);
+    m.mask = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, static_cast<unsigned>(d.tile) * 4u, 0, 0);
+  };
+  // LDS block of a unit: [0, 32*K) gather block as fetched (stride K), then 32 rows, then the mask
+  constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
+  auto publish = [&](const Meta &m, int buf) {
+    int32_t *dst = meta_lds + buf * kMetaInts;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = threadIdx.x + q * 256;
+      if (q < 3 || e < kRowsAt) dst[e] = m.nbr[q];     // words past 32*K are zeros nobody reads
+    }
+    if (threadIdx.x < kTileRows) dst[kRowsAt + threadIdx.x] = m.row;
+    if (threadIdx.x == 0) dst[kMaskAt] = m.mask;
+  };
+
+  struct Slice { f4 a[NQ]; f4 b[NQ]; };
+  // per-unit context (wave-uniform scalars + the lane's column)
+  struct Ctx {
+    const int32_t *meta;   // LDS block of the unit
+    uint32_t wg_mask;
+    int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
+    int v_w;
+    float ps, pb;
+    bool col_ok;
+  };
+
+  Slice S[DEPTH];   // operand ring: DEPTH-1 slices of loads in flight behind the one multiplied
+  float resv[4];
+
+  // lane (h, i) owns channels s*CK + h*HC .. + HC-1 of gathered row i: HC*4 contiguous bytes of the
+  // row (CK = 32: the half-wave pair reads the row's whole 128-B line in one slice) and the
+  // matching HC/8 packed weight blocks of its column
+  auto load = [&](const Ctx &c, int k, int s, Slice &S) {
+    const int src = c.meta[nbr_base + k];
+    const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + ahalf * HC) * 4u : kOob;
     const int s_a = s * (CK * 4);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, 0));
-    const int s_w = (k * p.Cin + s * CK) * row_stride;
+    const int s_w = (k * c8 + s * (CK / 8)) * p.Cout * 32;
 #pragma unroll
-    for (int j = 0; j < HC; ++j)
-#pragma unroll
-      for (int n = 0; n < NBW; ++n)
-        S.b[n][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, v_w[n], s_w + j * row_stride, 0));
+    for (int q = 0; q < NQ; ++q)
+      S.b[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                          rs_w, c.v_w + (q & 1) * 16, s_w + (q >> 1) * (p.Cout * 32), 0));
   };
-  auto compute = [&](int s, Slice &S) {
-    float a[HC];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { a[4 * q] = S.a[q][0]; a[4 * q + 1] = S.a[q][1]; a[4 * q + 2] = S.a[q][2]; a[4 * q + 3] = S.a[q][3]; }
-    if (p.bn_scale) {
-      const int c = s * CK + ahalf * HC;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const float4 sc = *reinterpret_cast<const float4 *>(bn_lds + c + 4 * q);
-        const float4 sh = *reinterpret_cast<const float4 *>(bn_lds + p.Cin + c + 4 * q);
-        a[4 * q] = fmaxf(fmaf(a[4 * q], sc.x, sh.x), 0.f);
-        a[4 * q + 1] = fmaxf(fmaf(a[4 * q + 1], sc.y, sh.y), 0.f);
-        a[4 * q + 2] = fmaxf(fmaf(a[4 * q + 2], sc.z, sh.z), 0.f);
-        a[4 * q + 3] = fmaxf(fmaf(a[4 * q + 3], sc.w, sh.w), 0.f);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < HC; ++j) a[j] = S.present ? a[j] : 0.f;
-#pragma unroll
-    for (int j = 0; j < HC; ++j)
-#pragma unroll
-      for (int n = 0; n < NBW; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], S.b[n][j], acc[n], 0, 0, 0);
-  };
-  auto advance = [&](int &k, int &s) {
+
+  auto advance = [&](const Ctx &c, int &k, int &s) {
     if (++s == n_slices) {
       s = 0;
-      const uint32_t rest = mask & ~((2u << k) - 1u);
-      k = rest ? __builtin_ctz(rest) : -1;
+      const uint32_t rest = c.wg_mask & ~((2u << k) - 1u);
+      k = rest ? __builtin_ctz(rest) : k;
     }
   };
 
-  // Every load below is issued unconditionally (past the end the current slice is re-read and
-  // dropped): with no branch between a prefetch and the MFMA block that precedes its use, hipcc's
-  // wait-count insertion keeps exact counts (vmcnt(20*NBW-ish) instead of draining the prefetch).
-  int k = mask ? __builtin_ctz(mask) : -1, s = 0;
-  if (k >= 0) {
-    load(k, s, S0);
-    while (true) {
-      int k1 = k, s1 = s;
-      advance(k1, s1);
-      const bool more1 = k1 >= 0;
-      load(more1 ? k1 : k, more1 ? s1 : s, S1);
-      __builtin_amdgcn_sched_barrier(0);   // prefetch of the next slice is in flight ...
-      compute(s, S0);
-      __builtin_amdgcn_sched_barrier(0);   // ... and is only consumed after this MFMA block
-      if (!more1) break;
-      int k2 = k1, s2 = s1;
-      advance(k2, s2);
-      const bool more2 = k2 >= 0;
-      load(more2 ? k2 : k1, more2 ? s2 : s1, S0);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(s1, S1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!more2) break;
-      k = k2;
-      s = s2;
+  // split the unit's (offset, slice) items over the waves, request the first operand slices, the
+  // residual rows and the epilogue constants.  Needs the unit's metadata in LDS.
+  auto setup = [&](const Unit &d, int buf, Ctx &c) {
+    c.ks = d.ks;
+    c.meta = meta_lds + buf * kMetaInts;
+    uint32_t m = static_cast<uint32_t>(c.meta[kMaskAt]);
+    if (!final_out) {
+      const int k_lo = d.ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
+      m &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);      // K <= 27
     }
-  }
+    m = __builtin_amdgcn_readfirstlane(m);
+    c.wg_mask = m;
+    c.col = d.cu * 32 + arow;
+    c.col_ok = c.col < p.Cout;
+    const int colc = min(c.col, p.Cout - 1);
+    c.v_w = (ahalf * (HC / 8) * p.Cout + colc) * 32;
+    const int items = __builtin_popcount(m) * n_slices;
+    const int per = (items + kWavesPerWg - 1) >> 2;
+    const int begin = min(items, wave * per);
+    c.rem = min(items, begin + per) - begin;
+    int rank = udiv(begin, p.magic_nsl);
+    c.s = begin - rank * n_slices;
+    uint32_t mm = m;
+    for (; rank > 0; --rank) mm &= mm - 1u;
+    c.k = mm ? __builtin_ctz(mm) : 0;
+    load(c, c.k, c.s, S[0]);
+    c.kp = c.k;
+    c.sp = c.s;
+#pragma unroll
+    for (int i = 1; i < DEPTH - 1; ++i) {
+      if (i < c.rem) advance(c, c.kp, c.sp);
+      load(c, c.kp, c.sp, S[i]);
+    }
+    const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
+    const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const unsigned off = (row4[rr] >= 0 && c.col_ok)
+                               ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
+      resv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
+    }
+    c.ps = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ps, colc * 4, 0, 0));
+    c.pb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pb, colc * 4, 0, 0));
+  };
 
-  // ---- cross-wave reduction through LDS in a fixed order (w0+w1+w2+w3), then each wave stores
-  //      4 of the 16 accumulator rows-groups: reg -> row (reg&3)+8*(reg>>2)+4*half
+  f32x16 acc;
+  auto compute = [&](Slice &S) {
+    // every operand of the slice is in registers before the matrix block starts: one wait, then
+    // back-to-back MFMAs with nothing in between
 #pragma unroll
-  for (int n = 0; n < NBW; ++n)
+    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(S.a[q]), "+v"(S.b[q]));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) red[((wave * NBW + n) * 16 + reg) * 64 + lane] = acc[n][reg];
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S.a[q][j], S.b[q][j], acc, 0, 0, 0);
+  };
+
+  unsigned long long stamp[8];
+  auto mark = [&](int i) {
+    if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter();
+  };
+
+  // ---- work distribution: static snake over the descending unit list.  (A dynamic tail fed by
+  //      per-XCD atomic counters was measured slower: a returning atomic sits in the same in-order
+  //      return queue as the wave's operand loads and stalls its matrix loop for microseconds.)
+  auto static_unit = [&](int r) {
+    return r * G + ((r & 1) ? G - 1 - static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x));
+  };
+
+  // ---- prologue of the workgroup: metadata of its first unit
+  int round = 0, u = blockIdx.x, buf = 0;
+  Unit du = decode(u);
+  Meta m;
+  fetch(du, m);
+  publish(m, 0);
   __syncthreads();
-  float *out = p.out + (p.ksplit > 1 ? static_cast<long long>(ks) * p.M_out * p.Cout : 0);
-  const bool add_res = p.residual != nullptr && p.ksplit == 1;
+  Ctx c;
+  setup(du, 0, c);
+
+  while (true) {
+    mark(0);
+    const int un = static_unit(round + 1);
+    const bool has_next = un < num_units;
+    const Unit dn = decode(has_next ? un : u);
+    fetch(dn, m);                       // lands during the matrix loop
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int reg = wave * 4 + rr;
-    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
-    const int row = rows_lds[r];
-    if (row < 0) continue;
-    const long long off = static_cast<long long>(row) * p.Cout + col;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // ---- matrix loop over this wave's items.  S[0..DEPTH-2] already hold items 0..DEPTH-2
+    //      (setup).  Past the end the last item is re-read and dropped, so every load is
+    //      unconditional and the wait counts stay exact; whole groups of DEPTH items keep the loop
+    //      single-exit (no register rotation), the tail is straight-line code.
+    {
+      int kp = c.kp, sp = c.sp, issued = DEPTH - 1;
+      const int rem = c.rem;
+      for (int g = rem / DEPTH; g > 0; --g) {
 #pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-      if (n < nbw && col + n * 32 < p.Cout) {
-        float v = red[((0 * NBW + n) * 16 + reg) * 64 + lane];
+        for (int i = 0; i < DEPTH; ++i) {
+          int k2 = kp, s2 = sp;
+          advance(c, k2, s2);
+          const bool more = issued < rem;
+          kp = more ? k2 : kp;
+          sp = more ? s2 : sp;
+          ++issued;
+          load(c, kp, sp, S[(i + DEPTH - 1) % DEPTH]);
+          __builtin_amdgcn_sched_barrier(0);   // the new slice's loads are in flight ...
+          compute(S[i]);
+          __builtin_amdgcn_sched_barrier(0);   // ... and are only consumed DEPTH-1 blocks later
+        }
+      }
+      const int tail = rem % DEPTH;            // the ring is back at S[0]
 #pragma unroll
-        for (int w = 1; w < kWavesPerWg; ++w) v += red[((w * NBW + n) * 16 + reg) * 64 + lane];
-        if (add_res) v += p.residual[off + n * 32];
-        out[off + n * 32] = v;
+      for (int i = 0; i < DEPTH - 1; ++i)
+        if (i < tail) compute(S[i]);
+    }
+    if constexpr (TRACE) { asm volatile("" : "+v"(acc[0])); }
+    mark(1);
+
+    // ---- partial sums + residual rows + next unit's metadata meet in LDS
+    __syncthreads();                     // the previous unit's epilogue has read `red`
+    mark(2);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) res_lds[(wave * 4 + rr) * 64 + lane] = resv[rr];
+    publish(m, buf ^ 1);
+    __syncthreads();
+    mark(3);
+
+    // ---- epilogue operands first (all LDS reads in flight together), then the next unit's first
+    //      operand loads, then the stores: fixed-order sum w0+w1+w2+w3 (+ residual, post); each
+    //      wave stores 4 row groups, padding rows go past the end of the buffer (dropped)
+    float v[4];
+    unsigned o_off[4];
+    {
+      const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
+      const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
+      float part[4][5];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int reg = wave * 4 + rr;
+#pragma unroll
+        for (int w = 0; w < kWavesPerWg; ++w) part[rr][w] = red[(w * 16 + reg) * 64 + lane];
+        part[rr][4] = res_lds[reg * 64 + lane];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float t = ((part[rr][0] + part[rr][1]) + part[rr][2]) + part[rr][3];
+        t += part[rr][4];
+        if (post) t = fmaxf(fmaf(t, c.ps, c.pb), 0.f);
+        v[rr] = t;
+        o_off[rr] = (row4[rr] >= 0 && c.col_ok)
+                        ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
       }
     }
+    const unsigned o_base = final_out ? 0u : static_cast<unsigned>(c.ks) * out_bytes;
+    const int rem_done = c.rem;
+    setup(dn, has_next ? (buf ^ 1) : buf, c);
+    mark(4);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), rs_out, o_off[rr], o_base, 0);
+    mark(5);
+    if constexpr (TRACE) {
+      if (lane == 0 && p.trace) {
+        unsigned long long *t = p.trace + (static_cast<long long>(u) * kWavesPerWg + wave) * 8;
+        for (int i = 0; i < 6; ++i) t[i] = stamp[i];
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        t[6] = static_cast<unsigned long long>(blockIdx.x);
+        t[7] = (static_cast<unsigned long long>(rem_done) << 48) | (static_cast<unsigned long long>(xcc & 0xf) << 32) | hw;
+      }
+    }
+    if (!has_next) break;
+    u = un;
+    ++round;
+    buf ^= 1;
   }
 }
 
@@ -463,10 +611,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const float *__restrict
   }
 }
 
-// fixed-order reduction of the offset-split partial sums (+ residual)
+// fixed-order reduction of the offset-split partial sums (+ residual, post)
 __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restrict__ partial,
                                                          const float4 *__restrict__ residual,
-                                                         int ksplit, long long n4,
+                                                         const float *__restrict__ post_scale,
+                                                         const float *__restrict__ post_shift,
+                                                         int ksplit, long long n4, int cout4,
                                                          float4 *__restrict__ out) {
   for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n4; t += gridDim.x * 256LL) {
     float4 a = partial[t];
@@ -478,6 +628,13 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restri
       const float4 r = residual[t];
       a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
     }
+    if (post_scale) {
+      const int c = static_cast<int>(t % cout4) * 4;
+      a.x = fmaxf(fmaf(a.x, post_scale[c], post_shift[c]), 0.f);
+      a.y = fmaxf(fmaf(a.y, post_scale[c + 1], post_shift[c + 1]), 0.f);
+      a.z = fmaxf(fmaf(a.z, post_scale[c + 2], post_shift[c + 2]), 0.f);
+      a.w = fmaxf(fmaf(a.w, post_scale[c + 3], post_shift[c + 3]), 0.f);
+    }
     out[t] = a;
   }
 }
@@ -486,10 +643,11 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restri
 // (Cout % 4 != 0).  One thread per (row, cout).
 __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
     const float *__restrict__ in, const int32_t *__restrict__ nbr, int M_out, int K, int Cin,
-    int Cout, const float *__restrict__ w_kio, const float *__restrict__ bn_scale,
-    const float *__restrict__ bn_shift, const float *__restrict__ residual,
+    int Cout, const float *__restrict__ w_k8, const float *__restrict__ post_scale,
+    const float *__restrict__ post_shift, const float *__restrict__ residual,
     float *__restrict__ out) {
   const int64_t total = static_cast<int64_t>(M_out) * Cout;
+  const int c8 = (Cin + 7) / 8;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
     const int j = static_cast<int>(t / Cout), co = static_cast<int>(t - static_cast<int64_t>(j) * Cout);
     float acc = 0.f;
@@ -497,24 +655,43 @@ __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
       const int s = nbr[static_cast<int64_t>(j) * K + k];
       if (s < 0) continue;
       const float *x = in + static_cast<int64_t>(s) * Cin;
-      const float *w = w_kio + static_cast<int64_t>(k) * Cin * Cout + co;
-      for (int ci = 0; ci < Cin; ++ci) {
-        float v = x[ci];
-        if (bn_scale) v = fmaxf(fmaf(v, bn_scale[ci], bn_shift[ci]), 0.f);
-        acc = fmaf(v, w[static_cast<int64_t>(ci) * Cout], acc);
-      }
+      for (int ci = 0; ci < Cin; ++ci)
+        acc = fmaf(x[ci], w_k8[((static_cast<int64_t>(k) * c8 + (ci >> 3)) * Cout + co) * 8 + (ci & 7)], acc);
     }
     if (residual) acc += residual[t];
+    if (post_scale) acc = fmaxf(fmaf(acc, post_scale[co], post_shift[co]), 0.f);
     out[t] = acc;
   }
 }
 
+// weight packing: src [Cout][K][Cin] (spconv "OKKKI", src_kio == 0) or [K][Cin][Cout]
+// (src_kio == 1) -> [K][ceil(Cin/8)][Cout][8], zero padded
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ w, int cout, int K,
+                                                         int cin, int src_kio,
+                                                         float *__restrict__ out) {
+  const int c8 = (cin + 7) / 8;
+  const int64_t total = static_cast<int64_t>(K) * c8 * cout * 8;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int j = static_cast<int>(t & 7);
+    int64_t r = t >> 3;
+    const int co = static_cast<int>(r % cout);
+    r /= cout;
+    const int blk = static_cast<int>(r % c8), k = static_cast<int>(r / c8);
+    const int ci = blk * 8 + j;
+    float v = 0.f;
+    if (ci < cin)
+      v = src_kio ? w[(static_cast<int64_t>(k) * cin + ci) * cout + co]
+                  : w[(static_cast<int64_t>(co) * K + k) * cin + ci];
+    out[t] = v;
+  }
+}
+
 template <int NBW>
-static void launch_v2(const ConvArgs &a, int grid, size_t lds, bool vec, hipStream_t stream) {
+static void launch_tile(const ConvArgs &a, int grid, size_t lds, bool vec, hipStream_t stream) {
   if (vec)
-    gather_conv_v2_kernel<NBW, true><<<grid, 256, lds, stream>>>(a);
+    gather_conv_tile_kernel<NBW, true><<<grid, 256, lds, stream>>>(a);
   else
-    gather_conv_v2_kernel<NBW, false><<<grid, 256, lds, stream>>>(a);
+    gather_conv_tile_kernel<NBW, false><<<grid, 256, lds, stream>>>(a);
 }
 
 }  // namespace sg
@@ -522,6 +699,19 @@ static void launch_v2(const ConvArgs &a, int grid, size_t lds, bool vec, hipStre
 using namespace sg;
 
 extern "C" {
+
+size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout) {
+  return static_cast<size_t>(kvol) * ((cin + 7) / 8) * cout * 8;
+}
+
+int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
+                          sg_stream_t stream) {
+  SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0, "sg_spconv_pack_weight: bad arguments");
+  const int64_t total = static_cast<int64_t>(sg_spconv_packed_weight_elems(kvol, cin, cout));
+  pack_weight_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>(w, cout, kvol, cin,
+                                                                         src_is_kio, w_k8);
+  return check_launch("sg_spconv_pack_weight");
+}
 
 // workspace for the offset-split path: ksplit_max * M_out * Cout floats
 size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
@@ -531,43 +721,46 @@ size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
 }
 
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
-                              int K, int Cin, int Cout, const float *w_kio, const float *bn_scale,
-                              const float *bn_shift, const float *residual, const int32_t *order,
+                              int K, int Cin, int Cout, const float *w_k8, const float *post_scale,
+                              const float *post_shift, const float *residual, const int32_t *order,
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream_) {
   SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
              "sg_spconv_gather_conv_f32: bad arguments (M_out=%d K=%d Cin=%d Cout=%d)", M_out, K,
              Cin, Cout);
-  SG_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr),
-             "sg_spconv_gather_conv_f32: bn_scale and bn_shift must come together");
+  SG_REQUIRE((post_scale == nullptr) == (post_shift == nullptr),
+             "sg_spconv_gather_conv_f32: post_scale and post_shift must come together");
   if (M_out == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
   if (Cout % 4 != 0) {
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
-                                stream>>>(in, nbr, M_out, K, Cin, Cout, w_kio, bn_scale, bn_shift,
+                                stream>>>(in, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,
                                           residual, out);
     return check_launch("sg_spconv_gather_conv_f32(scalar)");
   }
   const int NB = (Cout + 31) / 32;
   const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
-  // ---- decomposition: aim at >= ~2048 waves; widest column block that still fills the chip
-  const int target = 2048;
   const long long in_bytes_ll = static_cast<long long>(num_in_rows) * Cin * 4;
-  const long long w_bytes_ll = static_cast<long long>(K) * Cin * Cout * 4;
-  const bool use_v3 = Cin % 32 == 0 && in_bytes_ll < (1LL << 31) && num_in_rows > 0 &&
-                      order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr;
-  const int waves_per_unit = use_v3 ? kWavesPerWg : 1;   // v3: a workgroup's 4 waves share a tile
-  static const int bpu_env = getenv("SG_CONV_BPU") ? atoi(getenv("SG_CONV_BPU")) : 0;
-  int bpu = 1;                                    // 32-column blocks per unit
-  if (bpu_env) bpu = bpu_env < NB ? bpu_env : NB;
-  while (bpu > 1 &&
-         static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) * waves_per_unit < target)
-    --bpu;
-  int col_units = (NB + bpu - 1) / bpu;
+  const long long w_bytes_ll = static_cast<long long>(sg_spconv_packed_weight_elems(K, Cin, Cout)) * 4;
+  const bool persistent = Cin % 16 == 0 && in_bytes_ll < (1LL << 31) && num_in_rows > 0 &&
+                          static_cast<long long>(M_out) * Cout * 4 * kMaxK < (1LL << 32) &&
+                          static_cast<long long>(num_tiles) * kTileRows * K * 4 < (1LL << 31) &&
+                          order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr;
+  // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
+  //      that still fills the chip, the persistent kernel always works on 32-column blocks
+  const int target = 2048;
+  const int waves_per_unit = persistent ? kWavesPerWg : 1;
+  int bpu = 1;
+  if (!persistent) {
+    bpu = NB < 4 ? NB : 4;
+    while (bpu > 1 && static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) < target) --bpu;
+  }
+  const int col_units = (NB + bpu - 1) / bpu;
   int ksplit = 1;
-  long long waves = static_cast<long long>(num_tiles) * col_units * waves_per_unit;
+  const long long waves = static_cast<long long>(num_tiles) * col_units * waves_per_unit;
   if (waves < target / 2) {
-    { long long want = (target / 2 + waves - 1) / waves; ksplit = static_cast<int>(want < K ? want : K); }
+    const long long want = (target / 2 + waves - 1) / waves;
+    ksplit = static_cast<int>(want < K ? want : K);
     const size_t need = static_cast<size_t>(ksplit) * M_out * Cout * sizeof(float);
     if (ksplit > 1 && (ws == nullptr || ws_bytes < need)) ksplit = 1;   // no scratch: stay exact
   }
@@ -575,44 +768,88 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   ksplit = (K + k_per_split - 1) / k_per_split;
 
   ConvArgs a;
-  a.in = in; a.nbr = nbr; a.w = w_kio; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+  a.in = in; a.nbr = nbr; a.w = w_k8; a.post_scale = post_scale; a.post_shift = post_shift;
   a.residual = residual; a.order = order; a.tile_mask = tile_mask; a.nbr_tiles = nbr_tiles;
   a.out = ksplit > 1 ? static_cast<float *>(ws) : out;
   a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
-
-  const int cin_pad = (Cin + kCk - 1) / kCk * kCk;
-  const size_t lds = 2 * cin_pad * sizeof(float) + kWavesPerWg * kTileRows * kMaxK * sizeof(int32_t);
+  a.trace = nullptr;
   const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
-  const int grid = static_cast<int>((units + kWavesPerWg - 1) / kWavesPerWg);
-  const bool vec = (Cin % kCk) == 0;
-  if (use_v3 && bpu <= 2) {
-    const size_t lds3 = (static_cast<size_t>(kWavesPerWg) * bpu * 16 * 64 + 2 * Cin) * sizeof(float) +
-                        (kTileRows * kMaxK + kTileRows) * sizeof(int32_t);
-    const unsigned ib = static_cast<unsigned>(in_bytes_ll), wb = static_cast<unsigned>(w_bytes_ll);
-    static const int ck_env = getenv("SG_CONV_CK") ? atoi(getenv("SG_CONV_CK")) : 0;
-    const int ck = ck_env ? ck_env : 16;
-    const int grid3 = static_cast<int>(units);      // one workgroup per unit
-    if (bpu == 1 && ck == 16) gather_conv_v3_kernel<1, 16><<<grid3, 256, lds3, stream>>>(a, ib, wb);
-    else if (bpu == 1) gather_conv_v3_kernel<1, 32><<<grid3, 256, lds3, stream>>>(a, ib, wb);
-    else if (ck == 16) gather_conv_v3_kernel<2, 16><<<grid3, 256, lds3, stream>>>(a, ib, wb);
-    else gather_conv_v3_kernel<2, 32><<<grid3, 256, lds3, stream>>>(a, ib, wb);
-  } else
-  switch (bpu) {
-    case 1: launch_v2<1>(a, grid, lds, vec, stream); break;
-    case 2: launch_v2<2>(a, grid, lds, vec, stream); break;
-    case 3: launch_v2<3>(a, grid, lds, vec, stream); break;
-    default: launch_v2<4>(a, grid, lds, vec, stream); break;
+  a.num_units = static_cast<int>(units);
+  auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
+  a.magic_upt = magic(static_cast<unsigned>(col_units * ksplit));
+  a.magic_cu = magic(static_cast<unsigned>(col_units));
+  a.magic_nsl = 0;
+
+  if (persistent) {
+    // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
+    // XCD u % 8)
+    const size_t lds = (static_cast<size_t>(kWavesPerWg) * 16 * 64 + 16 * 64) * sizeof(float) +
+                       2 * kMetaInts * sizeof(int32_t);
+    static int num_cu = 0, occ = 0;
+    if (num_cu == 0) {
+      int dev = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (num_cu <= 0) num_cu = 256;
+    }
+    // 16-channel slices, 2-deep operand ring: measured best on gfx950 against 32-channel slices
+    // (whole 128-B lines per gather) and a 3-deep ring at every occupancy (profiles/README.md)
+    constexpr int kSliceCh = 16, kRing = 2;
+    auto launch = [&](int g_, bool trace) {
+      const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
+      if (trace) gather_conv_persistent_kernel<kSliceCh, kRing, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else gather_conv_persistent_kernel<kSliceCh, kRing, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+    };
+    a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
+    if (occ == 0) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_conv_persistent_kernel<kSliceCh, kRing, 0>, 256, lds);
+      if (const char *e = getenv("SG_CONV_OCC")) occ = atoi(e) > 0 && atoi(e) < occ ? atoi(e) : occ;   // developer knob
+      if (occ < 1) occ = 1;
+    }
+    long long g = static_cast<long long>(num_cu) * occ;
+    if (g > units) g = units;
+    if (g >= 8) g -= g % 8;
+    static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
+    if (trace_env) {
+      const size_t nb = static_cast<size_t>(units) * kWavesPerWg * 8 * sizeof(unsigned long long);
+      unsigned long long *dbuf = nullptr;
+      hipMalloc(&dbuf, nb);
+      hipMemsetAsync(dbuf, 0, nb, stream);
+      a.trace = dbuf;
+      launch(static_cast<int>(g), true);
+      hipStreamSynchronize(stream);
+      std::vector<unsigned long long> h(nb / 8);
+      hipMemcpy(h.data(), dbuf, nb, hipMemcpyDeviceToHost);
+      hipFree(dbuf);
+      if (FILE *f = fopen(trace_env, "ab")) {
+        long long hdr[8] = {M_out, K, Cin, Cout, units, col_units, ksplit, g};
+        fwrite(hdr, 8, 8, f);
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    } else {
+      launch(static_cast<int>(g), false);
+    }
+  } else {
+    const size_t lds = kWavesPerWg * kTileRows * kMaxK * sizeof(int32_t);
+    const int grid = static_cast<int>((units + kWavesPerWg - 1) / kWavesPerWg);
+    const bool vec = (Cin % kCk) == 0;
+    switch (bpu) {
+      case 1: launch_tile<1>(a, grid, lds, vec, stream); break;
+      case 2: launch_tile<2>(a, grid, lds, vec, stream); break;
+      case 3: launch_tile<3>(a, grid, lds, vec, stream); break;
+      default: launch_tile<4>(a, grid, lds, vec, stream); break;
+    }
   }
   if (ksplit > 1) {
     const long long n4 = static_cast<long long>(M_out) * Cout / 4;
     conv_reduce_kernel<<<grid_for(n4, 256), 256, 0, stream>>>(
-        reinterpret_cast<const float4 *>(ws), reinterpret_cast<const float4 *>(residual), ksplit, n4,
-        reinterpret_cast<float4 *>(out));
+        reinterpret_cast<const float4 *>(ws), reinterpret_cast<const float4 *>(residual), post_scale,
+        post_shift, ksplit, n4, Cout / 4, reinterpret_cast<float4 *>(out));
   }
   return check_launch("sg_spconv_gather_conv_f32");
 }
-
 
 // dw_kio [K][Cin][Cout] must be zero-filled by the caller; `in` is the (already activated) input
 // the forward conv gathered from.

@@ -227,18 +227,6 @@ __global__ void __launch_bounds__(256) plan_emit_kernel(const int32_t *__restric
   }
 }
 
-__global__ void __launch_bounds__(256) weight_kio_kernel(const float *__restrict__ w, int cout, int K,
-                                                        int cin, float *__restrict__ out) {
-  const int64_t total = static_cast<int64_t>(cout) * K * cin;
-  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
-    // t indexes the output [K][cin][cout] so the stores are coalesced
-    const int co = static_cast<int>(t % cout);
-    const int64_t r = t / cout;
-    const int ci = static_cast<int>(r % cin), k = static_cast<int>(r / cin);
-    out[t] = w[(static_cast<int64_t>(co) * K + k) * cin + ci];
-  }
-}
-
 }  // namespace sg
 
 using namespace sg;
@@ -364,14 +352,6 @@ int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *t
   plan_emit_kernel<<<min(num_tiles, 4096), 256, 0, stream>>>(nbr, M, K, rs, tmask, torder, num_tiles,
                                                             order, tile_mask, nbr_tiles);
   return check_launch("sg_spconv_plan");
-}
-
-int sg_spconv_weight_to_kio(const float *w_okki, int cout, int kvol, int cin, float *w_kio,
-                            sg_stream_t stream) {
-  SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0, "sg_spconv_weight_to_kio: bad arguments");
-  weight_kio_kernel<<<grid_for(static_cast<int64_t>(cout) * kvol * cin, 256), 256, 0,
-                      as_stream(stream)>>>(w_okki, cout, kvol, cin, w_kio);
-  return check_launch("sg_spconv_weight_to_kio");
 }
 
 }  // extern "C"

@@ -172,8 +172,29 @@ def _plan_pairs(plan):
     return plan._pairs
 
 
-def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, residual=None):
-    """out[j] = residual[j] + sum_k act(features[nbr[j,k]]) @ w_kio[k]   (fp32, HIP)"""
+def pack_weight(w, cout, kvol, cin, src_is_kio):
+    """[Cout,K,Cin] (src_is_kio=False) or [K,Cin,Cout] (True) -> the conv kernel's "k8" layout"""
+    lib = L.lib()
+    src = w.detach().float().contiguous()
+    out = torch.empty(lib.sg_spconv_packed_weight_elems(kvol, cin, cout), dtype=torch.float32,
+                      device=w.device)
+    L.check(lib.sg_spconv_pack_weight(L.ptr(src), cout, kvol, cin, 1 if src_is_kio else 0,
+                                      L.ptr(out), L.stream()), 'sg_spconv_pack_weight')
+    return out
+
+
+def bn_relu(feats, scale, shift):
+    """relu(feats * scale + shift) over [M, C] rows, one elementwise HIP kernel"""
+    feats = feats.contiguous()
+    out = torch.empty_like(feats)
+    L.check(L.lib().sg_bn_relu_f32(L.ptr(feats), L.ptr(scale), L.ptr(shift), feats.shape[0],
+                                   feats.shape[1], 1, L.ptr(out), L.stream()), 'sg_bn_relu_f32')
+    return out
+
+
+def gather_conv(features, plan, w_k8, cout, post_scale=None, post_shift=None, residual=None):
+    """out[j] = post(residual[j] + sum_k features[nbr[j,k]] @ W[k])   (fp32, HIP);
+    post = relu(x*post_scale + post_shift) when given"""
     lib = L.lib()
     prof = PROFILER
     if prof is not None:
@@ -190,7 +211,7 @@ def gather_conv(features, plan, w_kio, cout, bn_scale=None, bn_shift=None, resid
         ev0.record()
     L.check(lib.sg_spconv_gather_conv_f32(
         L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
-        L.ptr(w_kio), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(residual), L.ptr(plan.order),
+        L.ptr(w_k8), L.ptr(post_scale), L.ptr(post_shift), L.ptr(residual), L.ptr(plan.order),
         L.ptr(plan.tile_mask), L.ptr(plan.nbr_tiles), L.ptr(out), L.ptr(ws),
         nb if ws is not None else 0, L.stream()),
         'sg_spconv_gather_conv_f32')
@@ -206,10 +227,10 @@ class _GatherConvFn(torch.autograd.Function):
     transposed gather table with transposed weights; weight gradient = sg_spconv_wgrad_f32."""
 
     @staticmethod
-    def forward(ctx, feats, weight, w_kio, plan, bwd_plan, flip_k):
+    def forward(ctx, feats, weight, w_k8, plan, bwd_plan, flip_k):
         ctx.save_for_backward(feats, weight)
         ctx.plan, ctx.bwd_plan, ctx.flip_k = plan, bwd_plan, flip_k
-        return gather_conv(feats, plan, w_kio, weight.shape[0])
+        return gather_conv(feats, plan, w_k8, weight.shape[0])
 
     @staticmethod
     def backward(ctx, g):
@@ -224,7 +245,7 @@ class _GatherConvFn(torch.autograd.Function):
             w_t = weight.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
             if ctx.flip_k:
                 w_t = w_t.flip(0)
-            g_feats = gather_conv(g, bwd_plan, w_t.contiguous(), cin)
+            g_feats = gather_conv(g, bwd_plan, pack_weight(w_t, cin, kvol, cout, True), cin)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((kvol, cin, cout), dtype=torch.float32, device=g.device)
             L.check(L.lib().sg_spconv_wgrad_f32(L.ptr(feats), L.ptr(g), L.ptr(plan.nbr), plan.num_out,
@@ -290,19 +311,13 @@ class SparseConvolution(SparseModule):
                 f'stride={self.stride}, subm={self.subm}, inverse={self.inverse}, '
                 f'indice_key={self.indice_key}')
 
-    # [Cout, K, Cin] -> [K, Cin, Cout], cached until the weight changes
-    def weight_kio(self):
+    # [Cout, K, Cin] -> packed kernel layout, cached until the weight changes
+    def weight_packed(self):
         w = self.weight
         key = (w._version, w.data_ptr(), w.device, w.dtype)
         if self._kio_cache is None or self._kio_cache[0] != key:
             kvol = int(torch.tensor(self.kernel_size).prod())
-            src = w.detach().float().contiguous()
-            out = torch.empty((kvol, self.in_channels, self.out_channels), dtype=torch.float32,
-                              device=w.device)
-            L.check(L.lib().sg_spconv_weight_to_kio(L.ptr(src), self.out_channels, kvol,
-                                                    self.in_channels, L.ptr(out), L.stream()),
-                    'sg_spconv_weight_to_kio')
-            self._kio_cache = (key, out)
+            self._kio_cache = (key, pack_weight(w, self.out_channels, kvol, self.in_channels, False))
         return self._kio_cache[1]
 
     def _rule_and_plan(self, input):
@@ -330,11 +345,13 @@ class SparseConvolution(SparseModule):
                 input.indice_dict[key] = rule
         return rule.plan, rule.out_indices, rule.out_spatial_shape, (lambda: rule.inv_plan), False
 
-    def forward(self, input, bn_scale=None, bn_shift=None, residual=None):
+    def forward(self, input, post_scale=None, post_shift=None, residual=None):
+        """post_scale/post_shift/residual: inference-only fused epilogue,
+        out = relu((conv(x) + residual) * post_scale + post_shift)"""
         assert isinstance(input, SparseConvTensor)
         feats = input.features
         if self.conv1x1:   # plain GEMM on the active rows (blocks.py:31-41 semantics)
-            assert bn_scale is None and residual is None
+            assert post_scale is None and residual is None
             out = torch.mm(feats, self.weight.view(self.out_channels, self.in_channels).T)
             if self.bias is not None:
                 out = out + self.bias
@@ -342,12 +359,13 @@ class SparseConvolution(SparseModule):
         plan, out_indices, out_shape, bwd_plan, flip_k = self._rule_and_plan(input)
         x = (feats if feats.dtype == torch.float32 else feats.float()).contiguous()
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            assert bn_scale is None and residual is None, 'fused prologue/epilogue is inference-only'
-            out = _GatherConvFn.apply(x, self.weight, self.weight_kio(), plan,
+            assert post_scale is None and residual is None, 'fused epilogue is inference-only'
+            out = _GatherConvFn.apply(x, self.weight, self.weight_packed(), plan,
                                       bwd_plan() if x.requires_grad else None, flip_k)
         else:
-            out = gather_conv(x, plan, self.weight_kio(), self.out_channels, bn_scale, bn_shift,
-                              residual)
+            assert post_scale is None or self.bias is None
+            out = gather_conv(x, plan, self.weight_packed(), self.out_channels, post_scale,
+                              post_shift, residual)
         if self.bias is not None:
             out = out + self.bias.float()
         if out.dtype != feats.dtype:
@@ -412,9 +430,9 @@ class SparseSequential(SparseModule):
     (BatchNorm1d, ReLU, Identity ...) are applied to ``.features``.  Children are named
     '0','1',... or by the OrderedDict keys (state-dict compatibility).
 
-    In eval mode the pre-activation pattern BatchNorm1d -> ReLU -> sparse conv (blocks.py:57-70,
-    99-119) runs as ONE kernel (BN+ReLU applied to the gathered rows), and BatchNorm1d -> ReLU at
-    the end of a sequence (softgroup.py:65) as one elementwise kernel."""
+    In eval mode BatchNorm1d -> ReLU runs as one elementwise kernel, and when it sits BETWEEN two
+    sparse convs (blocks.py:57-70: BN, ReLU, conv, BN, ReLU, conv) it is the epilogue of the first
+    conv; a residual is the epilogue of the last conv."""
 
     def __init__(self, *args, **kwargs):
         super().__init__()
@@ -458,19 +476,16 @@ class SparseSequential(SparseModule):
                     and input.indices.shape[0] != 0 and not _needs_grad(input.features))
             if fast and _fusable_bn(m) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 scale, shift = _bn_affine(m)
-                nxt = mods[i + 2] if i + 2 < len(mods) else None
-                if (isinstance(nxt, SparseConvolution) and not nxt.conv1x1
-                        and not _needs_grad(nxt.weight, nxt.bias)):
-                    input = nxt(input, scale, shift, residual if i + 2 == last_conv else None)
-                    i += 3
-                    continue
-                feats = input.features.contiguous()
-                out = torch.empty_like(feats)
-                L.check(L.lib().sg_bn_relu_f32(L.ptr(feats), L.ptr(scale), L.ptr(shift),
-                                               feats.shape[0], feats.shape[1], 1, L.ptr(out),
-                                               L.stream()), 'sg_bn_relu_f32')
-                input = input.replace_feature(out)
+                input = input.replace_feature(bn_relu(input.features, scale, shift))
                 i += 2
+                continue
+            if (fast and isinstance(m, SparseConvolution) and not m.conv1x1 and m.bias is None
+                    and not _needs_grad(m.weight) and i + 2 < len(mods) and _fusable_bn(mods[i + 1])
+                    and isinstance(mods[i + 2], nn.ReLU)):
+                # conv -> BN -> ReLU -> (more): BN+ReLU is this conv's epilogue
+                scale, shift = _bn_affine(mods[i + 1])
+                input = m(input, post_scale=scale, post_shift=shift)
+                i += 3
                 continue
             if is_spconv_module(m):
                 if isinstance(m, SparseConvolution) and i == last_conv and residual is not None:
