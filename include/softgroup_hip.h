@@ -271,6 +271,45 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
 int sg_spconv_wgrad_f32(const float *in, const float *g_out, const int32_t *nbr, int num_out_rows,
                         int kvol, int cin, int cout, float *dw_kio, sg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Native executor of the sparse U-Net (inference): the whole of
+ *   [input_conv] -> UBlock -> [output BatchNorm1d + ReLU]
+ * (softgroup/model/softgroup.py:60-65 backbone, :93-95 tiny U-Net; modules of
+ * softgroup/model/blocks.py:44-143) in one call: rulebooks, plans and convolutions are launched
+ * back to back from C++, device memory comes from the caller's arena.  All pointers are device
+ * pointers; weights are packed with sg_spconv_pack_weight, BatchNorm1d is passed in eval form
+ * y = x*scale + shift.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sg_unet_block {     /* ResidualBlock, blocks.py:44-79 */
+  int cin, cout;
+  const float *bn1_scale, *bn1_shift;   /* [cin]  conv_branch.0 */
+  const float *w1;                      /* SubMConv3d(cin, cout)   conv_branch.2 */
+  const float *bn2_scale, *bn2_shift;   /* [cout] conv_branch.3 */
+  const float *w2;                      /* SubMConv3d(cout, cout)  conv_branch.5 */
+  const float *w_i;                     /* i_branch 1x1 conv (cin != cout) or NULL */
+} sg_unet_block;
+typedef struct sg_unet_level {     /* UBlock, blocks.py:82-143 */
+  int planes, n_blocks;
+  const sg_unet_block *blocks;                                /* [n_blocks] */
+  const sg_unet_block *tail;                                  /* [n_blocks] blocks_tail, NULL on the deepest level */
+  const float *down_bn_scale, *down_bn_shift, *down_w;        /* conv:   BN, ReLU, SparseConv3d(planes, next, k2 s2) */
+  const float *up_bn_scale, *up_bn_shift, *up_w;              /* deconv: BN, ReLU, SparseInverseConv3d(next, planes, k2) */
+} sg_unet_level;
+typedef struct sg_unet_desc {
+  int n_levels;
+  const sg_unet_level *levels;       /* host array, outermost first */
+  int input_cin;
+  const float *input_w;              /* SubMConv3d(input_cin, planes[0]) before the UBlock, or NULL */
+  const float *out_bn_scale, *out_bn_shift;   /* BatchNorm1d + ReLU after the UBlock, or NULL */
+} sg_unet_desc;
+/* upper bound of the arena sg_unet_forward needs for num_rows input voxels */
+size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);
+/* feats [num_rows, input_cin or planes[0]], indices int32 [num_rows,4], out [num_rows, planes[0]].
+ * Synchronises the stream once per down-sampling level (coarse voxel count). */
+int sg_unet_forward(const sg_unet_desc *desc, const float *feats, const int32_t *indices,
+                    int num_rows, const int32_t *spatial_shape_host, float *out, void *arena,
+                    size_t arena_bytes, sg_stream_t stream);
+
 /* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):
  * out = relu(x*scale + shift) (relu optional). */
 int sg_bn_relu_f32(const float *x, const float *scale, const float *shift, int64_t num_rows,

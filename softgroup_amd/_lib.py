@@ -53,6 +53,8 @@ SIGNATURES = {
     'sg_spconv_inverse_rulebook': (_i, [_vp, _vp, _i, _vp, _vp]),
     'sg_spconv_plan_workspace_bytes': (_sz, [_i]),
     'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sg_unet_arena_bytes': (_sz, [_vp, _i]),
+    'sg_unet_forward': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_packed_weight_elems': (_sz, [_i, _i, _i]),
     'sg_spconv_pack_weight': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),
@@ -98,15 +100,23 @@ def check(rc, what=''):
 
 
 def ptr(t):
-    """Device/host pointer of a (contiguous) tensor, or NULL for None."""
-    if t is None:
-        return None
-    return C.c_void_p(t.data_ptr())
+    """Device/host pointer of a (contiguous) tensor, or NULL for None (argtypes turn the integer
+    into a void*)."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = None
 
 
 def stream():
+    """handle of torch's current HIP stream on the current device (raw getter: this is called for
+    every kernel launch, torch.cuda.current_stream() costs several microseconds)"""
+    global _raw_stream
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (
+            lambda dev: torch.cuda.current_stream(dev).cuda_stream)
+    return _raw_stream(torch.cuda.current_device())
 
 
 def workspace(nbytes, device):

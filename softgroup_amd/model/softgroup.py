@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..spconv import pytorch as spconv
 from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs
+from ..spconv.unet_exec import UNetExecutor
 from .blocks import MLP, ResidualBlock, UBlock
 
 
@@ -71,6 +72,7 @@ class SoftGroup(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.fixed_modules = fixed_modules
+        self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
 
         norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
 
@@ -178,6 +180,14 @@ class SoftGroup(nn.Module):
         return ret
 
     def _unet_features(self, x):
+        """input_conv -> unet -> output_layer.  Inference runs in the native executor (one C call,
+        same kernels); anything it does not cover (training, autocast dtypes) takes the modules."""
+        ex = self.__dict__.get('_backbone_exec')
+        if ex is None:
+            ex = self.__dict__['_backbone_exec'] = UNetExecutor(self.unet, self.input_conv,
+                                                                 self.output_layer)
+        if self.use_executor and ex.usable(x.features):
+            return ex(x)
         return self.output_layer(self.unet(self.input_conv(x))).features
 
     def forward_backbone(self, input, input_map, x4_split=False, lvl_fusion=False):
@@ -392,7 +402,14 @@ class SoftGroup(nn.Module):
         return x
 
     def forward_instance(self, inst_feats, inst_map):
-        feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
+        ex = self.__dict__.get('_tiny_exec')
+        if ex is None:
+            ex = self.__dict__['_tiny_exec'] = UNetExecutor(self.tiny_unet, None,
+                                                             self.tiny_unet_outputlayer)
+        if self.use_executor and ex.usable(inst_feats.features):
+            feats = inst_feats.replace_feature(ex(inst_feats))
+        else:
+            feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
         inst_map = inst_map.long()
         mask_scores = self.mask_linear(feats.features)[inst_map]
         instance_batch_idxs = feats.indices[:, 0][inst_map]

@@ -1,0 +1,200 @@
+"""Host side of the native U-Net executor (csrc/unet_exec.hip, include/softgroup_hip.h
+``sg_unet_forward``): turns an ``input_conv`` / ``UBlock`` / ``output_layer`` module triple
+(reference softgroup/model/softgroup.py:60-65,93-95; blocks.py:44-143) into the C descriptor --
+packed weights, eval-mode BatchNorm as scale/shift -- and runs it with one call per forward.
+
+Used for inference only (no autograd through it); the module path launches the same kernels and
+remains the training path."""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from . import core
+
+
+class _Block(C.Structure):
+    _fields_ = [('cin', C.c_int), ('cout', C.c_int),
+                ('bn1_scale', C.c_void_p), ('bn1_shift', C.c_void_p), ('w1', C.c_void_p),
+                ('bn2_scale', C.c_void_p), ('bn2_shift', C.c_void_p), ('w2', C.c_void_p),
+                ('w_i', C.c_void_p)]
+
+
+class _Level(C.Structure):
+    _fields_ = [('planes', C.c_int), ('n_blocks', C.c_int),
+                ('blocks', C.POINTER(_Block)), ('tail', C.POINTER(_Block)),
+                ('down_bn_scale', C.c_void_p), ('down_bn_shift', C.c_void_p), ('down_w', C.c_void_p),
+                ('up_bn_scale', C.c_void_p), ('up_bn_shift', C.c_void_p), ('up_w', C.c_void_p)]
+
+
+class _Desc(C.Structure):
+    _fields_ = [('n_levels', C.c_int), ('levels', C.POINTER(_Level)),
+                ('input_cin', C.c_int), ('input_w', C.c_void_p),
+                ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p)]
+
+
+_arena = {}      # device -> uint8 tensor, grow-only
+
+
+def _get_arena(nbytes, device):
+    t = _arena.get(device)
+    if t is None or t.numel() < nbytes:
+        _arena[device] = t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return t
+
+
+class UNetExecutor:
+    """descriptor + cached device tensors for one (input_conv, unet, output_layer) triple"""
+
+    def __init__(self, unet, input_conv=None, output_layer=None):
+        self.unet, self.input_conv, self.output_layer = unet, input_conv, output_layer
+        self._key = None
+        self._keep = []
+        self._desc = None
+
+    # ---- eligibility: plain inference over the structure this executor understands
+    def _tensors(self):
+        """parameters and buffers of the three modules (the module tree is walked once; tensors
+        replaced by .to()/.cuda() or updated in place show up through data_ptr / _version)"""
+        ts = self.__dict__.get('_tensor_list')
+        if ts is None:
+            mods = [self.unet] + [m for m in (self.input_conv, self.output_layer) if m is not None]
+            self._bns = [sub for m in mods for sub in m.modules() if isinstance(sub, nn.BatchNorm1d)]
+            self._owners = [(dct, name) for m in mods for sub in m.modules()
+                            for dct in (sub._parameters, sub._buffers) for name in dct
+                            if dct[name] is not None]
+            ts = self._tensor_list = True
+        return [dct[name] for dct, name in self._owners]
+
+    def usable(self, feats):
+        if not (feats.is_cuda and feats.dtype == torch.float32):
+            return False
+        ts = self._tensors()
+        if torch.is_grad_enabled() and (feats.requires_grad or any(t.requires_grad for t in ts)):
+            return False
+        if any(bn.training or bn.running_mean is None for bn in self._bns):
+            return False
+        return self._supported()
+
+    def _supported(self):
+        ok = getattr(self, '_ok', None)
+        if ok is None:
+            try:
+                self._walk(self.unet, dry=True)
+                ok = True
+            except (AssertionError, AttributeError, IndexError):
+                ok = False
+            self._ok = ok
+        return ok
+
+    # ---- descriptor
+    def _bn(self, bn):
+        s, b = core._bn_affine(bn)
+        self._keep += [s, b]
+        return s.data_ptr(), b.data_ptr()
+
+    def _w(self, conv):
+        w = conv.weight_packed()
+        self._keep.append(w)
+        return w.data_ptr()
+
+    def _block(self, rb, dry):
+        from ..model.blocks import ResidualBlock, Custom1x1Subm3d
+        assert isinstance(rb, ResidualBlock)
+        cb = list(rb.conv_branch._modules.values())
+        assert len(cb) == 6 and isinstance(cb[0], nn.BatchNorm1d) and isinstance(cb[1], nn.ReLU) \
+            and isinstance(cb[2], core.SubMConv3d) and isinstance(cb[3], nn.BatchNorm1d) \
+            and isinstance(cb[4], nn.ReLU) and isinstance(cb[5], core.SubMConv3d)
+        assert cb[2].bias is None and cb[5].bias is None
+        ib = list(rb.i_branch._modules.values())
+        assert len(ib) == 1
+        one = ib[0] if isinstance(ib[0], Custom1x1Subm3d) else None
+        assert one is not None or isinstance(ib[0], nn.Identity)
+        assert one is None or one.bias is None
+        b = _Block()
+        b.cin, b.cout = cb[2].in_channels, cb[2].out_channels
+        if dry:
+            return b
+        b.bn1_scale, b.bn1_shift = self._bn(cb[0])
+        b.w1 = self._w(cb[2])
+        b.bn2_scale, b.bn2_shift = self._bn(cb[3])
+        b.w2 = self._w(cb[5])
+        if one is not None:
+            w = core.pack_weight(one.weight, one.out_channels, 1, one.in_channels, False)
+            self._keep.append(w)
+            b.w_i = w.data_ptr()
+        return b
+
+    def _walk(self, ub, dry=False):
+        """-> list of _Level, outermost first"""
+        from ..model.blocks import UBlock
+        assert isinstance(ub, UBlock)
+        lv = _Level()
+        lv.planes = ub.nPlanes[0]
+        blocks = list(ub.blocks._modules.values())
+        lv.n_blocks = len(blocks)
+        arr = (_Block * len(blocks))(*[self._block(b, dry) for b in blocks])
+        self._keep.append(arr)
+        lv.blocks = arr
+        out = [lv]
+        if len(ub.nPlanes) > 1:
+            cv = list(ub.conv._modules.values())
+            dc = list(ub.deconv._modules.values())
+            assert len(cv) == 3 and isinstance(cv[0], nn.BatchNorm1d) and isinstance(cv[2], core.SparseConv3d)
+            assert len(dc) == 3 and isinstance(dc[0], nn.BatchNorm1d) and isinstance(dc[2], core.SparseInverseConv3d)
+            assert cv[2].bias is None and dc[2].bias is None
+            tail = list(ub.blocks_tail._modules.values())
+            assert len(tail) == len(blocks)
+            tarr = (_Block * len(tail))(*[self._block(b, dry) for b in tail])
+            self._keep.append(tarr)
+            lv.tail = tarr
+            if not dry:
+                lv.down_bn_scale, lv.down_bn_shift = self._bn(cv[0])
+                lv.down_w = self._w(cv[2])
+                lv.up_bn_scale, lv.up_bn_shift = self._bn(dc[0])
+                lv.up_w = self._w(dc[2])
+            out += self._walk(ub.u, dry)
+        return out
+
+    def _state_key(self):
+        return tuple((t._version, t.data_ptr()) for t in self._tensors())
+
+    def _descriptor(self):
+        key = self._state_key()
+        if self._desc is None or key != self._key:
+            self._keep = []
+            levels = self._walk(self.unet)
+            larr = (_Level * len(levels))(*levels)
+            d = _Desc()
+            d.n_levels, d.levels = len(levels), larr
+            if self.input_conv is not None:
+                ic = list(self.input_conv._modules.values())
+                assert len(ic) == 1 and isinstance(ic[0], core.SubMConv3d) and ic[0].bias is None
+                d.input_cin = ic[0].in_channels
+                d.input_w = self._w(ic[0])
+            if self.output_layer is not None:
+                ol = list(self.output_layer._modules.values())
+                assert len(ol) == 2 and isinstance(ol[0], nn.BatchNorm1d) and isinstance(ol[1], nn.ReLU)
+                d.out_bn_scale, d.out_bn_shift = self._bn(ol[0])
+            self._keep.append(larr)
+            self._desc, self._key = d, key
+        return self._desc
+
+    # ---- run
+    def __call__(self, x):
+        """x: SparseConvTensor -> features [M, planes[0]] of the U-Net output (after output_layer)"""
+        lib = L.lib()
+        d = self._descriptor()
+        feats = x.features.contiguous()
+        idx = x.indices.contiguous()
+        M = feats.shape[0]
+        out = torch.empty((M, d.levels[0].planes), dtype=torch.float32, device=feats.device)
+        if M == 0:
+            return out
+        nb = lib.sg_unet_arena_bytes(C.byref(d), M)
+        arena = _get_arena(nb, feats.device)
+        shape = (C.c_int32 * 3)(*x.spatial_shape)
+        L.check(lib.sg_unet_forward(C.byref(d), L.ptr(feats), L.ptr(idx), M, shape, L.ptr(out),
+                                    L.ptr(arena), arena.numel(), L.stream()), 'sg_unet_forward')
+        return out

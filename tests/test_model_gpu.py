@@ -96,6 +96,30 @@ def test_forward_test_entry_and_determinism(setup):
     assert np.array_equal(r1['semantic_preds'], r2['semantic_preds'])
 
 
+def test_native_executor_matches_module_path(setup):
+    """sg_unet_forward (C++ executor, one call per U-Net) against the nn.Module path: same conv
+    kernels in the same order, so the features agree to float rounding of the 1x1 convs (own MFMA
+    kernel there, hipBLASLt in the module path); the executor must really have run."""
+    batch, model, _ = setup
+    from softgroup_amd.spconv.unet_exec import UNetExecutor
+    calls = []
+    orig = UNetExecutor.__call__
+    UNetExecutor.__call__ = lambda self, x: (calls.append(1), orig(self, x))[1]
+    try:
+        model.use_executor = True
+        a = _gpu_stages(model, batch)
+        assert len(calls) == 2, 'backbone and tiny U-Net must go through the native executor'
+        model.use_executor = False
+        b = _gpu_stages(model, batch)
+        assert len(calls) == 2
+    finally:
+        UNetExecutor.__call__ = orig
+        model.use_executor = True
+    np.testing.assert_allclose(a['feats'].cpu().numpy(), b['feats'].cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(a['pidx'], b['pidx']) and torch.equal(a['poff'], b['poff'])
+    np.testing.assert_allclose(a['mask'].cpu().numpy(), b['mask'].cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
 def test_state_dict_contract():
     """parameter names/shapes of SURVEY App. A (what reference checkpoints contain)"""
     model = synthetic.build_model(device='cpu')

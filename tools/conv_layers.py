@@ -22,6 +22,7 @@ def main():
             model(batch)
         prof = spcore.ConvProfiler()
         spcore.PROFILER = prof
+        model.use_executor = False      # per-launch events are recorded on the module path
         reps = 5
         for _ in range(reps):
             model(batch)

@@ -21,6 +21,7 @@ def main():
     batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     model = synthetic.build_model(seed=0)
+    model.use_executor = False
     with torch.no_grad():
         model(batch)
         torch.cuda.synchronize()
