@@ -106,15 +106,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # forward_test returns as soon as the scan's GPU work is enqueued; turning its results into host
+    # objects (numpy arrays, RLE mask strings) runs on the model's results thread and overlaps the
+    # next scan.  Every one of the K result dicts is fully materialised inside the timed region.
     with torch.no_grad():
         for _ in range(args.warmup):
-            ret = model(batch)
+            model(batch).resolve()
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ret = model(batch)
+        rets = [model(batch) for _ in range(args.steps)]
+        for r in rets:
+            r.resolve()
         sync_all()
         elapsed = time.perf_counter() - t0
+    assert all('pred_instances' in r and 'semantic_preds' in r for r in rets)
+    del rets
     if dist_on:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..spconv import pytorch as spconv
 from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs
+from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
 from .blocks import MLP, ResidualBlock, UBlock
 
@@ -73,6 +74,7 @@ class SoftGroup(nn.Module):
         self.test_cfg = test_cfg
         self.fixed_modules = fixed_modules
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
+        self.async_results = True    # host-side result formatting overlaps the next forward
 
         norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
 
@@ -149,34 +151,64 @@ class SoftGroup(nn.Module):
             pt_offset_labels = self.merge_4_parts(pt_offset_labels)
         semantic_preds = semantic_scores.max(1)[1]
         tasks = _cfg(tcfg, 'eval_tasks')
-        ret = dict(scan_id=scan_ids[0])
-        if 'semantic' in tasks or 'panoptic' in tasks:
-            ret.update(semantic_labels=semantic_labels.cpu().numpy(),
-                       instance_labels=instance_labels.cpu().numpy())
-        if 'semantic' in tasks:
-            ret.update(self.get_point_wise_results(coords_float, color_feats, semantic_preds,
-                                                   pt_offsets, pt_offset_labels, v2p_map, lvl_fusion))
-        if not self.semantic_only:
-            if 'instance' in tasks or 'panoptic' in tasks:
-                if lvl_fusion:
-                    batch_idxs = x.indices[:, 0].int()
-                    coords_float = ops.voxelization(coords_float, p2v_map)
-                proposals_idx, proposals_offset = self.forward_grouping(
-                    semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
-                    lvl_fusion=lvl_fusion)
-                inst_feats, inst_map = self.clusters_voxelization(
-                    proposals_idx, proposals_offset, output_feats, coords_float,
-                    **self.instance_voxel_cfg)
-                _, cls_scores, iou_scores, mask_scores = self.forward_instance(inst_feats, inst_map)
-                pred_instances = self.get_instances(scan_ids[0], proposals_idx, semantic_scores,
-                                                    cls_scores, iou_scores, mask_scores,
-                                                    v2p_map=v2p_map, lvl_fusion=lvl_fusion)
-            if 'instance' in tasks:
-                ret.update(pred_instances=pred_instances,
-                           gt_instances=self.get_gt_instances(semantic_labels, instance_labels))
-            if 'panoptic' in tasks:
-                ret.update(panoptic_preds=self.panoptic_fusion(semantic_preds.cpu().numpy(),
-                                                               pred_instances))
+        ret = LazyResults(scan_id=scan_ids[0])
+        inst = None
+        if not self.semantic_only and ('instance' in tasks or 'panoptic' in tasks):
+            if lvl_fusion:
+                batch_idxs = x.indices[:, 0].int()
+                coords_float = ops.voxelization(coords_float, p2v_map)
+            proposals_idx, proposals_offset = self.forward_grouping(
+                semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
+                lvl_fusion=lvl_fusion)
+            inst_feats, inst_map = self.clusters_voxelization(
+                proposals_idx, proposals_offset, output_feats, coords_float,
+                **self.instance_voxel_cfg)
+            _, cls_scores, iou_scores, mask_scores = self.forward_instance(inst_feats, inst_map)
+            inst = (proposals_idx, cls_scores, iou_scores, mask_scores)
+
+        # ---- everything below only turns device results into host objects (numpy arrays, RLE
+        #      strings): it can run on the results thread, on its own stream, while the caller
+        #      already enqueues the next scan
+        def finish():
+            out = {}
+            if 'semantic' in tasks or 'panoptic' in tasks:
+                out.update(semantic_labels=semantic_labels.cpu().numpy(),
+                           instance_labels=instance_labels.cpu().numpy())
+            if 'semantic' in tasks:
+                out.update(self.get_point_wise_results(coords_float, color_feats, semantic_preds,
+                                                       pt_offsets, pt_offset_labels, v2p_map,
+                                                       lvl_fusion))
+            if inst is not None:
+                pred_instances = self.get_instances(scan_ids[0], inst[0], semantic_scores, inst[1],
+                                                    inst[2], inst[3], v2p_map=v2p_map,
+                                                    lvl_fusion=lvl_fusion)
+                if 'instance' in tasks:
+                    out.update(pred_instances=pred_instances,
+                               gt_instances=self.get_gt_instances(semantic_labels, instance_labels))
+                if 'panoptic' in tasks:
+                    out.update(panoptic_preds=self.panoptic_fusion(semantic_preds.cpu().numpy(),
+                                                                   pred_instances))
+            return out
+
+        if not (self.async_results and semantic_scores.is_cuda):
+            ret.update(finish())
+            return ret
+        main = torch.cuda.current_stream()
+        done = torch.cuda.Event()
+        done.record(main)
+        side = self.__dict__.get('_results_stream')
+        if side is None:
+            side = self.__dict__['_results_stream'] = torch.cuda.Stream()
+        dev = semantic_scores.device
+
+        def job():
+            with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():
+                side.wait_event(done)
+                out = finish()
+                side.synchronize()
+            return out
+
+        ret.defer(lazy_worker().submit(job))
         return ret
 
     def _unet_features(self, x):
@@ -541,7 +573,7 @@ class SoftGroup(nn.Module):
         shift = self.semantic_classes - self.instance_classes
         sem = semantic_labels - shift + 1
         sem[sem < 0] = 0
-        instance_labels += 1
+        instance_labels = instance_labels + 1      # (the reference increments its private copy in place)
         gt = sem * 1000 + instance_labels
         gt[instance_labels < 0] = 0
         return gt.cpu().numpy()
