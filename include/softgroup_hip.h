@@ -152,7 +152,7 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
                          const float *seg_thr, int n_seg, int32_t *n_cluster_host,
                          int32_t *sum_npoint_host, void *ws, size_t ws_bytes, sg_stream_t stream);
 /* same ws buffer, untouched since sg_bfs_cluster_label */
-int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
+int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n, int64_t n_edges,
                         const int32_t *seg_of_point, const float *seg_thr, int n_cluster,
                         int sum_npoint, int32_t *cluster_idxs, int32_t *cluster_offsets, void *ws,
                         size_t ws_bytes, sg_stream_t stream);

@@ -37,7 +37,7 @@ SIGNATURES = {
     'sg_octree_ballquery_fill': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     'sg_bfs_workspace_bytes': (_sz, [_i, _i64]),
     'sg_bfs_cluster_label': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _i, _pi32, _pi32, _vp, _sz, _vp]),
-    'sg_bfs_cluster_emit': (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'sg_bfs_cluster_emit': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'sg_sec_mean': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     'sg_sec_min': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     'sg_sec_max': (_i, [_vp, _vp, _i, _i, _vp, _vp]),

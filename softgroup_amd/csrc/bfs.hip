@@ -34,12 +34,13 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 struct BfsWs {
   int32_t *parent, *lab, *size, *cid, *coff, *owner, *seeds, *ebase, *wcnt, *asym_nodes;
   int4 *label;  // per point: (label, local slot, list start, list len)
+  int2 *erec;   // per edge of a kept cluster: (target slot | target list len << 16, target list start)
   int32_t *counters;  // [0] #asym source nodes  [1] changed flag  [2] nCluster  [3] sumNPoint
   void *scan_ws;
   size_t scan_bytes;
 };
 
-static bool bfs_carve(void *ws, size_t ws_bytes, int n, BfsWs *w) {
+static bool bfs_carve(void *ws, size_t ws_bytes, int n, int64_t n_edges, BfsWs *w) {
   Workspace a(ws, ws_bytes);
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
   w->parent = a.take<int32_t>(nn);
@@ -56,7 +57,8 @@ static bool bfs_carve(void *ws, size_t ws_bytes, int n, BfsWs *w) {
   w->counters = a.take<int32_t>(64);
   w->scan_bytes = scan_workspace_bytes(n);
   w->scan_ws = a.take<char>(w->scan_bytes);
-  return w->scan_ws != nullptr;
+  w->erec = a.take<int2>(static_cast<size_t>(n_edges > 0 ? n_edges : 1));
+  return w->scan_ws != nullptr && w->erec != nullptr;
 }
 
 // ---------------------------------------------------------------- A. union-find
@@ -223,6 +225,30 @@ __global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int4 *__rest
   }
 }
 
+// Edge records for the ordered emission: for every edge e = (v -> t) whose source lies in a kept
+// cluster, everything the BFS replay needs about the target in one 8-byte read: its slot in the
+// cluster's claim array (0xffff = t belongs to another cluster, never claimed), and its own list
+// (start, length) so that a claimed target becomes a frontier node without a second lookup.
+// One wave per source node; this is the only place that gathers node_rec[] at random.
+__global__ void __launch_bounds__(256) bfs_edge_rec_kernel(const int32_t *__restrict__ idx,
+                                                          const int4 *__restrict__ node_rec,
+                                                          const int32_t *__restrict__ cid,
+                                                          const int32_t *__restrict__ seeds,
+                                                          int n, int n_cluster,
+                                                          int2 *__restrict__ erec) {
+  const int lane = threadIdx.x & 63;
+  for (int v = (blockIdx.x * 256 + threadIdx.x) >> 6; v < n; v += (gridDim.x * 256) >> 6) {
+    const int4 rv = node_rec[v];
+    const int c = cid[rv.x];
+    if (c >= n_cluster || seeds[c] != rv.x) continue;          // source not in a kept cluster
+    for (int p = lane; p < rv.w; p += 64) {
+      const int4 rt = node_rec[idx[rv.z + p]];
+      erec[rv.z + p] = rt.x == rv.x ? make_int2((rt.y & 0xffff) | (rt.w << 16), rt.z)
+                                    : make_int2(0xffff, 0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- D. ordered emission
 // workgroup-wide exclusive scan of one int per thread (kEmitThreads threads)
 __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
@@ -243,8 +269,9 @@ __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
 }
 
 constexpr int kOwnCap = 16384;     // cluster sizes up to this keep their claim array in LDS (64 KB)
-constexpr int kFrontChunk = 2048;  // frontier nodes staged per chunk (st, len, edge base, winners)
+constexpr int kFrontChunk = 1024;  // frontier nodes staged per chunk (st, len, edge base, winners)
 constexpr int kECap = 16384;       // edges of a level whose target slots are cached in LDS (32 KB)
+constexpr int kE2 = 6144;          // ... whose target (list start, len) are cached too (36 KB)
 
 // One workgroup per kept cluster.  The output segment doubles as the FIFO queue (column 1 of
 // cluster_idxs).  Per BFS level:
@@ -254,20 +281,26 @@ constexpr int kECap = 16384;       // edges of a level whose target slots are ca
 //   count   winners per frontier node (ballot + popcount), prefix over nodes;
 //   append  winners in edge order to the queue and mark them visited (-1).
 // FAST level (cluster claims in LDS, <= kFrontChunk frontier nodes, <= kECap edges): the frontier's
-// (start,len) stay in LDS from the previous level's append, target slots are cached in LDS by the
-// claim pass, so count needs no global access and append re-reads only the winners' ids: ~3 L2
-// round trips per level instead of ~10.  Anything larger takes the GENERIC path (chunked, all
-// state re-read from global), which typically means few, fat levels.
+// (start,len) stay in LDS from the previous level's append; the claim pass reads one 8-byte edge
+// record per edge (bfs_edge_rec_kernel) and caches the target's slot -- and for levels of <= kE2
+// edges also its list (start,len) -- in LDS, so counting and appending the winners touch no global
+// memory on the level's critical path: ONE memory round trip per level.  Winners are written to
+// the queue as EDGE indices (fire-and-forget stores); they are turned into point ids in one
+// parallel sweep when the cluster is done (or before a GENERIC level, which reads the queue).
+// Anything larger takes the GENERIC path (chunked, all state re-read from global), which typically
+// means few, fat levels.
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
-    const int4 *__restrict__ node_rec, const int32_t *__restrict__ seeds,
-    const int32_t *__restrict__ cluster_offsets, int n_cluster, int32_t *owner_g,
-    int32_t *cluster_idxs) {
+    const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
+    const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
+    int32_t *owner_g, int32_t *cluster_idxs) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
   __shared__ int f_st[2][kFrontChunk], f_ln[2][kFrontChunk];
   __shared__ int f_eb[kFrontChunk], f_wc[kFrontChunk];
   __shared__ unsigned short ebuf[kECap];
+  __shared__ int e_st[kE2];
+  __shared__ unsigned short e_ln[kE2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int c = blockIdx.x; c < n_cluster; c += gridDim.x) {
     const int seed = seeds[c];
@@ -304,6 +337,15 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       if (own_in_lds) own_lds[rec2(v).y] = -1; else SG_ST(&owner_g[v], -1);
     };
     int head = 0, tail = 1;
+    int conv_lo = -1;       // queue entries [conv_lo, tail) hold edge indices, not point ids yet
+    auto convert_pending = [&]() {
+      if (conv_lo < 0) return;
+      for (int o = conv_lo + threadIdx.x; o < tail; o += kEmitThreads)
+        SG_ST(&Q[2 * o + 1], idx[SG_LD(&Q[2 * o + 1])]);
+      conv_lo = -1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
     int cur = 0;            // which f_st/f_ln buffer holds the current frontier (if any)
     bool in_lds = true;     // frontier (start,len) of this level already in f_st/f_ln[cur]?
     while (head < tail) {
@@ -324,12 +366,17 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         E = carry;
       }
       if (E >= 0 && E <= kECap) {
+        const bool cached = E <= kE2;
         for (int q = wave; q < L; q += kEmitWaves) {                  // claim
           const int st = f_st[cur][q], ln = f_ln[cur][q], base = f_eb[q];
           for (int p = lane; p < ln; p += 64) {
-            const int2 ll = rec2(idx[st + p]);
-            const unsigned short slot = ll.x == seed ? static_cast<unsigned short>(ll.y) : 0xffffu;
+            const int2 r = erec[st + p];
+            const unsigned short slot = static_cast<unsigned short>(r.x & 0xffff);
             ebuf[base + p] = slot;
+            if (cached) {
+              e_st[base + p] = r.y;
+              e_ln[base + p] = static_cast<unsigned short>(r.x >> 16);
+            }
             if (slot != 0xffffu && own_lds[slot] > base + p) atomicMin(&own_lds[slot], base + p);
           }
         }
@@ -374,21 +421,25 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
             }
             const uint64_t bal = __ballot(win);
             if (win) {
-              const int v = idx[st + p];
               const int oo = o + mask_prefix(bal);
               SG_ST(&Q[2 * (tail + oo)], c);
-              SG_ST(&Q[2 * (tail + oo) + 1], v);
+              SG_ST(&Q[2 * (tail + oo) + 1], st + p);     // edge index; point id = idx[edge]
               if (keep) {
-                const int4 rec = node_rec[v];
-                f_st[nxt][oo] = rec.z;
-                f_ln[nxt][oo] = rec.w;
+                if (cached) {
+                  f_st[nxt][oo] = e_st[base + p];
+                  f_ln[nxt][oo] = e_ln[base + p];
+                } else {
+                  const int2 r = erec[st + p];
+                  f_st[nxt][oo] = r.y;
+                  f_ln[nxt][oo] = r.x >> 16;
+                }
               }
               own_lds[slot] = -1;     // visited; only this edge can match pos, see header
             }
             o += __popcll(bal);
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (conv_lo < 0 && t_new > 0) conv_lo = tail;
         __syncthreads();
         head = tail;
         tail += t_new;
@@ -397,6 +448,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         continue;
       }
       // ---------------- GENERIC level ----------------
+      convert_pending();          // it reads point ids from the queue
       // stage chunk `ch` of the frontier: list start/len into LDS, edge base = carry + prefix
       auto stage = [&](int ch, int carry_in) -> int {
         const int q0 = ch * kFrontChunk, cnt = min(kFrontChunk, L - q0);
@@ -499,6 +551,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       cur = 0;
       in_lds = keep;
     }
+    convert_pending();
     __syncthreads();
   }
 }
@@ -510,9 +563,10 @@ using namespace sg;
 extern "C" {
 
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges) {
-  (void)n_edges;
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
-  return 14 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) + 256;
+  const size_t ne = static_cast<size_t>(n_edges > 0 ? n_edges : 1);
+  return 14 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) +
+         align_up(ne * sizeof(int2)) + 256;
 }
 
 // Synchronises `stream` (the cluster count decides the size of the outputs).
@@ -520,11 +574,10 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
                          int list_flags, const int32_t *seg_of_point, const float *seg_thr,
                          int n_seg, int32_t *n_cluster_host, int32_t *sum_npoint_host, void *ws,
                          size_t ws_bytes, sg_stream_t stream_) {
-  (void)n_edges;
   SG_REQUIRE(n >= 0 && n_seg >= 1 && seg_thr != nullptr, "sg_bfs_cluster_label: bad arguments");
   hipStream_t stream = as_stream(stream_);
   BfsWs w;
-  if (!bfs_carve(ws, ws_bytes, n, &w)) {
+  if (!bfs_carve(ws, ws_bytes, n, n_edges, &w)) {
     set_error("sg_bfs_cluster_label: workspace too small");
     return SG_ERR_WORKSPACE;
   }
@@ -583,14 +636,14 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
   return check_launch("sg_bfs_cluster_label");
 }
 
-int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
+int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n, int64_t n_edges,
                         const int32_t *seg_of_point, const float *seg_thr, int n_cluster,
                         int sum_npoint, int32_t *cluster_idxs, int32_t *cluster_offsets, void *ws,
                         size_t ws_bytes, sg_stream_t stream_) {
   SG_REQUIRE(n >= 0 && n_cluster >= 0 && sum_npoint >= 0, "sg_bfs_cluster_emit: bad arguments");
   hipStream_t stream = as_stream(stream_);
   BfsWs w;
-  if (!bfs_carve(ws, ws_bytes, n, &w)) {
+  if (!bfs_carve(ws, ws_bytes, n, n_edges, &w)) {
     set_error("sg_bfs_cluster_emit: workspace too small");
     return SG_ERR_WORKSPACE;
   }
@@ -601,8 +654,10 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   bfs_seed_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, w.label, w.size, w.cid, w.coff,
                                                        seg_of_point, seg_thr, w.seeds,
                                                        cluster_offsets);
+  bfs_edge_rec_kernel<<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, w.label, w.cid, w.seeds, n,
+                                                                     n_cluster, w.erec);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
-      bq_idxs, start_len, w.label, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs);
+      bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs);
   return check_launch("sg_bfs_cluster_emit");
 }
 

@@ -173,7 +173,7 @@ def bfs_cluster_segments(ball_query_idxs, start_len, seg_thr, seg_of_point=None,
             'sg_bfs_cluster_label')
     cluster_idxs = torch.empty((sp.value, 2), dtype=torch.int32, device=dev)
     cluster_offsets = torch.zeros(nc.value + 1, dtype=torch.int32, device=dev)
-    L.check(lib.sg_bfs_cluster_emit(L.ptr(ball_query_idxs), L.ptr(start_len), n,
+    L.check(lib.sg_bfs_cluster_emit(L.ptr(ball_query_idxs), L.ptr(start_len), n, n_edges,
                                     L.ptr(seg_of_point), L.ptr(seg_thr), nc.value, sp.value,
                                     L.ptr(cluster_idxs), L.ptr(cluster_offsets), L.ptr(ws), nb, st),
             'sg_bfs_cluster_emit')
