@@ -19,6 +19,8 @@
 //      a node is claimed by atomicMin(pos) and the next frontier is the claimed nodes in pos
 //      order (wave ballot + popcount prefix per source node, workgroup prefix over nodes) --
 //      exactly the order the sequential queue produces.
+#include <stdlib.h>
+
 #include "common.h"
 #include "scan.h"
 
@@ -270,8 +272,7 @@ __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
 
 constexpr int kOwnCap = 16384;     // cluster sizes up to this keep their claim array in LDS (64 KB)
 constexpr int kFrontChunk = 1024;  // frontier nodes staged per chunk (st, len, edge base, winners)
-constexpr int kECap = 16384;       // edges of a level whose target slots are cached in LDS (32 KB)
-constexpr int kE2 = 6144;          // ... whose target (list start, len) are cached too (36 KB)
+constexpr int kE2 = 4096;           // edges of a fast level (slot, list start/len, edge id cached in LDS: 48 KB)
 
 // One workgroup per kept cluster.  The output segment doubles as the FIFO queue (column 1 of
 // cluster_idxs).  Per BFS level:
@@ -280,27 +281,27 @@ constexpr int kE2 = 6144;          // ... whose target (list start, len) are cac
 //           <= kOwnCap points, else on the global owner[] array;
 //   count   winners per frontier node (ballot + popcount), prefix over nodes;
 //   append  winners in edge order to the queue and mark them visited (-1).
-// FAST level (cluster claims in LDS, <= kFrontChunk frontier nodes, <= kECap edges): the frontier's
-// (start,len) stay in LDS from the previous level's append; the claim pass reads one 8-byte edge
-// record per edge (bfs_edge_rec_kernel) and caches the target's slot -- and for levels of <= kE2
-// edges also its list (start,len) -- in LDS, so counting and appending the winners touch no global
-// memory on the level's critical path: ONE memory round trip per level.  Winners are written to
-// the queue as EDGE indices (fire-and-forget stores); they are turned into point ids in one
-// parallel sweep when the cluster is done (or before a GENERIC level, which reads the queue).
-// Anything larger takes the GENERIC path (chunked, all state re-read from global), which typically
-// means few, fat levels.
+// FAST level (cluster claims in LDS, <= kFrontChunk frontier nodes, <= kE2 edges): the frontier's
+// (start,len) stay in LDS from the previous level's append; the level's edges are processed FLAT
+// (one thread per edge), every thread reads one 8-byte edge record (bfs_edge_rec_kernel) and
+// caches the target's slot, list (start,len) and the edge id in LDS, so the level costs ONE memory
+// round trip and counting / appending the winners touch no global memory on the critical path.
+// Winners are written to the queue as EDGE indices (fire-and-forget stores); they are turned into
+// point ids in one parallel sweep when the cluster is done (or before a GENERIC level, which reads
+// the queue).  Anything larger takes the GENERIC path (chunked, all state re-read from global),
+// which typically means few, fat levels.
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
     const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
-    int32_t *owner_g, int32_t *cluster_idxs) {
+    int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
   __shared__ int f_st[2][kFrontChunk], f_ln[2][kFrontChunk];
   __shared__ int f_eb[kFrontChunk], f_wc[kFrontChunk];
-  __shared__ unsigned short ebuf[kECap];
-  __shared__ int e_st[kE2];
-  __shared__ unsigned short e_ln[kE2];
+  __shared__ unsigned short ebuf[kE2];     // fast level, per edge: target slot
+  __shared__ int e_st[kE2], e_g[kE2];      //   target list start, global edge index
+  __shared__ unsigned short e_ln[kE2];     //   target list length
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int c = blockIdx.x; c < n_cluster; c += gridDim.x) {
     const int seed = seeds[c];
@@ -337,6 +338,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       if (own_in_lds) own_lds[rec2(v).y] = -1; else SG_ST(&owner_g[v], -1);
     };
     int head = 0, tail = 1;
+    int n_fast = 0, n_gen = 0, sum_e = 0, max_l = 0;   // developer statistics (SG_BFS_STATS)
     int conv_lo = -1;       // queue entries [conv_lo, tail) hold edge indices, not point ids yet
     auto convert_pending = [&]() {
       if (conv_lo < 0) return;
@@ -351,6 +353,9 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     while (head < tail) {
       const int L = tail - head;
       // ---------------- FAST level ----------------
+      // Flat over the level's edges: thread t owns edges t, t + 512, ... of the concatenated lists
+      // (edge -> (frontier node, position) by a binary search over the nodes' edge bases in LDS),
+      // so all edge records of a level are requested at once: ONE memory round trip per level.
       int E = -1;
       if (own_in_lds && in_lds && L <= kFrontChunk) {
         int carry = 0;
@@ -365,89 +370,57 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
         __syncthreads();
         E = carry;
       }
-      if (E >= 0 && E <= kECap) {
-        const bool cached = E <= kE2;
-        for (int q = wave; q < L; q += kEmitWaves) {                  // claim
-          const int st = f_st[cur][q], ln = f_ln[cur][q], base = f_eb[q];
-          for (int p = lane; p < ln; p += 64) {
-            const int2 r = erec[st + p];
-            const unsigned short slot = static_cast<unsigned short>(r.x & 0xffff);
-            ebuf[base + p] = slot;
-            if (cached) {
-              e_st[base + p] = r.y;
-              e_ln[base + p] = static_cast<unsigned short>(r.x >> 16);
-            }
-            if (slot != 0xffffu && own_lds[slot] > base + p) atomicMin(&own_lds[slot], base + p);
+      if (E >= 0 && E <= kE2) {
+        ++n_fast; sum_e += E; max_l = max(max_l, L);
+        for (int e = threadIdx.x; e < E; e += kEmitThreads) {         // claim
+          int lo = 0, hi = L;                                         // last q with f_eb[q] <= e
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (f_eb[mid] <= e) lo = mid; else hi = mid;
           }
+          const int g = f_st[cur][lo] + (e - f_eb[lo]);
+          const int2 r = erec[g];
+          const unsigned short slot = static_cast<unsigned short>(r.x & 0xffff);
+          ebuf[e] = slot;
+          e_g[e] = g;
+          e_st[e] = r.y;
+          e_ln[e] = static_cast<unsigned short>(r.x >> 16);
+          if (slot != 0xffffu && own_lds[slot] > e) atomicMin(&own_lds[slot], e);
         }
         __syncthreads();
-        for (int q = wave; q < L; q += kEmitWaves) {                  // count winners
-          const int ln = f_ln[cur][q], base = f_eb[q];
-          int wins = 0;
-          for (int p0 = 0; p0 < ln; p0 += 64) {
-            const int p = p0 + lane;
-            bool win = false;
-            if (p < ln) {
-              const unsigned short slot = ebuf[base + p];
-              win = slot != 0xffffu && own_lds[slot] == base + p;
-            }
-            wins += __popcll(__ballot(win));
-          }
-          if (lane == 0) f_wc[q] = wins;
-        }
-        __syncthreads();
-        int t_new = 0;
-        for (int b0 = 0; b0 < L; b0 += kEmitThreads) {                // prefix of winner counts
-          const int q = b0 + threadIdx.x;
-          const int w_ = q < L ? f_wc[q] : 0;
-          int tot;
-          const int ex = wg_excl_scan(w_, lds_scan, &tot);
-          if (q < L) f_wc[q] = t_new + ex;
-          t_new += tot;
-        }
-        __syncthreads();
-        const bool keep = t_new <= kFrontChunk;                      // next frontier fits in LDS
         const int nxt = cur ^ 1;
-        for (int q = wave; q < L; q += kEmitWaves) {                  // append in edge order
-          const int st = f_st[cur][q], ln = f_ln[cur][q], base = f_eb[q];
-          int o = f_wc[q];
-          for (int p0 = 0; p0 < ln; p0 += 64) {
-            const int p = p0 + lane;
-            bool win = false;
-            unsigned short slot = 0xffffu;
-            if (p < ln) {
-              slot = ebuf[base + p];
-              win = slot != 0xffffu && own_lds[slot] == base + p;
-            }
-            const uint64_t bal = __ballot(win);
-            if (win) {
-              const int oo = o + mask_prefix(bal);
-              SG_ST(&Q[2 * (tail + oo)], c);
-              SG_ST(&Q[2 * (tail + oo) + 1], st + p);     // edge index; point id = idx[edge]
-              if (keep) {
-                if (cached) {
-                  f_st[nxt][oo] = e_st[base + p];
-                  f_ln[nxt][oo] = e_ln[base + p];
-                } else {
-                  const int2 r = erec[st + p];
-                  f_st[nxt][oo] = r.y;
-                  f_ln[nxt][oo] = r.x >> 16;
-                }
-              }
-              own_lds[slot] = -1;     // visited; only this edge can match pos, see header
-            }
-            o += __popcll(bal);
+        int t_new = 0;
+        for (int b0 = 0; b0 < E; b0 += kEmitThreads) {                // winners, in edge order
+          const int e = b0 + threadIdx.x;
+          unsigned short slot = 0xffffu;
+          bool win = false;
+          if (e < E) {
+            slot = ebuf[e];
+            win = slot != 0xffffu && own_lds[slot] == e;
           }
+          int tot;
+          const int oo = t_new + wg_excl_scan(win ? 1 : 0, lds_scan, &tot);
+          if (win) {
+            SG_ST(&Q[2 * (tail + oo)], c);
+            SG_ST(&Q[2 * (tail + oo) + 1], e_g[e]);      // edge index; point id = idx[edge]
+            if (oo < kFrontChunk) {
+              f_st[nxt][oo] = e_st[e];
+              f_ln[nxt][oo] = e_ln[e];
+            }
+            own_lds[slot] = -1;     // visited; only this edge can match pos, see header
+          }
+          t_new += tot;
         }
         if (conv_lo < 0 && t_new > 0) conv_lo = tail;
         __syncthreads();
         head = tail;
         tail += t_new;
         cur = nxt;
-        in_lds = keep;
+        in_lds = t_new <= kFrontChunk;
         continue;
       }
       // ---------------- GENERIC level ----------------
+      ++n_gen; max_l = max(max_l, L);
       convert_pending();          // it reads point ids from the queue
       // stage chunk `ch` of the frontier: list start/len into LDS, edge base = carry + prefix
       auto stage = [&](int ch, int carry_in) -> int {
@@ -552,6 +525,10 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       in_lds = keep;
     }
     convert_pending();
+    if (stats && threadIdx.x == 0 && c < 256) {
+      stats[c * 8 + 0] = size; stats[c * 8 + 1] = n_fast; stats[c * 8 + 2] = n_gen;
+      stats[c * 8 + 3] = sum_e; stats[c * 8 + 4] = max_l;
+    }
     __syncthreads();
   }
 }
@@ -656,8 +633,23 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
                                                        cluster_offsets);
   bfs_edge_rec_kernel<<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, w.label, w.cid, w.seeds, n,
                                                                      n_cluster, w.erec);
+  static const bool want_stats = getenv("SG_BFS_STATS") != nullptr;     // developer tool
+  int32_t *stats = nullptr;
+  if (want_stats) {
+    hipMalloc(&stats, 256 * 8 * 4);
+    hipMemsetAsync(stats, 0, 256 * 8 * 4, stream);
+  }
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
-      bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs);
+      bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
+      stats);
+  if (want_stats) {
+    int32_t h[256 * 8];
+    hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost);
+    hipFree(stats);
+    for (int c = 0; c < n_cluster && c < 256; ++c)
+      fprintf(stderr, "bfs cluster %d: size %d fast levels %d generic levels %d edges %d max frontier %d\n", c,
+              h[c * 8], h[c * 8 + 1], h[c * 8 + 2], h[c * 8 + 3], h[c * 8 + 4]);
+  }
   return check_launch("sg_bfs_cluster_emit");
 }
 
