@@ -250,6 +250,8 @@ int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_i
  *   eval-mode BatchNorm1d + ReLU that FOLLOWS this conv and precedes the next one in
  *   blocks.py:57-70 (conv_branch: BN, ReLU, conv, BN, ReLU, conv), fused into the epilogue.  `in`
  *   is taken as is (already activated by the producer's epilogue or by sg_bn_relu_f32).
+ *   Optional second output out_act = relu(out * act_scale + act_shift): the BatchNorm1d + ReLU of
+ *   the NEXT block, when `out` itself is still needed raw (residual identity, skip concat).
  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).  cout % 4 == 0 takes the MFMA
  * path; other shapes the scalar path of the same operator.  order/tile_mask/nbr_tiles from
  * sg_spconv_plan (all NULL = natural order, all offsets, slower general kernel).  cin % 16 == 0 with
@@ -260,7 +262,8 @@ size_t sg_spconv_conv_workspace_bytes(int num_out_rows, int cout);
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr,
                               int num_out_rows, int kvol, int cin, int cout, const float *w_k8,
                               const float *post_scale, const float *post_shift,
-                              const float *residual, const int32_t *order,
+                              const float *residual, const float *act_scale,
+                              const float *act_shift, float *out_act, const int32_t *order,
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);
 

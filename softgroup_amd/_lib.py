@@ -59,7 +59,7 @@ SIGNATURES = {
     'sg_spconv_pack_weight': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),
     'sg_spconv_gather_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _vp, _vp, _sz, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_wgrad_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'sg_rle_format_bound': (_i64, [_i64, _i]),
     'sg_rle_format_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),

@@ -53,6 +53,9 @@ struct ConvArgs {
   const float *post_scale;   // [Cout] or null
   const float *post_shift;
   const float *residual;     // [M_out][Cout] or null
+  const float *act_scale;    // second output: out_act = relu(out * act_scale + act_shift), or null
+  const float *act_shift;
+  float *out_act;            // [M_out][Cout]
   const int32_t *order;      // [num_tiles*32] or null
   const uint32_t *tile_mask;
   const int32_t *nbr_tiles;  // [num_tiles][32][K] gather rows in plan order, or null
@@ -192,11 +195,14 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
   float *out = p.out + (final_out ? 0 : static_cast<long long>(ks) * p.M_out * p.Cout);
   const bool add_res = p.residual != nullptr && final_out;
   const bool post = p.post_scale != nullptr && final_out;
-  float ps[NBW], pb[NBW];
+  const bool act = p.out_act != nullptr && final_out;
+  float ps[NBW], pb[NBW], as[NBW], ab[NBW];
 #pragma unroll
   for (int n = 0; n < NBW; ++n) {
     ps[n] = post ? p.post_scale[coff[n]] : 1.f;
     pb[n] = post ? p.post_shift[coff[n]] : 0.f;
+    as[n] = act ? p.act_scale[coff[n]] : 1.f;
+    ab[n] = act ? p.act_shift[coff[n]] : 0.f;
   }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
@@ -211,6 +217,7 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
         if (add_res) v += p.residual[off + n * 32];
         if (post) v = fmaxf(fmaf(v, ps[n], pb[n]), 0.f);
         out[off + n * 32] = v;
+        if (act) p.out_act[off + n * 32] = fmaxf(fmaf(v, as[n], ab[n]), 0.f);
       }
     }
   }
@@ -260,6 +267,7 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
   const bool final_out = p.ksplit == 1;
   const bool add_res = p.residual != nullptr && final_out;
   const bool post = p.post_scale != nullptr && final_out;
+  const bool act = p.out_act != nullptr && final_out;
   const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
   const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;
 
@@ -275,6 +283,12 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
       const_cast<float *>(post ? p.post_scale : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(post ? p.post_shift : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_as = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(act ? p.act_scale : p.in), 0, act ? p.Cout * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ab = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(act ? p.act_shift : p.in), 0, act ? p.Cout * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
+      act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int32_t *>(p.nbr_tiles), 0, static_cast<unsigned>(num_tiles) * tileK * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ord = __builtin_amdgcn_make_buffer_rsrc(
@@ -343,7 +357,7 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
     uint32_t wg_mask;
     int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
     int v_w;
-    float ps, pb;
+    float ps, pb, as, ab;
     bool col_ok;
   };
 
@@ -418,6 +432,8 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
     }
     c.ps = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ps, colc * 4, 0, 0));
     c.pb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pb, colc * 4, 0, 0));
+    c.as = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_as, colc * 4, 0, 0));
+    c.ab = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ab, colc * 4, 0, 0));
   };
 
   f32x16 acc;
@@ -509,7 +525,7 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
     // ---- epilogue operands first (all LDS reads in flight together), then the next unit's first
     //      operand loads, then the stores: fixed-order sum w0+w1+w2+w3 (+ residual, post); each
     //      wave stores 4 row groups, padding rows go past the end of the buffer (dropped)
-    float v[4];
+    float v[4], va[4];
     unsigned o_off[4];
     {
       const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
@@ -528,6 +544,7 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
         t += part[rr][4];
         if (post) t = fmaxf(fmaf(t, c.ps, c.pb), 0.f);
         v[rr] = t;
+        va[rr] = fmaxf(fmaf(t, c.as, c.ab), 0.f);
         o_off[rr] = (row4[rr] >= 0 && c.col_ok)
                         ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
       }
@@ -539,6 +556,11 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), rs_out, o_off[rr], o_base, 0);
+    if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[rr]), rs_act, o_off[rr], 0, 0);
+    }
     mark(5);
     if constexpr (TRACE) {
       if (lane == 0 && p.trace) {
@@ -616,6 +638,9 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restri
                                                          const float4 *__restrict__ residual,
                                                          const float *__restrict__ post_scale,
                                                          const float *__restrict__ post_shift,
+                                                         const float *__restrict__ act_scale,
+                                                         const float *__restrict__ act_shift,
+                                                         float4 *__restrict__ out_act,
                                                          int ksplit, long long n4, int cout4,
                                                          float4 *__restrict__ out) {
   for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n4; t += gridDim.x * 256LL) {
@@ -636,6 +661,14 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restri
       a.w = fmaxf(fmaf(a.w, post_scale[c + 3], post_shift[c + 3]), 0.f);
     }
     out[t] = a;
+    if (out_act) {
+      const int c = static_cast<int>(t % cout4) * 4;
+      a.x = fmaxf(fmaf(a.x, act_scale[c], act_shift[c]), 0.f);
+      a.y = fmaxf(fmaf(a.y, act_scale[c + 1], act_shift[c + 1]), 0.f);
+      a.z = fmaxf(fmaf(a.z, act_scale[c + 2], act_shift[c + 2]), 0.f);
+      a.w = fmaxf(fmaf(a.w, act_scale[c + 3], act_shift[c + 3]), 0.f);
+      out_act[t] = a;
+    }
   }
 }
 
@@ -645,7 +678,8 @@ __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
     const float *__restrict__ in, const int32_t *__restrict__ nbr, int M_out, int K, int Cin,
     int Cout, const float *__restrict__ w_k8, const float *__restrict__ post_scale,
     const float *__restrict__ post_shift, const float *__restrict__ residual,
-    float *__restrict__ out) {
+    const float *__restrict__ act_scale, const float *__restrict__ act_shift,
+    float *__restrict__ out_act, float *__restrict__ out) {
   const int64_t total = static_cast<int64_t>(M_out) * Cout;
   const int c8 = (Cin + 7) / 8;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
@@ -661,6 +695,7 @@ __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
     if (residual) acc += residual[t];
     if (post_scale) acc = fmaxf(fmaf(acc, post_scale[co], post_shift[co]), 0.f);
     out[t] = acc;
+    if (out_act) out_act[t] = fmaxf(fmaf(acc, act_scale[co], act_shift[co]), 0.f);
   }
 }
 
@@ -722,7 +757,8 @@ size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
 
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
                               int K, int Cin, int Cout, const float *w_k8, const float *post_scale,
-                              const float *post_shift, const float *residual, const int32_t *order,
+                              const float *post_shift, const float *residual, const float *act_scale,
+                              const float *act_shift, float *out_act, const int32_t *order,
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream_) {
   SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
@@ -730,12 +766,14 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
              Cin, Cout);
   SG_REQUIRE((post_scale == nullptr) == (post_shift == nullptr),
              "sg_spconv_gather_conv_f32: post_scale and post_shift must come together");
+  SG_REQUIRE((out_act == nullptr) == (act_scale == nullptr) && (out_act == nullptr) == (act_shift == nullptr),
+             "sg_spconv_gather_conv_f32: act_scale, act_shift and out_act must come together");
   if (M_out == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
   if (Cout % 4 != 0) {
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
                                 stream>>>(in, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,
-                                          residual, out);
+                                          residual, act_scale, act_shift, out_act, out);
     return check_launch("sg_spconv_gather_conv_f32(scalar)");
   }
   const int NB = (Cout + 31) / 32;
@@ -748,7 +786,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                           order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
-  const int target = 2048;
+  static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 2048;   // developer knob
+  const int target = target_env;
   const int waves_per_unit = persistent ? kWavesPerWg : 1;
   int bpu = 1;
   if (!persistent) {
@@ -769,7 +808,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
 
   ConvArgs a;
   a.in = in; a.nbr = nbr; a.w = w_k8; a.post_scale = post_scale; a.post_shift = post_shift;
-  a.residual = residual; a.order = order; a.tile_mask = tile_mask; a.nbr_tiles = nbr_tiles;
+  a.residual = residual; a.act_scale = act_scale; a.act_shift = act_shift; a.out_act = out_act;
+  a.order = order; a.tile_mask = tile_mask; a.nbr_tiles = nbr_tiles;
   a.out = ksplit > 1 ? static_cast<float *>(ws) : out;
   a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
@@ -846,7 +886,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     const long long n4 = static_cast<long long>(M_out) * Cout / 4;
     conv_reduce_kernel<<<grid_for(n4, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4 *>(ws), reinterpret_cast<const float4 *>(residual), post_scale,
-        post_shift, ksplit, n4, Cout / 4, reinterpret_cast<float4 *>(out));
+        post_shift, act_scale, act_shift, reinterpret_cast<float4 *>(out_act), ksplit, n4, Cout / 4,
+        reinterpret_cast<float4 *>(out));
   }
   return check_launch("sg_spconv_gather_conv_f32");
 }

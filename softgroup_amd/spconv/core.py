@@ -211,7 +211,8 @@ def gather_conv(features, plan, w_k8, cout, post_scale=None, post_shift=None, re
         ev0.record()
     L.check(lib.sg_spconv_gather_conv_f32(
         L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
-        L.ptr(w_k8), L.ptr(post_scale), L.ptr(post_shift), L.ptr(residual), L.ptr(plan.order),
+        L.ptr(w_k8), L.ptr(post_scale), L.ptr(post_shift), L.ptr(residual), None, None, None,
+        L.ptr(plan.order),
         L.ptr(plan.tile_mask), L.ptr(plan.nbr_tiles), L.ptr(out), L.ptr(ws),
         nb if ws is not None else 0, L.stream()),
         'sg_spconv_gather_conv_f32')
