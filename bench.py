@@ -171,17 +171,37 @@ def main():
         n_pass = min(args.steps, 5)
         gbps = s['bytes'] / (s['ms'] * 1e-3) / 1e9
         tflops = s['flops'] / (s['ms'] * 1e-3) / 1e12
+        launches = max(s['launches'], 1)
+        # HBM traffic of the same kernel from rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in KiB, separate
+        # passes, collected by the recipe in profiles/README.md on this workload and committed as
+        # profiles/r01_conv_pmc.json).  FETCH_SIZE x2 is the guide's gfx950 correction for 16-B/lane
+        # reads (MI355X_MICROARCH.md "HBM"); null when the file is not there.
+        traffic = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv_pmc.json')
+        try:
+            pmc = json.load(open(pmc_path))['counters']
+            traffic = int((2 * pmc['FETCH_SIZE']['per_dispatch'] + pmc['WRITE_SIZE']['per_dispatch']) * 1024)
+        except (OSError, ValueError, KeyError):
+            pass
+        hbm = {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+               'frac': round(gbps / HBM_PEAK_GBPS, 4)}
+        mfma = {'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
+        # the roof that actually binds is the one with the larger fraction (fp32 MFMA for this
+        # kernel: AI = 2*Cout/4.25 flop/B of gathered data); the other one is kept alongside
+        bound = 'mfma' if mfma['frac'] >= hbm['frac'] else 'hbm'
         out['roofline'] = {
             'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv, fp32 MFMA)',
-            'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': round(gbps / HBM_PEAK_GBPS, 4), 'traffic': None,
+            'bound': bound, **(mfma if bound == 'mfma' else hbm),
+            'traffic': traffic,
             'launches_per_scan': s['launches'] // n_pass,
             'kernel_ms_per_scan': round(s['ms'] / n_pass, 3),
-            'avg_launch_us': round(s['ms'] * 1e3 / max(s['launches'], 1), 2),
+            'avg_launch_us': round(s['ms'] * 1e3 / launches, 2),
+            'algorithmic_bytes_per_launch': s['bytes'] // launches,
+            'algorithmic_flops_per_launch': s['flops'] // launches,
             'algorithmic_bytes_per_scan': s['bytes'] // n_pass,
-            'mfma': {'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': round(tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                     'flops_per_scan': s['flops'] // n_pass},
+            'flops_per_scan': s['flops'] // n_pass,
+            'hbm': hbm, 'mfma': mfma,
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
