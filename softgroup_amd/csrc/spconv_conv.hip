@@ -225,8 +225,11 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // Main kernel: persistent workgroups (Cin % 16 == 0, plan present).
-//   * grid = resident workgroups only; workgroup b walks units b, 2G-1-b, 2G+b, ... of the
-//     heaviest-first unit list (snake), so every workgroup gets one unit of every weight band.
+//   * grid = resident workgroups only (every CU holds the same number of them: a smaller grid with
+//     whole rounds was measured slower, CUs with one workgroup more fall behind);
+//     workgroup b takes one unit per round of G from the heaviest-first unit list, rounds running
+//     forward or reversed after the Thue-Morse word, so every workgroup gets one unit of every
+//     weight band and the totals are even.
 //   * unit = (32-row tile, one 32-column block, offset range); its (offset, slice) items are
 //     split evenly over the 4 waves (imbalance <= 1 slice); partial sums meet in LDS and are added
 //     in a fixed order.
@@ -458,8 +461,11 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
   // ---- work distribution: static snake over the descending unit list.  (A dynamic tail fed by
   //      per-XCD atomic counters was measured slower: a returning atomic sits in the same in-order
   //      return queue as the wave's operand loads and stalls its matrix loop for microseconds.)
+  // round r runs forward or reversed after the Thue-Morse word (F R R F R F F R ...): for a convex
+  // descending weight list that evens the per-workgroup totals better than plain alternation
   auto static_unit = [&](int r) {
-    return r * G + ((r & 1) ? G - 1 - static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x));
+    return r * G + ((__builtin_popcount(r) & 1) ? G - 1 - static_cast<int>(blockIdx.x)
+                                                : static_cast<int>(blockIdx.x));
   };
 
   // ---- prologue of the workgroup: metadata of its first unit
@@ -834,7 +840,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
       if (num_cu <= 0) num_cu = 256;
     }
     // 16-channel slices, 2-deep operand ring: measured best on gfx950 against 32-channel slices
-    // (whole 128-B lines per gather) and a 3-deep ring at every occupancy (profiles/README.md)
+    // (whole 128-B lines per gather) and 3- / 4-deep rings at every occupancy, also on the
+    // single-round (latency-bound) layers (profiles/README.md)
     constexpr int kSliceCh = 16, kRing = 2;
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
@@ -850,6 +857,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     long long g = static_cast<long long>(num_cu) * occ;
     if (g > units) g = units;
     if (g >= 8) g -= g % 8;
+
     static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
     if (trace_env) {
       const size_t nb = static_cast<size_t>(units) * kWavesPerWg * 8 * sizeof(unsigned long long);

@@ -194,3 +194,84 @@ def test_large_scene_linearity_and_determinism():
         cx2 = conv(spconv.SparseConvTensor(x, ti, shape, 1)).features
     assert torch.equal(cx, cx2)
     np.testing.assert_allclose(cxy.cpu().numpy(), (2 * cx - 3 * cy).cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('cin,cout,n,kernel', [
+    (64, 64, 9000, 'persistent'),      # several rounds of units
+    (128, 96, 300, 'persistent+split'),  # tiny layer: offsets split over units, reduce kernel
+    (6, 32, 5000, 'tile'),             # Cin % 16 != 0: general kernel
+    (32, 6, 2000, 'scalar'),           # Cout % 4 != 0: scalar path
+])
+def test_conv_epilogues_through_the_c_abi(cin, cout, n, kernel):
+    """sg_spconv_gather_conv_f32 with every epilogue at once -- residual, in-place BatchNorm+ReLU
+    (`post`) and the second activated output (`act`) -- on each kernel path, against plain torch on
+    the oracle's gather table."""
+    from softgroup_amd import _lib as L
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape = [40, 40, 24]
+    idx = _scene(rng, n, shape)
+    M = len(idx)
+    rule = core.SubMRule(t(idx), shape)
+    plan = rule.plan
+    f = torch.randn(M, cin, device=DEV)
+    w = torch.randn(cout, 27, cin, device=DEV) * 0.1
+    res = torch.randn(M, cout, device=DEV)
+    ps, pb = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    as_, ab = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    w_k8 = core.pack_weight(w, cout, 27, cin, False)
+    out = torch.empty(M, cout, device=DEV)
+    out_act = torch.empty(M, cout, device=DEV)
+    lib = L.lib()
+    nb = lib.sg_spconv_conv_workspace_bytes(M, cout)
+    ws = L.workspace(nb, f.device)
+    L.check(lib.sg_spconv_gather_conv_f32(
+        L.ptr(f), M, L.ptr(plan.nbr), M, 27, cin, cout, L.ptr(w_k8), L.ptr(ps), L.ptr(pb), L.ptr(res),
+        L.ptr(as_), L.ptr(ab), L.ptr(out_act), L.ptr(plan.order), L.ptr(plan.tile_mask),
+        L.ptr(plan.nbr_tiles), L.ptr(out), L.ptr(ws), nb, L.stream()), 'sg_spconv_gather_conv_f32')
+    nbr = plan.nbr.long()
+    gathered = torch.where((nbr >= 0)[:, :, None], f[nbr.clamp(min=0)], torch.zeros((), device=DEV))   # [M,27,cin]
+    ref = torch.einsum('mkc,okc->mo', gathered.double(), w.double()) + res.double()
+    ref = torch.relu(ref * ps.double() + pb.double())
+    ref_act = torch.relu(ref * as_.double() + ab.double())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(out_act.cpu().numpy(), ref_act.float().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_unet_executor_small_net_and_arena_error():
+    """sg_unet_forward on a 3-level UBlock (odd extents, channels 16/32/48) against the module
+    path; an arena that is too small must come back as an error, not as a crash."""
+    import functools
+    from softgroup_amd import _lib as L
+    from softgroup_amd.model.blocks import ResidualBlock, UBlock
+    from softgroup_amd.spconv import unet_exec
+    torch.manual_seed(3)
+    norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+    unet = UBlock([16, 32, 48], norm_fn, 2, ResidualBlock, indice_key_id=1).to(DEV).eval()
+    out_layer = spconv.SparseSequential(norm_fn(16), nn.ReLU()).to(DEV).eval()
+    for m in list(unet.modules()) + list(out_layer.modules()):
+        if isinstance(m, nn.BatchNorm1d):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.normal_(1, 0.2)
+                m.bias.normal_(0, 0.2)
+    rng = np.random.default_rng(8)
+    shape = [45, 37, 29]
+    idx = _scene(rng, 6000, shape, B=2)
+    x = spconv.SparseConvTensor(torch.randn(len(idx), 16, device=DEV), t(idx), shape, 2)
+    ex = unet_exec.UNetExecutor(unet, None, out_layer)
+    with torch.no_grad():
+        assert ex.usable(x.features)
+        got = ex(x)
+        ref = out_layer(unet(x)).features
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    # too small an arena
+    orig = unet_exec._get_arena
+    unet_exec._get_arena = lambda nb, dev: torch.empty(1 << 16, dtype=torch.uint8, device=dev)
+    try:
+        with torch.no_grad(), pytest.raises(L.SoftGroupHipError, match='arena'):
+            ex(x)
+    finally:
+        unet_exec._get_arena = orig
+    with torch.no_grad():
+        assert torch.equal(ex(x), got)          # and the executor is still usable, bit-identical
