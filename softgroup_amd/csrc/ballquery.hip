@@ -10,7 +10,7 @@
 // cells are found through an open-addressing table keyed by (batch, cx, cy, cz); points are
 // counting-sorted by cell into a float4 {x,y,z,id} array so the candidate scan is a
 // contiguous 16-B/lane stream.  One wave per query point: lanes 0..26 probe the 27 cells,
-// then all 64 lanes stream the candidates; accepted ids are compacted with ballot+popcount
+// then all 64 lanes stream the candidates (flat over the 27 ranges); accepted ids are compacted with ballot+popcount
 // into LDS and rank-sorted there (ascending) before one coalesced write.  Two passes
 // (count -> scan -> fill) make the CSR layout deterministic (the reference's atomic cursor
 // does not).
@@ -92,14 +92,42 @@ __device__ __forceinline__ float dist2(float ox, float oy, float oz, float x, fl
 }
 
 // number of accepted candidates with id < limit (limit = INT_MAX counts all)
-__device__ __forceinline__ int bq_scan_count(const float4 *__restrict__ sorted, int my_start,
-                                             int my_count, float ox, float oy, float oz,
-                                             float r2, int limit) {
+// The candidates of a query are the concatenation of its 27 cells' point ranges.  They are walked
+// FLAT, 64 at a time: lane t of a chunk finds its cell by a 5-step binary search over the cells'
+// inclusive prefix counts (held by lanes 0..26, read with shuffles), so a query with ~150
+// candidates costs 3 coalesced-ish load rounds instead of 27 dependent ones.
+struct BqCells {
+  int start, excl, incl, total;   // per lane (cell = lane < 27): range start, prefix counts; wave total
+};
+__device__ __forceinline__ BqCells bq_cells(int my_start, int my_count) {
+  BqCells c;
+  c.start = my_start;
+  c.incl = wave_incl_scan(my_count);
+  c.excl = c.incl - my_count;
+  c.total = __shfl(c.incl, 63, 64);
+  return c;
+}
+// index into `sorted` of flat candidate t (t < total)
+__device__ __forceinline__ int bq_candidate(const BqCells &c, int t) {
+  int lo = 0, hi = 26;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const bool right = __shfl(c.incl, mid, 64) <= t;
+    lo = right ? mid + 1 : lo;
+    hi = right ? hi : mid;
+  }
+  return __shfl(c.start, lo, 64) + (t - __shfl(c.excl, lo, 64));
+}
+
+__device__ __forceinline__ int bq_scan_count(const float4 *__restrict__ sorted, const BqCells &c,
+                                             float ox, float oy, float oz, float r2, int limit) {
   int total = 0;
-  for (int c = 0; c < 27; ++c) {
-    const int st = __shfl(my_start, c, 64), ct = __shfl(my_count, c, 64);
-    for (int j = lane_id(); j < ct; j += 64) {
-      const float4 p = sorted[st + j];
+  for (int t0 = 0; t0 < c.total; t0 += 64) {
+    const int t = t0 + lane_id();
+    const int at = bq_candidate(c, min(t, c.total - 1));
+    if (t < c.total) {
+      const float4 p = sorted[at];
       total += (dist2(ox, oy, oz, p.x, p.y, p.z) < r2 && __float_as_int(p.w) < limit) ? 1 : 0;
     }
   }
@@ -138,8 +166,9 @@ __global__ void __launch_bounds__(256) bq_query_kernel(const float *__restrict__
         s = (s + 1) & mask;
       }
     }
+    const BqCells cells = bq_cells(my_start, my_count);
     if (!FILL) {
-      const int total = bq_scan_count(sorted, my_start, my_count, ox, oy, oz, r2, 0x7fffffff);
+      const int total = bq_scan_count(sorted, cells, ox, oy, oz, r2, 0x7fffffff);
       if (lane == 0) start_len[2 * i + 1] = min(total, kBqCap);
       continue;
     }
@@ -149,22 +178,20 @@ __global__ void __launch_bounds__(256) bq_query_kernel(const float *__restrict__
     int m = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
       m = 0;
-      for (int cc = 0; cc < 27; ++cc) {
-        const int st = __shfl(my_start, cc, 64), ct = __shfl(my_count, cc, 64);
-        for (int j0 = 0; j0 < ct; j0 += 64) {
-          const int j = j0 + lane;
-          bool ok = false;
-          int id = 0;
-          if (j < ct) {
-            const float4 p = sorted[st + j];
-            id = __float_as_int(p.w);
-            ok = dist2(ox, oy, oz, p.x, p.y, p.z) < r2 && id < limit;
-          }
-          const uint64_t bal = __ballot(ok);
-          const int pos = m + mask_prefix(bal);
-          if (ok && pos < kBqBuf) buf[pos] = id;
-          m += __popcll(bal);
+      for (int t0 = 0; t0 < cells.total; t0 += 64) {
+        const int t = t0 + lane;
+        const int at = bq_candidate(cells, min(t, cells.total - 1));
+        bool ok = false;
+        int id = 0;
+        if (t < cells.total) {
+          const float4 p = sorted[at];
+          id = __float_as_int(p.w);
+          ok = dist2(ox, oy, oz, p.x, p.y, p.z) < r2 && id < limit;
         }
+        const uint64_t bal = __ballot(ok);
+        const int pos = m + mask_prefix(bal);
+        if (ok && pos < kBqBuf) buf[pos] = id;
+        m += __popcll(bal);
       }
       if (m <= kBqBuf) break;
       // Rare: more accepted candidates than the LDS stage holds.  Find the id threshold below
@@ -172,7 +199,7 @@ __global__ void __launch_bounds__(256) bq_query_kernel(const float *__restrict__
       int lo = 0, hi = n;  // smallest T with count(id < T) >= out_len
       while (lo < hi) {
         const int mid = lo + (hi - lo) / 2;
-        const int cmid = bq_scan_count(sorted, my_start, my_count, ox, oy, oz, r2, mid);
+        const int cmid = bq_scan_count(sorted, cells, ox, oy, oz, r2, mid);
         if (cmid >= out_len) hi = mid; else lo = mid + 1;
       }
       limit = lo;

@@ -78,6 +78,24 @@ def main():
         print(f'  first loop start per workgroup: mean {first.mean():.0f} p90 {np.percentile(first, 90):.0f}')
         last = np.array([t[wgid == w, :, 5].max() for w in np.unique(wgid)])
         print(f'  workgroup end: p10 {np.percentile(last, 10):.0f} p50 {np.percentile(last, 50):.0f} p90 {np.percentile(last, 90):.0f} max {last.max()}')
+        # per workgroup: work (slices of its 4 waves' max per unit) vs finishing time
+        wgs = np.unique(wgid)
+        work = np.array([n_iter[wgid == w].max(1).sum() for w in wgs])
+        nun = np.array([(wgid == w).sum() for w in wgs])
+        print(f'  per workgroup: units {nun.min()}..{nun.max()}, slices mean {work.mean():.1f} min {work.min()} max {work.max()}; '
+              f'corr(work, end) = {np.corrcoef(work, last)[0, 1]:.2f}')
+        speed = last / np.maximum(work, 1)
+        wxcc = np.array([xcc[wgid == w][0, 0] for w in wgs])
+        for x in np.unique(wxcc):
+            sel = wxcc == x
+            print(f'    xcc {x}: workgroups {sel.sum():4d} end mean {last[sel].mean():9.0f} max {last[sel].max():9.0f} '
+                  f'ticks/slice {speed[sel].mean():7.0f} work mean {work[sel].mean():.1f}')
+        wcu = np.array([cu[wgid == w][0, 0] for w in wgs])
+        per_cu_end = np.array([last[wcu == c].max() for c in np.unique(wcu)])
+        per_cu_n = np.array([(wcu == c).sum() for c in np.unique(wcu)])
+        print(f'  per CU: resident workgroups {per_cu_n.min()}..{per_cu_n.max()}; last end p10 {np.percentile(per_cu_end, 10):.0f} '
+              f'p50 {np.percentile(per_cu_end, 50):.0f} p90 {np.percentile(per_cu_end, 90):.0f}; '
+              f'corr(n resident, end) = {np.corrcoef(per_cu_n, per_cu_end)[0, 1]:.2f}')
         w0 = np.unique(wgid)[:3]
         for w in w0:
             sel = np.where(wgid == w)[0]
