@@ -275,3 +275,27 @@ def test_unet_executor_small_net_and_arena_error():
         unet_exec._get_arena = orig
     with torch.no_grad():
         assert torch.equal(ex(x), got)          # and the executor is still usable, bit-identical
+
+
+@pytest.mark.parametrize('n,shape', [(1, [8, 8, 8]), (7, [9, 9, 9]), (40, [5, 6, 7]), (700, [33, 17, 9]),
+                                     (3000, [12, 12, 12])])
+def test_unet_executor_degenerate_sizes(n, shape):
+    """tiny / odd inputs: levels that lose all voxels to the odd-extent drop, single-tile layers,
+    fewer units than XCDs -- executor and module path must agree and stay finite."""
+    import functools
+    from softgroup_amd.model.blocks import ResidualBlock, UBlock
+    from softgroup_amd.spconv import unet_exec
+    torch.manual_seed(n)
+    norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+    unet = UBlock([32, 64, 96], norm_fn, 2, ResidualBlock, indice_key_id=1).to(DEV).eval()
+    inp = spconv.SparseSequential(spconv.SubMConv3d(6, 32, 3, padding=1, bias=False, indice_key='subm1')).to(DEV).eval()
+    out_layer = spconv.SparseSequential(norm_fn(32), nn.ReLU()).to(DEV).eval()
+    rng = np.random.default_rng(n)
+    idx = _scene(rng, n, shape)
+    x = spconv.SparseConvTensor(torch.randn(len(idx), 6, device=DEV), t(idx), shape, 1)
+    ex = unet_exec.UNetExecutor(unet, inp, out_layer)
+    with torch.no_grad():
+        got = ex(x)
+        ref = out_layer(unet(inp(x))).features
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), atol=5e-5, rtol=1e-5)
