@@ -157,18 +157,30 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel: gather_conv_mfma (sparse-conv implicit GEMM).  Extra pass of the same
         # steps with a HIP event pair around every launch, on the launch stream.
-        # (the module path launches the same conv kernels as the native executor used in the timed
-        # region, one Python call per launch, which is where the event pairs are recorded)
+        # (a) algorithmic bytes / flops per launch: one forward on the module path, which makes one
+        #     Python call per conv launch (same kernels as the native executor of the timed region);
+        # (b) kernel time: the library brackets every conv launch with a HIP event pair on its launch
+        #     stream (sg_spconv_profile) while the SAME path as the timed region runs n_pass scans.
         prof = spcore.ConvProfiler()
         spcore.PROFILER = prof
         model.use_executor = False
         with torch.no_grad():
-            for _ in range(min(args.steps, 5)):
-                model(batch)
+            model(batch).resolve()
         s = prof.summary()
         spcore.PROFILER = None
         model.use_executor = True
         n_pass = min(args.steps, 5)
+        lib = _lib.lib()
+        _lib.check(lib.sg_spconv_profile(1), 'sg_spconv_profile')
+        with torch.no_grad():
+            for _ in range(n_pass):
+                model(batch).resolve()
+        torch.cuda.synchronize()
+        ms, nl = _lib.C.c_double(0), _lib.C.c_int(0)
+        _lib.check(lib.sg_spconv_profile_read(_lib.C.byref(ms), _lib.C.byref(nl)), 'sg_spconv_profile_read')
+        _lib.check(lib.sg_spconv_profile(0), 'sg_spconv_profile')
+        assert nl.value == s['launches'] * n_pass, (nl.value, s['launches'])
+        s = dict(launches=nl.value, ms=ms.value, bytes=s['bytes'] * n_pass, flops=s['flops'] * n_pass)
         gbps = s['bytes'] / (s['ms'] * 1e-3) / 1e9
         tflops = s['flops'] / (s['ms'] * 1e-3) / 1e12
         launches = max(s['launches'], 1)

@@ -267,6 +267,13 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);
 
+/* Measurement hook (bench.py roofline): while enabled, every sg_spconv_gather_conv_f32 call -- from
+ * Python or from inside sg_unet_forward -- is bracketed by a HIP event pair on its launch stream.
+ * sg_spconv_profile_read waits for the events and returns the summed kernel time and the number of
+ * calls since the last sg_spconv_profile(1). */
+int sg_spconv_profile(int enable);
+int sg_spconv_profile_read(double *total_ms, int *launches);
+
 /* Weight gradient of the same operator (training; spconv's backward reached through autograd,
  * tools/train.py:58): dw_kio[k][ci][co] += sum_j in[nbr[j,k]][ci] * g_out[j][co].  dw_kio is
  * [K][Cin][Cout], zero-filled by the caller.  The input gradient needs no extra entry point: it is

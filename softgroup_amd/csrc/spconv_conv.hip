@@ -735,11 +735,50 @@ static void launch_tile(const ConvArgs &a, int grid, size_t lds, bool vec, hipSt
     gather_conv_tile_kernel<NBW, false><<<grid, 256, lds, stream>>>(a);
 }
 
+// Optional timing of the conv launches with HIP events recorded inside the library, right around
+// the kernel launches on the launch stream (bench.py's roofline measurement; off by default).
+struct ConvProf {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;     // start/stop pairs, reused across sessions
+  size_t used = 0;
+  hipEvent_t take() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+static ConvProf g_conv_prof;
+
 }  // namespace sg
 
 using namespace sg;
 
 extern "C" {
+
+int sg_spconv_profile(int enable) {
+  g_conv_prof.enabled = enable != 0;
+  if (enable) g_conv_prof.used = 0;
+  return SG_OK;
+}
+
+int sg_spconv_profile_read(double *total_ms, int *launches) {
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < g_conv_prof.used; i += 2) {
+    if (hipEventSynchronize(g_conv_prof.pool[i + 1]) != hipSuccess) {
+      set_error("sg_spconv_profile_read: event synchronisation failed");
+      return SG_ERR_LAUNCH;
+    }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g_conv_prof.pool[i], g_conv_prof.pool[i + 1]);
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = static_cast<int>(g_conv_prof.used / 2);
+  return SG_OK;
+}
 
 size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout) {
   return static_cast<size_t>(kvol) * ((cin + 7) / 8) * cout * 8;
@@ -776,6 +815,16 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
              "sg_spconv_gather_conv_f32: act_scale, act_shift and out_act must come together");
   if (M_out == 0) return SG_OK;
   hipStream_t stream = as_stream(stream_);
+  struct ProfScope {      // start event now, stop event when the call has enqueued its last kernel
+    hipStream_t st;
+    bool on;
+    ProfScope(hipStream_t s, bool count) : st(s), on(g_conv_prof.enabled && count) {
+      if (on) hipEventRecord(g_conv_prof.take(), st);
+    }
+    ~ProfScope() {
+      if (on) hipEventRecord(g_conv_prof.take(), st);
+    }
+  } prof_scope(stream, K > 1);     // the 1x1 identity-branch convs are not part of the conv roofline
   if (Cout % 4 != 0) {
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
                                 stream>>>(in, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,
