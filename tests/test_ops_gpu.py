@@ -202,6 +202,25 @@ def test_bfs_cluster_directed_lists_capped():
     assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
 
 
+def test_bfs_cluster_bigger_than_the_lds_claim_array():
+    """one 22 500-point cluster (> 16 384: claims live in global memory, every level takes the
+    generic path) next to small ones that take the fast path -- membership and BFS order exact."""
+    g = np.stack(np.meshgrid(np.arange(150), np.arange(150), indexing='ij'), -1).reshape(-1, 2)
+    sheet = np.concatenate([g * 0.02, np.zeros((len(g), 1))], 1)
+    rng = np.random.default_rng(23)
+    small = [rng.normal(0, 0.01, (300, 3)) + np.array([5.0 + 0.5 * i, 1.0, 1.0]) for i in range(4)]
+    xyz = np.concatenate([sheet] + small).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    n = len(xyz)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(np.zeros(n, np.int32)), t(np.array([0, n], np.int32)),
+                                    0.03, 300)
+    mean = torch.tensor([-1.0])
+    ci, co = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
+    rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 50.0, 0)
+    assert np.diff(rco).max() == 22500 and len(rco) - 1 == 5
+    assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
+
+
 def test_bfs_cluster_empty_and_all_dropped():
     mean = torch.tensor([-1.0])
     ci, co = ops.bfs_cluster(mean, torch.zeros(0, dtype=torch.int32, device=DEV),
