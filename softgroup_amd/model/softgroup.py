@@ -159,7 +159,7 @@ class SoftGroup(nn.Module):
                 coords_float = ops.voxelization(coords_float, p2v_map)
             proposals_idx, proposals_offset = self.forward_grouping(
                 semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
-                lvl_fusion=lvl_fusion)
+                lvl_fusion=lvl_fusion, batch_size=None if x4_split else batch_size)
             inst_feats, inst_map = self.clusters_voxelization(
                 proposals_idx, proposals_offset, output_feats, coords_float,
                 **self.instance_voxel_cfg)
@@ -258,7 +258,7 @@ class SoftGroup(nn.Module):
     # ------------------------------------------------------------------ grouping
     @force_fp32(apply_to=('semantic_scores', 'pt_offsets'))
     def forward_grouping(self, semantic_scores, pt_offsets, batch_idxs, coords_float,
-                         grouping_cfg=None, lvl_fusion=False):
+                         grouping_cfg=None, lvl_fusion=False, batch_size=None):
         """-> proposals_idx int32 [S,2] (proposal id, point idx), proposals_offset int32 [nP+1].
         Same values and order as the reference (softgroup.py:411-480), kept on the GPU."""
         g = self.grouping_cfg
@@ -273,7 +273,8 @@ class SoftGroup(nn.Module):
         ignore = set(_cfg(g, 'ignore_classes'))
         classes = [c for c in range(self.semantic_classes) if c not in ignore]
         min_npoint = _cfg(self.test_cfg, 'min_npoint')
-        batch_size = int(batch_idxs.max()) + 1
+        if batch_size is None:       # (the reference reads it back from the GPU every time)
+            batch_size = int(batch_idxs.max()) + 1
         scores = semantic_scores.softmax(dim=-1)
 
         if with_pyramid or with_octree:
