@@ -227,7 +227,9 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
  * 32-row MFMA tile only visits kernel offsets some row of the tile really has.
  * T = ceil(M_out/32) tiles, emitted heaviest first (descending number of offsets) so that the
  * dispatcher spreads heavy and light tiles over the chip (longest-processing-time-first):
- *   order[T*32]       : row ids of every tile (rows sorted by neighbour mask), -1 padding
+ *   order[T*32]       : row ids of every tile, -1 padding.  Rows are sorted by their neighbour mask
+ *                       with the bits permuted by offset frequency in this layer (rarest offset =
+ *                       most significant bit; ties: lower offset is the more common one)
  *   tile_mask[T]      : OR of the masks of the tile's rows
  *   nbr_tiles[T*32*K] : the tile's gather-table rows copied contiguously (-1 for padding rows)
  * Row order behind the API is untouched: a tile computes rows order[32t .. 32t+31] and stores

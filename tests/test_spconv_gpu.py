@@ -50,11 +50,24 @@ def test_subm_rulebook_and_plan_exact():
     assert np.array_equal(tm, np.bitwise_or.reduce(row_mask, 1))
     pop = np.array([bin(int(x)).count('1') for x in tm])
     assert (np.diff(pop) <= 0).all()                                   # heaviest tiles first
-    # inside the mask-sorted sequence every tile is a contiguous run: per-tile mask ranges are disjoint-sorted
-    lo = np.where(valid, row_mask, np.uint32(0xffffffff)).min(1)
-    hi = row_mask.max(1)
+    # rows are sorted by the mask with its bits permuted by offset frequency (rarest offset = MSB,
+    # ties: lower offset more common); every tile is a contiguous run of that sequence, so the
+    # per-tile key ranges are disjoint and sorted
+    freq = ((nbr >= 0).sum(0)).astype(np.int64)
+    pos = np.array([sum(1 for o in range(27) if freq[o] > freq[k] or (freq[o] == freq[k] and o < k))
+                    for k in range(27)])
+    key = (((mask[:, None] >> np.arange(27)) & 1).astype(np.uint64) << pos.astype(np.uint64)).sum(1)
+    row_key = np.where(valid, key[np.clip(order, 0, None)], 0).astype(np.uint64)
+    lo = np.where(valid, row_key, np.uint64(0xffffffff)).min(1)
+    hi = row_key.max(1)
     o = np.argsort(lo, kind='stable')
     assert (hi[o][:-1] <= lo[o][1:]).all()
+    # and it pays: fewer (tile, offset) pairs than sorting by the raw mask
+    def pairs(seq):
+        pad = np.zeros(T * 32, np.uint32)
+        pad[:M] = seq
+        return sum(bin(int(x)).count('1') for x in np.bitwise_or.reduce(pad.reshape(T, 32), 1))
+    assert pop.sum() <= pairs(np.sort(mask))
     nt = rule.plan.nbr_tiles.cpu().numpy().reshape(T, 32, 27)
     exp = np.where(valid[:, :, None], nbr[np.clip(order, 0, None)], -1)
     assert np.array_equal(nt, exp)
