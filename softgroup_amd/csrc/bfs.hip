@@ -195,12 +195,28 @@ __global__ void __launch_bounds__(256) bfs_label_kernel(int n, const int32_t *__
                                                        const int32_t *__restrict__ start_len,
                                                        int4 *__restrict__ node_rec, int32_t *size) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int l = lab[root_of[i]];
+  const bool valid = i < n;
+  const int l = valid ? lab[root_of[i]] : -1;
+  // slot = running count of the label.  Neighbouring points mostly share their label, so the
+  // lanes of a wave with equal labels are counted together: one atomic per distinct label.
+  int slot = 0;
+  uint64_t todo = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int ll = __shfl(l, leader, 64);
+    const uint64_t same = __ballot(valid && l == ll) & todo;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&size[ll], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if ((same >> lane) & 1ull) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (!valid) return;
   // (cluster label, slot of the point inside its cluster, list start, list length): one 16-B
   // record per point so that the ordered emission fetches everything about a node in one load.
   // The slot indexes the cluster's visited/claim array when that array lives in LDS.
-  node_rec[i] = make_int4(l, atomicAdd(&size[l], 1), start_len[2 * i], start_len[2 * i + 1]);
+  node_rec[i] = make_int4(l, slot, start_len[2 * i], start_len[2 * i + 1]);
 }
 
 __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size) {
