@@ -284,7 +284,17 @@ class SoftGroup(nn.Module):
                                             lvl_fusion)
 
         # ---- all classes at once: segment s = position of the class in `classes`
-        cls_t = torch.tensor(classes, device=dev)
+        # (constants of the configuration live on the device once, not re-uploaded per scan)
+        const = self.__dict__.setdefault('_grouping_const', {})
+        ck = (str(dev), tuple(classes), float(npoint_thr), tuple(class_mean.tolist()))
+        if ck not in const:
+            m = class_mean[classes].numpy()
+            # thr = npoint_thr (absolute) if class mean == -1 else npoint_thr * mean, fp32
+            thr = np.where(m == np.float32(-1), np.float32(npoint_thr), np.float32(npoint_thr) * m)
+            const[ck] = (torch.tensor(classes, device=dev),
+                         torch.from_numpy(thr.astype(np.float32)).to(dev),
+                         torch.zeros(2, dtype=torch.int32, device=dev))
+        cls_t, seg_thr, dummy_offsets = const[ck]
         sel = scores[:, cls_t].t() > _cfg(g, 'score_thr')                  # [n_seg, N]
         sel &= (sel.sum(1, keepdim=True) >= min_npoint)                    # small classes are skipped
         seg, obj = sel.nonzero(as_tuple=True)                              # class-major, point-ascending
@@ -294,12 +304,7 @@ class SoftGroup(nn.Module):
         pts = (coords_float[obj] + pt_offsets[obj]).contiguous()
         seg32 = seg.int()
         key = (seg32 * batch_size + batch_idxs[obj].int()).contiguous()    # never mix classes/scenes
-        dummy_offsets = torch.zeros(2, dtype=torch.int32, device=dev)
         nbr_idx, start_len = ops.ballquery_batch_p(pts, key, dummy_offsets, radius, mean_active)
-        # thr = npoint_thr (absolute) if class mean == -1 else npoint_thr * mean, fp32
-        m = class_mean[classes].numpy()
-        thr = np.where(m == np.float32(-1), np.float32(npoint_thr), np.float32(npoint_thr) * m)
-        seg_thr = torch.from_numpy(thr.astype(np.float32)).to(dev)
         proposals_idx, proposals_offset = ops.bfs_cluster_segments(
             nbr_idx, start_len, seg_thr, seg32.contiguous(), ops.LISTS_SORTED | ops.LISTS_RADIUS)
         if proposals_idx.shape[0] == 0:
