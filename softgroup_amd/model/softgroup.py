@@ -431,7 +431,10 @@ class SoftGroup(nn.Module):
     @force_fp32(apply_to=('x'))
     def global_pool(self, x, expand=False):
         ids = x.indices[:, 0]
-        counts = torch.bincount(ids.long(), minlength=x.batch_size)
+        # voxels per proposal; scatter_add into a fixed-size tensor (bincount would read the maximum
+        # back to the host first)
+        counts = torch.zeros(x.batch_size, dtype=torch.long, device=ids.device).scatter_add_(
+            0, ids.long(), torch.ones_like(ids, dtype=torch.long))
         offsets = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
         pooled = ops.global_avg_pool(x.features.contiguous(), offsets)
         if not expand:
