@@ -146,6 +146,17 @@ def main():
     }
 
     if rank == 0:
+        # the same K scans with result formatting done in line (no overlap with the next scan), for
+        # reference next to the pipelined figure above
+        model.async_results = False
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(min(args.steps, 10)):
+                model(batch)
+            torch.cuda.synchronize()
+            out['ms_per_step_unpipelined'] = round((time.perf_counter() - t1) / min(args.steps, 10) * 1e3, 3)
+        model.async_results = True
         stages, info = stage_times(model, batch)
         out['stages_ms'] = stages
         out['scene'] = info
