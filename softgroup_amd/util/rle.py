@@ -47,7 +47,7 @@ def rle_encode_many(length, starts, lens, bounds):
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     L.check(lib.sg_rle_format_host(vp(starts), vp(lens), vp(bounds), n, vp(buf), cap, vp(offs)),
             'sg_rle_format_host')
-    mv = memoryview(buf)
     o = offs.tolist()
+    text = buf[:o[n]].tobytes().decode('ascii')        # one decode, then plain string slices
     length = int(length)
-    return [dict(length=length, counts=str(mv[o[g]:o[g + 1]], 'ascii')) for g in range(n)]
+    return [dict(length=length, counts=text[o[g]:o[g + 1]]) for g in range(n)]
