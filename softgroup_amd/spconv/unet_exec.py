@@ -34,6 +34,7 @@ class _Desc(C.Structure):
                 ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p)]
 
 
+_ERR_WORKSPACE = -2     # SG_ERR_WORKSPACE (include/softgroup_hip.h)
 _arena = {}      # device -> uint8 tensor, grow-only
 
 
@@ -192,9 +193,16 @@ class UNetExecutor:
         out = torch.empty((M, d.levels[0].planes), dtype=torch.float32, device=feats.device)
         if M == 0:
             return out
-        nb = lib.sg_unet_arena_bytes(C.byref(d), M)
-        arena = _get_arena(nb, feats.device)
+        # sg_unet_arena_bytes prices every level with all M voxels (a bound that always suffices);
+        # real scenes shrink ~2-4x per level, so a quarter of it is tried first and the bound only
+        # if the executor reports the arena too small (the cached arena only ever grows)
+        full = lib.sg_unet_arena_bytes(C.byref(d), M)
         shape = (C.c_int32 * 3)(*x.spatial_shape)
-        L.check(lib.sg_unet_forward(C.byref(d), L.ptr(feats), L.ptr(idx), M, shape, L.ptr(out),
-                                    L.ptr(arena), arena.numel(), L.stream()), 'sg_unet_forward')
+        for nb in (max(full // 4, min(full, 64 << 20)), full):
+            arena = _get_arena(nb, feats.device)
+            rc = lib.sg_unet_forward(C.byref(d), L.ptr(feats), L.ptr(idx), M, shape, L.ptr(out),
+                                     L.ptr(arena), arena.numel(), L.stream())
+            if rc != _ERR_WORKSPACE or nb == full:
+                L.check(rc, 'sg_unet_forward')
+                break
         return out
