@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int4 *__rest
 
 // Edge records for the ordered emission: for every edge e = (v -> t) whose source lies in a kept
 // cluster, everything the BFS replay needs about the target in one 8-byte read: its slot in the
-// cluster's claim array (0xffff = t belongs to another cluster, never claimed), and its own list
+// cluster's claim array (0xffff = t belongs to another cluster, never claimed; saturates at 0xfffe
+// for clusters too large for the LDS array, which claim by point id instead), and its own list
 // (start, length) so that a claimed target becomes a frontier node without a second lookup.
 // One wave per source node; this is the only place that gathers node_rec[] at random.
 __global__ void __launch_bounds__(256) bfs_edge_rec_kernel(const int32_t *__restrict__ idx,
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(256) bfs_edge_rec_kernel(const int32_t *__rest
     if (c >= n_cluster || seeds[c] != rv.x) continue;          // source not in a kept cluster
     for (int p = lane; p < rv.w; p += 64) {
       const int4 rt = node_rec[idx[rv.z + p]];
-      erec[rv.z + p] = rt.x == rv.x ? make_int2((rt.y & 0xffff) | (rt.w << 16), rt.z)
+      erec[rv.z + p] = rt.x == rv.x ? make_int2(min(rt.y, 0xfffe) | (rt.w << 16), rt.z)
                                     : make_int2(0xffff, 0);
     }
   }
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
       // (edge -> (frontier node, position) by a binary search over the nodes' edge bases in LDS),
       // so all edge records of a level are requested at once: ONE memory round trip per level.
       int E = -1;
-      if (own_in_lds && in_lds && L <= kFrontChunk) {
+      if (in_lds && L <= kFrontChunk) {
         int carry = 0;
         for (int b0 = 0; b0 < L; b0 += kEmitThreads) {
           const int q = b0 + threadIdx.x;
@@ -401,8 +402,16 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
           e_g[e] = g;
           e_st[e] = r.y;
           e_ln[e] = static_cast<unsigned short>(r.x >> 16);
-          if (slot != 0xffffu && own_lds[slot] > e) atomicMin(&own_lds[slot], e);
+          if (slot != 0xffffu) {
+            if (own_in_lds) {
+              if (own_lds[slot] > e) atomicMin(&own_lds[slot], e);
+            } else {          // cluster larger than the LDS claim array: claims by point id in global
+              const int v = idx[g];
+              if (SG_LD(&owner_g[v]) > e) atomicMin(&owner_g[v], e);
+            }
+          }
         }
+        if (!own_in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int nxt = cur ^ 1;
         int t_new = 0;
@@ -410,9 +419,17 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
           const int e = b0 + threadIdx.x;
           unsigned short slot = 0xffffu;
           bool win = false;
+          int v = 0;
           if (e < E) {
             slot = ebuf[e];
-            win = slot != 0xffffu && own_lds[slot] == e;
+            if (slot != 0xffffu) {
+              if (own_in_lds) {
+                win = own_lds[slot] == e;
+              } else {
+                v = idx[e_g[e]];
+                win = SG_LD(&owner_g[v]) == e;
+              }
+            }
           }
           int tot;
           const int oo = t_new + wg_excl_scan(win ? 1 : 0, lds_scan, &tot);
@@ -423,11 +440,13 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
               f_st[nxt][oo] = e_st[e];
               f_ln[nxt][oo] = e_ln[e];
             }
-            own_lds[slot] = -1;     // visited; only this edge can match pos, see header
+            // visited; only this edge can match pos, see header
+            if (own_in_lds) own_lds[slot] = -1; else SG_ST(&owner_g[v], -1);
           }
           t_new += tot;
         }
         if (conv_lo < 0 && t_new > 0) conv_lo = tail;
+        if (!own_in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         head = tail;
         tail += t_new;
