@@ -9,7 +9,7 @@
  *
  * Parity pin: voxelize_idx / bfs_cluster / octree build are checked against the
  * reference's own C++ (compiled unmodified into oracle/_ref, see build_ref.py) in
- * tests/test_oracle_pinned.py and against tests/golden/*.npz generated from it.
+ * tests/test_oracle_golden.py and against tests/golden/*.npz generated from it.
  * The CUDA-only kernels of the reference (voxelize_fp/bp, ballquery_batch_p,
  * octree_ball_query, sec_*, global_avg_pool, mask IoU/label) have no CPU build in
  * the reference and no golden vectors: their restatements below are "parity

@@ -12,7 +12,7 @@
  * Weight layout [Cout, kD, kH, kW, Cin] (tools/convert_checkpoint.py:17-19).
  * "Parity unpinned" against spconv itself; pinned instead against the dense
  * torch.nn.functional.conv3d / conv_transpose3d equivalence in
- * tests/test_oracle_conv_dense.py (fp32, tolerance 1e-4).
+ * tests/test_oracle_golden.py::test_sparse_conv_matches_dense_torch (fp32, tolerance 1e-4).
  *
  * Also the CPU baseline timed by bench.py (kind "port").
  * Build: gcc -O3 -march=native -fopenmp -fPIC -shared.
