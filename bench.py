@@ -166,8 +166,7 @@ def main():
         out['device'] = {'name': name.value.decode(), 'cus': cu.value, 'clock_khz': clk.value}
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel: gather_conv_mfma (sparse-conv implicit GEMM).  Extra pass of the same
-        # steps with a HIP event pair around every launch, on the launch stream.
+        # dominant kernel: gather_conv_persistent_kernel (sparse-conv implicit GEMM)
         # (a) algorithmic bytes / flops per launch: one forward on the module path, which makes one
         #     Python call per conv launch (same kernels as the native executor of the timed region);
         # (b) kernel time: the library brackets every conv launch with a HIP event pair on its launch
