@@ -26,6 +26,20 @@ def _stale(out, srcs):
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(out) for s in srcs)
 
 
+def _cpu_tag():
+    """identifies the host CPU's instruction set: the conv oracle is built with -march=native, and
+    the built library travels from the build container to the GPU box"""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('flags'):
+                    import hashlib
+                    return hashlib.sha1(' '.join(sorted(line.split(':', 1)[1].split())).encode()).hexdigest()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def build(force=False):
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(HERE, 'sg_oracle.c')
@@ -33,9 +47,14 @@ def build(force=False):
         subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-std=c11',
                                src, '-o', _SO, '-lm'])
     src = os.path.join(HERE, 'sg_oracle_conv.c')
-    if os.path.exists(src) and (force or _stale(_SO_CONV, [src])):
+    stamp = _SO_CONV + '.cpu'
+    tag = _cpu_tag()
+    built_for = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if os.path.exists(src) and (force or _stale(_SO_CONV, [src]) or built_for != tag):
         subprocess.check_call(['gcc', '-O3', '-march=native', '-fopenmp', '-fPIC', '-shared',
                                '-std=c11', src, '-o', _SO_CONV, '-lm'])
+        with open(stamp, 'w') as f:
+            f.write(tag)
     return _SO, _SO_CONV
 
 
