@@ -228,13 +228,15 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle  # checker only: CPU restatement of the reference model
-        from oracle.model import OracleSoftGroup
+        from oracle import parity
         oracle.build()
         cpu_batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
-        ora = OracleSoftGroup(model.state_dict(), synthetic.SCANNET_MODEL_CFG)
-        t0 = time.perf_counter()
-        ora.forward_test(cpu_batch)
-        cpu_s = time.perf_counter() - t0
+        # one oracle forward of the SAME scene: timed as the CPU baseline, and its outputs are the
+        # full-size parity check of the GPU path (stage-wise: floats <= 1e-4, proposals / instance
+        # labels / RLE strings identical; end to end: instance drift)
+        rep = parity.parity_report(model, cpu_batch, synthetic.SCANNET_MODEL_CFG)
+        cpu_s = rep.pop('oracle_forward_s')
+        out['parity_at_bench'] = rep
         out['cpu_baseline'] = {
             'value': round(1.0 / cpu_s, 4), 'unit': 'scans/s', 'cores': os.cpu_count(),
             'kind': 'port',

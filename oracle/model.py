@@ -325,8 +325,8 @@ class OracleSoftGroup:
             batch_idxs = _np(batch['voxel_coords'])[:, 0].astype(np.int32)
             coords_float = O.voxelization(coords_float, _np(batch['p2v_map']))
         pidx, poff = self.grouping(sem, off, batch_idxs, coords_float, lvl_fusion)
-        ret = dict(semantic_scores=sem, pt_offsets=off, proposals_idx=pidx, proposals_offset=poff,
-                   pred_instances=[])
+        ret = dict(semantic_scores=sem, pt_offsets=off, output_feats=feats, proposals_idx=pidx,
+                   proposals_offset=poff, pred_instances=[])
         if pidx.shape[0] == 0:
             return ret
         inst, inst_map = self.clusters_voxelization(pidx, poff, feats, coords_float)

@@ -33,3 +33,18 @@ def test_version_and_error_text():
     # bad argument -> negative status + readable message, no crash
     rc = lib.sg_voxelize_idx_host(None, -1, 4, 4, None, None, None)
     assert rc < 0 and b'sg_voxelize_idx_host' in lib.sg_last_error()
+
+
+def test_reference_gpu_oracle_library_exports_its_entry_points():
+    """oracle/_ref/sg_ref_gpu_ops.so (the reference's CUDA kernels built with hipcc, test-only):
+    loads without a GPU and exports every sgref_* entry point oracle/ref_gpu.py calls."""
+    import pytest
+    from oracle import ref_gpu
+    if not ref_gpu.available():
+        pytest.skip('oracle/_ref/sg_ref_gpu_ops.so not built (/root/reference absent at build time)')
+    raw = ctypes.CDLL(ref_gpu.SO)
+    src = open(os.path.join(ROOT, 'oracle', 'ref_gpu.py')).read()
+    used = set(re.findall(r"\b(sgref_[a-z_]+)", src))
+    assert len(used) >= 14
+    missing = [s for s in sorted(used) if not hasattr(raw, s)]
+    assert not missing, missing
