@@ -27,7 +27,11 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 def build_gpu(force=False):
     """hipcc build of the reference's CUDA kernels (cross-compiles without a GPU).  Default
     floating-point contraction (hipcc's -ffp-contract=fast-honor-pragmas is the analogue of nvcc's
-    default -fmad=true the reference is built with, setup.py:17-23)."""
+    default -fmad=true the reference is built with, setup.py:15-23).  -fno-slp-vectorize keeps the
+    contraction the one of LLVM's generic DAG combiner, which nvcc's NVVM back end shares
+    (mul dy,dy; fma dx,dx; fma dz,dz for the d2 of the ball queries); with SLP on, hipcc packs
+    dx*dx and dz*dz into one v_pk_mul_f32 first and a different product gets rounded -- an
+    AMDGPU-only artefact that no CUDA build of the reference can have."""
     if not os.path.isdir(REF_SRC):
         return OUT_GPU if os.path.exists(OUT_GPU) else None
     src = os.path.join(HERE, 'ref_gpu_tu.hip')
@@ -37,7 +41,7 @@ def build_gpu(force=False):
             and all(os.path.getmtime(OUT_GPU) > os.path.getmtime(d) for d in deps)):
         return OUT_GPU
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [HIPCC, '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-w',
+    cmd = [HIPCC, '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-w', '-fno-slp-vectorize',
            f'-I{shim}', f'-I{REF_SRC}', src, '-o', OUT_GPU]
     subprocess.check_call(cmd)
     return OUT_GPU

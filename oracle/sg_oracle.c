@@ -145,12 +145,18 @@ void orc_voxelize_bp(const float *d_out, float *d_feats, const int32_t *rules, i
 /* ------------------------------------------------------------------------- */
 /* ballquery_batch_p  (bfs_cluster/bfs_cluster.cu:15-66)                       */
 /* ------------------------------------------------------------------------- */
-/* d2 uses the contraction nvcc's default -fmad=true applies to                 */
-/* (dx*dx + dy*dy) + dz*dz : fma(dz,dz, fma(dy,dy, dx*dx))  (SURVEY App. B-3);  */
-/* the HIP kernel writes the same three operations explicitly.                  */
+/* d2 = (dx*dx + dy*dy) + dz*dz under the reference build's default floating-point      */
+/* contraction (nvcc -fmad=true, setup.py:15-23).  The fusion is done by LLVM's generic   */
+/* DAG combiner, which NVVM (nvcc) and AMDGPU share: in fadd(fmul, fmul) the LEFT product  */
+/* is fused and the right one rounded, i.e.  mul t = dy*dy; fma t = dx*dx + t;             */
+/* fma d2 = dz*dz + t.  This is what the reference's own kernel compiles to here           */
+/* (oracle/build_ref.py, SLP vectorisation off: v_mul dy,dy / v_fmac dx,dx / v_fmac dz,dz) */
+/* and tests/test_ref_gpu_kernels.py pins it on pairs within 1 ulp of the radius.          */
+/* (Round 1 assumed fma(dz,dz,fma(dy,dy,dx*dx)), SURVEY App. B-3: refuted by that test.)   */
+/* The HIP kernel writes the same three operations explicitly.                             */
 static inline float dist2_fma(float ox, float oy, float oz, float x, float y, float z) {
   float dx = ox - x, dy = oy - y, dz = oz - z;
-  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
 }
 
 /* start offsets follow ascending point order (one of the atomic orders the    */
@@ -333,7 +339,7 @@ static inline int is_intersection(const float *box, const float *pt, float r) {
   if (dist_y <= (h / 2)) return 1;
   if (dist_z <= (l / 2)) return 1;
   float dx = dist_x - w / 2, dy = dist_y - h / 2, dz = dist_z - l / 2;
-  return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= r * r; /* same contraction note as dist2_fma */
+  return fmaf(dz, dz, fmaf(dx, dx, dy * dy)) <= r * r; /* same contraction note as dist2_fma */
 }
 
 int64_t orc_octree_ball_query(const float *points, const float *boxes, const int32_t *pt_inds,

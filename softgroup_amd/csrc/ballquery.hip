@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256) bq_scatter_kernel(const float *__restrict
 
 __device__ __forceinline__ float dist2(float ox, float oy, float oz, float x, float y, float z) {
   const float dx = __fsub_rn(ox, x), dy = __fsub_rn(oy, y), dz = __fsub_rn(oz, z);
-  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  // contraction of the reference build (LLVM DAG combiner shared by NVVM and AMDGPU: the left
+  // product of dx*dx + dy*dy is fused, the right one rounded), pinned by tests/test_ref_gpu_kernels.py
+  return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
 }
 
 // number of accepted candidates with id < limit (limit = INT_MAX counts all)

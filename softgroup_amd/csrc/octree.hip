@@ -28,7 +28,7 @@ __device__ __forceinline__ bool box_hit(const float *__restrict__ b, float cx, f
   if (dist_y <= hh) return true;
   if (dist_z <= hl) return true;
   const float dx = __fsub_rn(dist_x, hw), dy = __fsub_rn(dist_y, hh), dz = __fsub_rn(dist_z, hl);
-  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))) <= __fmul_rn(r, r);
+  return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy))) <= __fmul_rn(r, r);
 }
 
 template <bool FILL>
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) octree_query_kernel(const float *__restri
             p = pt_inds[st + j];
             const float dx = __fsub_rn(cx, points[3 * p]), dy = __fsub_rn(cy, points[3 * p + 1]),
                         dz = __fsub_rn(cz, points[3 * p + 2]);
-            ok = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx))) < r2;
+            ok = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy))) < r2;
           }
           const uint64_t bal = __ballot(ok);
           if (FILL) {

@@ -881,28 +881,43 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // XCD u % 8)
     const size_t lds = (static_cast<size_t>(kWavesPerWg) * 16 * 64 + 16 * 64) * sizeof(float) +
                        2 * kMetaInts * sizeof(int32_t);
-    static int num_cu = 0, occ = 0;
+    static int num_cu = 0;
     if (num_cu == 0) {
       int dev = 0;
       hipGetDevice(&dev);
       hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (num_cu <= 0) num_cu = 256;
     }
-    // 16-channel slices, 2-deep operand ring: measured best on gfx950 against 32-channel slices
-    // (whole 128-B lines per gather) and 3- / 4-deep rings at every occupancy, also on the
-    // single-round (latency-bound) layers (profiles/README.md)
-    constexpr int kSliceCh = 16, kRing = 2;
+    // 16-channel slices.  Operand ring: 2 deep on the big layers (several rounds of units per
+    // workgroup, 4-5 workgroups per CU hide the load latency; deeper rings measured slower there,
+    // profiles/README.md); `ring_small` deep on layers that run as a single round of units, where a
+    // wave's time is the chain of its dependent memory round trips, not the matrix pipe.
+    constexpr int kSliceCh = 16;
+    static const int ring_small_env = getenv("SG_CONV_RING_SMALL") ? atoi(getenv("SG_CONV_RING_SMALL")) : 2;   // developer knob
+    static int occ_tab[3] = {0, 0, 0};     // resident workgroups per CU for ring depth 2, 4, 8
+    auto occupancy = [&](int which) {
+      if (occ_tab[which] == 0) {
+        int o = 0;
+        if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0>, 256, lds);
+        else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0>, 256, lds);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0>, 256, lds);
+        if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
+        occ_tab[which] = o < 1 ? 1 : o;
+      }
+      return occ_tab[which];
+    };
+    int which = 0;
+    if (units <= static_cast<long long>(num_cu) * occupancy(0))      // single round of units
+      which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : 0;
+    const int occ = occupancy(which);
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (trace) gather_conv_persistent_kernel<kSliceCh, kRing, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else gather_conv_persistent_kernel<kSliceCh, kRing, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 1) gather_conv_persistent_kernel<kSliceCh, 4, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else gather_conv_persistent_kernel<kSliceCh, 2, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
     };
     a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
-    if (occ == 0) {
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_conv_persistent_kernel<kSliceCh, kRing, 0>, 256, lds);
-      if (const char *e = getenv("SG_CONV_OCC")) occ = atoi(e) > 0 && atoi(e) < occ ? atoi(e) : occ;   // developer knob
-      if (occ < 1) occ = 1;
-    }
     long long g = static_cast<long long>(num_cu) * occ;
     if (g > units) g = units;
     if (g >= 8) g -= g % 8;
