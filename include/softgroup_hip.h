@@ -212,6 +212,13 @@ size_t sg_spconv_hash_workspace_bytes(int num_rows);
 /* builds the coordinate hash in ws, then fills nbr[M,27] */
 int sg_spconv_subm_rulebook(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
                             int32_t *nbr, void *ws, size_t ws_bytes, sg_stream_t stream);
+/* Row counts of every level of an n_levels-deep U-Net (level l+1 = strided k2 s2 of level l, same
+ * drop rule) from the finest coordinates alone: counts[0..n_levels) on the device (counts[0] is
+ * left 0: it is num_rows).  Lets a caller size all levels with ONE read-back instead of one per
+ * down-sampling (spconv sizes each strided conv's output by a device->host copy of its own). */
+size_t sg_spconv_level_rows_workspace_bytes(int num_rows, int n_levels);
+int sg_spconv_level_rows(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
+                         int n_levels, int32_t *counts, void *ws, size_t ws_bytes, sg_stream_t stream);
 /* pass 1: in2out[M] (-1 = dropped), meta[0] = M_out.  pass 2: out_indices[M_out,4], child[M_out,8] */
 int sg_spconv_down_build(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
                          int32_t *in2out, int32_t *meta, void *ws, size_t ws_bytes,
@@ -317,7 +324,8 @@ typedef struct sg_unet_desc {
 /* upper bound of the arena sg_unet_forward needs for num_rows input voxels */
 size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);
 /* feats [num_rows, input_cin or planes[0]], indices int32 [num_rows,4], out [num_rows, planes[0]].
- * Synchronises the stream once per down-sampling level (coarse voxel count). */
+ * One host synchronisation per call (the row counts of all levels, read back from an internal
+ * stream right at the start). */
 int sg_unet_forward(const sg_unet_desc *desc, const float *feats, const int32_t *indices,
                     int num_rows, const int32_t *spatial_shape_host, float *out, void *arena,
                     size_t arena_bytes, sg_stream_t stream);

@@ -159,6 +159,45 @@ __global__ void __launch_bounds__(256) inverse_rulebook_kernel(const int32_t *__
   }
 }
 
+// ---- active sites of EVERY level of a U-Net from the finest level's coordinates alone: level l+1
+// holds the distinct (c >> 1) of level l that fall inside shape_l / 2 (same drop rule as
+// down_insert_kernel), so one pass over the finest voxels with one small key-only hash table per
+// coarser level gives all the row counts at once.  The executor reads them back with a single
+// host sync and can then size and enqueue the whole U-Net without waiting for the GPU again.
+__global__ void __launch_bounds__(256) pyramid_count_kernel(const int32_t *__restrict__ indices, int M,
+                                                           Shape3 shape, int n_levels,
+                                                           uint64_t *__restrict__ keys, uint32_t cap,
+                                                           int32_t *__restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool alive = i < M;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (alive) c = reinterpret_cast<const int4 *>(indices)[i];
+  Shape3 s = shape;
+  const uint32_t mask = cap - 1;
+  for (int l = 1; l < n_levels; ++l) {
+    const Shape3 os{s.s0 / 2, s.s1 / 2, s.s2 / 2};
+    c.y >>= 1; c.z >>= 1; c.w >>= 1;
+    alive = alive && c.y < os.s0 && c.z < os.s1 && c.w < os.s2;
+    bool fresh = false;
+    if (alive) {
+      const uint64_t key = lin_key(c.x, c.y, c.z, c.w, os);
+      uint64_t *tab = keys + static_cast<size_t>(l - 1) * cap;
+      uint32_t slot = static_cast<uint32_t>(mix64(key)) & mask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
+                                                  static_cast<unsigned long long>(kKeyEmpty),
+                                                  static_cast<unsigned long long>(key));
+        if (prev == kKeyEmpty) { fresh = true; break; }
+        if (prev == key) break;
+        slot = (slot + 1) & mask;
+      }
+    }
+    const uint64_t b = __ballot(fresh);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[l], __popcll(b));
+    s = os;
+  }
+}
+
 // ---- tile plan
 // Rows are sorted by their neighbour mask so that the 32 rows of a tile share as many kernel
 // offsets as possible.  The sort key is the mask with its bits PERMUTED by how common each offset
@@ -373,6 +412,29 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
   inverse_rulebook_kernel<<<grid_for(static_cast<int64_t>(M) * 8, 256, 256 * 32), 256, 0,
                             as_stream(stream)>>>(indices_fine, in2out, M, inv_nbr);
   return check_launch("sg_spconv_inverse_rulebook");
+}
+
+size_t sg_spconv_level_rows_workspace_bytes(int M, int n_levels) {
+  return static_cast<size_t>(n_levels > 1 ? n_levels - 1 : 0) * align_up(hash_cap(M) * 8) + 256;
+}
+
+int sg_spconv_level_rows(const int32_t *indices, int M, const int32_t *shape_host, int n_levels,
+                         int32_t *counts, void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(M >= 0 && shape_host && n_levels >= 1 && n_levels <= 16 && counts,
+             "sg_spconv_level_rows: bad arguments");
+  hipStream_t stream = as_stream(stream_);
+  hipMemsetAsync(counts, 0, static_cast<size_t>(n_levels) * 4, stream);
+  if (M == 0 || n_levels == 1) return check_launch("sg_spconv_level_rows");
+  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_spconv_level_rows_workspace_bytes(M, n_levels),
+             "sg_spconv_level_rows: workspace too small");
+  const size_t cap = hash_cap(M);
+  SG_REQUIRE(align_up(cap * 8) == cap * 8, "sg_spconv_level_rows: internal table alignment");
+  hipMemsetAsync(ws, 0xff, static_cast<size_t>(n_levels - 1) * cap * 8, stream);
+  const Shape3 shape{shape_host[0], shape_host[1], shape_host[2]};
+  pyramid_count_kernel<<<(M + 255) / 256, 256, 0, stream>>>(indices, M, shape, n_levels,
+                                                           static_cast<uint64_t *>(ws),
+                                                           static_cast<uint32_t>(cap), counts);
+  return check_launch("sg_spconv_level_rows");
 }
 
 size_t sg_spconv_plan_workspace_bytes(int M) {

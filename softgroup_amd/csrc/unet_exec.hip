@@ -6,11 +6,15 @@
 // The Python module path (softgroup_amd/spconv + model/blocks.py) launches the same kernels in
 // the same order; it stays the path for training.  Here nothing but kernel launches happens
 // between two layers: no interpreter, no allocator calls (a caller-provided arena, stack
-// discipline per level), one host sync per down-sampling (the number of coarse voxels).
-// Two streams: everything that depends only on voxel coordinates (rulebooks, plans -- and the host
-// syncs they need) runs on an internal index stream and races ahead of the convolutions on the
-// caller's stream, which wait per level on an event; index tables are never recycled inside a
-// forward, so the only cross-stream hazards are the read-after-write ones the events cover.
+// discipline per level) and ONE host sync per forward: the row counts of all levels come from one
+// pass over the finest coordinates (sg_spconv_level_rows) and are read back right at the start.
+// Two streams: everything that depends only on voxel coordinates (rulebooks, plans) runs on an
+// internal index stream and races ahead of the convolutions on the caller's stream, which wait
+// per level on an event; index tables are never recycled inside a forward, so the only
+// cross-stream hazards are the read-after-write ones the events cover.
+// Runtime state (index stream, events, pinned read-back words) is kept per device; calls on one
+// device are serialised by a mutex (one forward owns the device's index stream at a time).
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -89,14 +93,14 @@ struct Exec {
   Arena ix;             // index tables and their scratch: index stream only (bump, no recycling)
   sg_stream_t stream;   // caller's stream (convolutions, elementwise)
   sg_stream_t istream;  // index stream
-  int32_t *host_meta;   // pinned, 2 ints
+  const int32_t *level_rows;   // host: rows of every level (known before anything is enqueued)
   hipEvent_t *events;
   int n_events, next_event;
 
   Exec(const sg_unet_desc *desc, void *arena, size_t bytes, size_t index_bytes, sg_stream_t s,
        sg_stream_t is)
       : d(desc), ar(static_cast<char *>(arena) + index_bytes, bytes - index_bytes),
-        ix(arena, index_bytes), stream(s), istream(is), host_meta(nullptr), events(nullptr),
+        ix(arena, index_bytes), stream(s), istream(is), level_rows(nullptr), events(nullptr),
         n_events(0), next_event(0) {}
 
   // the caller's stream may not run past this point before the index stream got here
@@ -245,23 +249,14 @@ struct Exec {
     }
     if (deeper) {
       const int c2 = d->levels[l + 1].planes;
-      // ---- index stream: strided-conv pairs (the number of coarse voxels comes back to the host;
-      //      only the index stream is waited for, the convolutions above keep running), their
-      //      plan, and the inverse table + plan the way back up will need
+      // ---- index stream: strided-conv pairs (the number of coarse voxels is already known on the
+      //      host: level_rows), their plan, and the inverse table + plan the way back up will need
       SG_IALLOC(in2out, int32_t, rows ? rows : 1);
       SG_IALLOC(meta, int32_t, 64);
       const size_t nbh = sg_spconv_hash_workspace_bytes(rows);
       SG_IALLOC(hws, char, nbh);          // coordinate hash: built by down_build, read by down_fill
-      int rows2 = 0;
-      if (rows) {
-        SG_TRY(sg_spconv_down_build(indices, rows, shape, in2out, meta, hws, nbh, istream));
-        if (hipMemcpyAsync(host_meta, meta, sizeof(int32_t), hipMemcpyDeviceToHost, as_stream(istream)) != hipSuccess ||
-            hipStreamSynchronize(as_stream(istream)) != hipSuccess) {
-          set_error("sg_unet_forward: reading the coarse voxel count failed");
-          return SG_ERR_LAUNCH;
-        }
-        rows2 = host_meta[0];
-      }
+      const int rows2 = rows ? level_rows[l + 1] : 0;
+      if (rows) SG_TRY(sg_spconv_down_build(indices, rows, shape, in2out, meta, hws, nbh, istream));
       SG_IALLOC(idx2, int32_t, static_cast<size_t>(rows2 ? rows2 : 1) * 4);
       SG_IALLOC(child, int32_t, static_cast<size_t>(rows2 ? rows2 : 1) * 8);
       if (rows) SG_TRY(sg_spconv_down_fill(indices, rows, in2out, rows2, idx2, child, hws, nbh, istream));
@@ -339,7 +334,8 @@ static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
   size_t total = 1 << 20;
   for (int l = 0; l < d->n_levels; ++l)
     total += rows * (2 * 43 + 16) * 4 + 2 * sg_spconv_hash_workspace_bytes(num_rows) + (256 << 10);
-  return align_up(total + sg_spconv_plan_workspace_bytes(num_rows), 4096);
+  return align_up(total + sg_spconv_plan_workspace_bytes(num_rows) +
+                  sg_spconv_level_rows_workspace_bytes(num_rows, d->n_levels), 4096);
 }
 
 size_t sg_unet_arena_bytes(const sg_unet_desc *d, int num_rows) {
@@ -363,21 +359,38 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   const size_t index_bytes = unet_index_bytes(d, num_rows);
   SG_REQUIRE(arena != nullptr && arena_bytes > index_bytes,
              "sg_unet_forward: arena of %zu bytes, need sg_unet_arena_bytes()", arena_bytes);
-  constexpr int kEvents = 64;
-  static int32_t *host_meta = nullptr;
-  static hipStream_t istream = nullptr;
-  static hipEvent_t events[kEvents];
-  if (host_meta == nullptr) {
-    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&host_meta), 64) == hipSuccess,
+  // ---- per-device runtime state
+  constexpr int kEvents = 64, kMaxDev = 64, kMaxLevels = 16;
+  struct DeviceState {
+    std::mutex mu;
+    int32_t *host_rows = nullptr;     // pinned [kMaxLevels]
+    int32_t *dev_rows = nullptr;      // device [kMaxLevels]
+    hipStream_t istream = nullptr;
+    hipEvent_t events[kEvents];
+    bool ready = false;
+  };
+  static DeviceState states[kMaxDev];
+  SG_REQUIRE(d->n_levels <= kMaxLevels, "sg_unet_forward: at most %d levels", kMaxLevels);
+  int dev = 0;
+  SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev,
+             "sg_unet_forward: no current device");
+  DeviceState &st = states[dev];
+  std::lock_guard<std::mutex> guard(st.mu);
+  if (!st.ready) {
+    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), kMaxLevels * 4) == hipSuccess,
                "sg_unet_forward: pinned allocation failed");
-    SG_REQUIRE(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking) == hipSuccess,
+    SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), kMaxLevels * 4) == hipSuccess,
+               "sg_unet_forward: device allocation failed");
+    SG_REQUIRE(hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
                "sg_unet_forward: stream creation failed");
     for (int i = 0; i < kEvents; ++i)
-      SG_REQUIRE(hipEventCreateWithFlags(&events[i], hipEventDisableTiming) == hipSuccess,
+      SG_REQUIRE(hipEventCreateWithFlags(&st.events[i], hipEventDisableTiming) == hipSuccess,
                  "sg_unet_forward: event creation failed");
+    st.ready = true;
   }
+  hipStream_t istream = st.istream;
+  hipEvent_t *events = st.events;
   Exec ex(d, arena, arena_bytes, index_bytes, stream, reinterpret_cast<sg_stream_t>(istream));
-  ex.host_meta = host_meta;
   ex.events = events;
   ex.n_events = kEvents;
   // the index stream starts where the caller's stream is now: the coordinates are ready, and the
@@ -388,6 +401,27 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     return SG_ERR_LAUNCH;
   }
   ex.next_event = 1;
+  // ---- rows of every level, one read-back (the only host sync of the forward; it waits for the
+  //      index stream only -- whatever the caller's stream still has queued keeps running)
+  int32_t level_rows[kMaxLevels];
+  level_rows[0] = num_rows;
+  if (d->n_levels > 1) {
+    const size_t m = ex.ix.mark();
+    const size_t nb = sg_spconv_level_rows_workspace_bytes(num_rows, d->n_levels);
+    char *ws = ex.ix.take<char>(nb);
+    SG_REQUIRE(ws != nullptr, "sg_unet_forward: index arena too small (%zu bytes)", ex.ix.cap);
+    SG_TRY(sg_spconv_level_rows(indices, num_rows, spatial_shape_host, d->n_levels, st.dev_rows, ws, nb,
+                                reinterpret_cast<sg_stream_t>(istream)));
+    if (hipMemcpyAsync(st.host_rows, st.dev_rows, sizeof(int32_t) * d->n_levels, hipMemcpyDeviceToHost,
+                       istream) != hipSuccess ||
+        hipStreamSynchronize(istream) != hipSuccess) {
+      set_error("sg_unet_forward: reading the level row counts failed");
+      return SG_ERR_LAUNCH;
+    }
+    for (int l = 1; l < d->n_levels; ++l) level_rows[l] = st.host_rows[l];
+    ex.ix.release(m);
+  }
+  ex.level_rows = level_rows;
   const bool pre = d->input_w != nullptr;
   return ex.level(0, pre ? nullptr : feats, nullptr, indices, num_rows, spatial_shape_host,
                   pre ? feats : nullptr, d->input_cin, d->out_bn_scale, d->out_bn_shift, out);

@@ -92,6 +92,29 @@ def test_down_rulebook_exact_incl_odd_extent_drop():
     assert np.array_equal(inv, exp)
 
 
+def test_level_rows_of_all_levels_in_one_pass():
+    """sg_spconv_level_rows: the row count of every U-Net level from the finest coordinates alone
+    (what lets sg_unet_forward run with a single host sync) == the chain of strided rulebooks of
+    the oracle, including the odd-extent drops at every level."""
+    from softgroup_amd import _lib as L
+    rng = np.random.default_rng(4)
+    for shape, n, B in (([129, 67, 35], 40000, 3), ([300, 250, 135], 120000, 1), ([20, 20, 20], 3000, 7),
+                        ([5, 3, 2], 30, 1)):
+        idx = _scene(rng, n, shape, B=B)
+        n_levels = 7
+        exp, cur, sh = [len(idx)], idx, list(shape)
+        for _ in range(n_levels - 1):
+            if len(cur):
+                cur, _, _, sh = oracle.down_rulebook(cur, sh)
+            exp.append(len(cur))
+        counts = torch.full((n_levels, ), -7, dtype=torch.int32, device=DEV)
+        ws = L.workspace(L.lib().sg_spconv_level_rows_workspace_bytes(len(idx), n_levels), DEV)
+        shp = (L.C.c_int32 * 3)(*shape)
+        L.check(L.lib().sg_spconv_level_rows(L.ptr(t(idx)), len(idx), shp, n_levels, L.ptr(counts),
+                                             L.ptr(ws), ws.numel(), L.stream()), 'sg_spconv_level_rows')
+        assert counts.tolist()[1:] == exp[1:], (shape, counts.tolist(), exp)
+
+
 @pytest.mark.parametrize('cin,cout', [(6, 32), (32, 32), (64, 32), (64, 64), (96, 224), (32, 16), (3, 48)])
 def test_subm_conv_vs_oracle(cin, cout):
     rng = np.random.default_rng(cin * 1000 + cout)
