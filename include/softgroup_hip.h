@@ -342,6 +342,30 @@ int sg_gather_rows_i64idx_f32(const float *in, const int64_t *index, int64_t num
                               int channels, float *out, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Instance extraction for the inference result (SoftGroup.get_instances, softgroup.py:537-604),
+ * all instance classes at once, without the reference's dense int32 [nProposal, N] mask per class.
+ *   proposals_idx int32 [S,2] = (proposal, point), mask_scores f32 [S, stride] (stride >= n_classes)
+ *   sg_instance_npoint: npoint[p*n_classes + i] = #{pairs of proposal p with mask_scores[e,i] >
+ *       mask_thr}  (softgroup.py:569-570,584: the row sums of the dense mask)
+ *   sg_instance_runs: inst_of[i*n_prop + p] = output index of the kept (class i, proposal p)
+ *       instance or -1 (the caller applies cls_score_thr / min_npoint, softgroup.py:573-588, and
+ *       numbers the survivors in the reference's order: class-major, proposal-ascending).
+ *       Produces the runs of consecutive points of every kept instance's mask in ascending point
+ *       order: runs of instance k = [bounds[k], bounds[k+1]) of starts[] / ends[] (0-based,
+ *       end exclusive) -- the input of sg_rle_format_host (lens = ends - starts).  Runs past
+ *       runs_capacity are dropped (bounds still count them: check bounds[n_kept] <= capacity;
+ *       sum of the kept instances' npoint is always enough).
+ * ---------------------------------------------------------------------------------------- */
+int sg_instance_npoint(const int32_t *proposals_idx, const float *mask_scores, int64_t num_pairs,
+                       int stride, int n_classes, float mask_thr, int n_prop, int32_t *npoint,
+                       sg_stream_t stream);
+size_t sg_instance_runs_workspace_bytes(int n_kept, int n_points);
+int sg_instance_runs(const int32_t *proposals_idx, const float *mask_scores, int64_t num_pairs,
+                     int stride, int n_classes, float mask_thr, const int32_t *inst_of, int n_prop,
+                     int n_kept, int n_points, int32_t *starts, int32_t *ends, int64_t *bounds,
+                     int64_t runs_capacity, void *ws, size_t ws_bytes, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Instance-mask run-length strings in the reference's wire format (softgroup/util/rle.py:5-19,
  * called per instance from softgroup.py:595-603): "start len start len ..." with 1-based starts.
  * runs of instance g = [bounds[g], bounds[g+1]) of (starts, lens), all host int64.

@@ -65,6 +65,9 @@ SIGNATURES = {
     'sg_spconv_gather_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_wgrad_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'sg_instance_npoint': (_i, [_vp, _vp, _i64, _i, _i, _f, _i, _vp, _vp]),
+    'sg_instance_runs_workspace_bytes': (_sz, [_i, _i]),
+    'sg_instance_runs': (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     'sg_rle_format_bound': (_i64, [_i64, _i]),
     'sg_rle_format_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),

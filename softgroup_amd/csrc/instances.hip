@@ -1,0 +1,181 @@
+// instances.hip -- instance extraction for the inference result (the step right after the hot
+// path).  Replaces the dense-mask part of SoftGroup.get_instances
+// (softgroup/model/softgroup.py:537-604): for every instance class i and proposal p the reference
+// builds an int32 [nProposal, N] matrix, sets mask[p, point] = 1 where mask_scores[:, i] > thr,
+// filters proposals (cls score, >= min_npoint points), copies the matrix to the host and
+// run-length encodes each row in Python (util/rle.py:5-19).
+//
+// Here, for ALL classes at once:
+//   sg_instance_npoint   npoint[p, i] = #{pairs of proposal p with mask_scores[e, i] > thr}
+//                        (pairs arrive grouped by proposal: one atomic per (wave, proposal, class))
+//   -- host: keep[p, i] = cls_prob > cls_thr && npoint >= min_npoint, kept (class, proposal) pairs
+//      numbered class-major (the reference's output order), tiny [nP, nc] work --
+//   sg_instance_runs     one N-bit row per KEPT instance only (32x18 less memory than the
+//                        reference's per-class int32 matrices), set by atomicOr; run starts / ends
+//                        are the 0->1 / 1->0 transitions of the bit rows, numbered by one
+//                        device-wide scan of the per-word start counts; since every run is closed
+//                        inside its own row, the r-th start and the r-th end of the scan order
+//                        belong together.  Output: starts[], ends[] (exclusive), bounds[k] = first
+//                        run of instance k -- exactly what sg_rle_format_host turns into the
+//                        reference's "start len start len ..." strings.
+// HBM-bound streaming work: S*nc score reads + n_kept*N/8 bitmap bytes (written once, read 3x).
+#include "common.h"
+#include "scan.h"
+
+namespace sg {
+
+// grid = (pair chunks, classes); pairs of one proposal are consecutive, so a wave's lanes form a
+// few runs of equal proposal id: the head lane of each run adds the run's popcount
+__global__ void __launch_bounds__(256) instance_npoint_kernel(const int32_t *__restrict__ pairs,
+                                                             const float *__restrict__ mask_scores,
+                                                             int64_t S, int stride, float thr, int nc,
+                                                             int32_t *__restrict__ npoint) {
+  const int i = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  for (int64_t e0 = (blockIdx.x * 256LL + threadIdx.x) - lane; e0 < S; e0 += gridDim.x * 256LL) {
+    const int64_t e = e0 + lane;
+    const bool valid = e < S;
+    const int p = valid ? pairs[2 * e] : -1;
+    const bool on = valid && mask_scores[e * stride + i] > thr;
+    const int p_prev = __shfl_up(p, 1, 64);
+    const bool head = valid && (lane == 0 || p != p_prev);
+    const uint64_t heads = __ballot(head), ons = __ballot(on);
+    if (head) {
+      const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+      const int end = above ? __ffsll(static_cast<long long>(above)) - 1 : 64;
+      const uint64_t span = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+      const int cnt = __popcll(ons & span);
+      if (cnt) atomicAdd(&npoint[static_cast<int64_t>(p) * nc + i], cnt);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) instance_bitmap_kernel(const int32_t *__restrict__ pairs,
+                                                             const float *__restrict__ mask_scores,
+                                                             int64_t S, int stride, float thr, int nc,
+                                                             const int32_t *__restrict__ inst_of,
+                                                             int n_prop, int words,
+                                                             uint32_t *__restrict__ bits) {
+  const int i = blockIdx.y;
+  for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < S; e += gridDim.x * 256LL) {
+    if (!(mask_scores[e * stride + i] > thr)) continue;
+    const int2 pq = reinterpret_cast<const int2 *>(pairs)[e];
+    const int k = inst_of[static_cast<int64_t>(i) * n_prop + pq.x];
+    if (k < 0) continue;
+    atomicOr(&bits[static_cast<int64_t>(k) * words + (pq.y >> 5)], 1u << (pq.y & 31));
+  }
+}
+
+__device__ __forceinline__ uint32_t run_starts(const uint32_t *__restrict__ bits, int64_t t, int j) {
+  const uint32_t w = bits[t];
+  const uint32_t carry = j > 0 ? bits[t - 1] >> 31 : 0u;
+  return w & ~((w << 1) | carry);
+}
+
+__global__ void __launch_bounds__(256) instance_runs_emit_kernel(const uint32_t *__restrict__ bits,
+                                                                int64_t total_words, int words,
+                                                                const int32_t *__restrict__ base,
+                                                                int32_t *__restrict__ starts,
+                                                                int32_t *__restrict__ ends,
+                                                                int64_t *__restrict__ bounds,
+                                                                int64_t capacity) {
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total_words; t += gridDim.x * 256LL) {
+    const int j = static_cast<int>(t % words);
+    const uint32_t w = bits[t];
+    const uint32_t carry = j > 0 ? bits[t - 1] >> 31 : 0u;
+    const uint32_t next = j + 1 < words ? bits[t + 1] & 1u : 0u;
+    uint32_t sb = w & ~((w << 1) | carry);
+    uint32_t eb = w & ~((w >> 1) | (next << 31));
+    const int b0 = base[t];
+    if (j == 0) bounds[t / words] = b0;
+    int r = b0;
+    while (sb) {
+      const int b = __ffs(static_cast<int>(sb)) - 1;
+      sb &= sb - 1;
+      if (r < capacity) starts[r] = j * 32 + b;
+      ++r;
+    }
+    // a run that is open across the lower word boundary started earlier: its end is numbered one
+    // below this word's first start
+    r = b0 - static_cast<int>(carry & w & 1u);
+    while (eb) {
+      const int b = __ffs(static_cast<int>(eb)) - 1;
+      eb &= eb - 1;
+      if (r < capacity) ends[r] = j * 32 + b + 1;
+      ++r;
+    }
+  }
+}
+
+__global__ void instance_runs_total_kernel(const int32_t *__restrict__ total, int n_kept,
+                                           int64_t *__restrict__ bounds) {
+  bounds[n_kept] = *total;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+int sg_instance_npoint(const int32_t *proposals_idx, const float *mask_scores, int64_t S, int stride,
+                       int n_classes, float mask_thr, int n_prop, int32_t *npoint,
+                       sg_stream_t stream_) {
+  SG_REQUIRE(S >= 0 && stride >= n_classes && n_classes >= 1 && n_prop >= 0,
+             "sg_instance_npoint: bad arguments");
+  hipStream_t stream = as_stream(stream_);
+  hipMemsetAsync(npoint, 0, static_cast<size_t>(n_prop) * n_classes * 4, stream);
+  if (S == 0 || n_prop == 0) return check_launch("sg_instance_npoint");
+  dim3 grid(grid_for(S, 256, 1024), n_classes);
+  instance_npoint_kernel<<<grid, 256, 0, stream>>>(proposals_idx, mask_scores, S, stride, mask_thr,
+                                                  n_classes, npoint);
+  return check_launch("sg_instance_npoint");
+}
+
+static int64_t instance_words(int n_points) { return (static_cast<int64_t>(n_points) + 31) / 32; }
+
+size_t sg_instance_runs_workspace_bytes(int n_kept, int n_points) {
+  const int64_t tw = static_cast<int64_t>(n_kept > 0 ? n_kept : 1) * instance_words(n_points);
+  return align_up(tw * 4) * 2 + align_up(scan_workspace_bytes(tw)) + 512;
+}
+
+int sg_instance_runs(const int32_t *proposals_idx, const float *mask_scores, int64_t S, int stride,
+                     int n_classes, float mask_thr, const int32_t *inst_of, int n_prop, int n_kept,
+                     int n_points, int32_t *starts, int32_t *ends, int64_t *bounds,
+                     int64_t runs_capacity, void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(S >= 0 && stride >= n_classes && n_classes >= 1 && n_prop >= 0 && n_kept >= 0 &&
+                 n_points >= 0 && runs_capacity >= 0,
+             "sg_instance_runs: bad arguments");
+  hipStream_t stream = as_stream(stream_);
+  if (n_kept == 0) return SG_OK;
+  const int words = static_cast<int>(instance_words(n_points));
+  const int64_t tw = static_cast<int64_t>(n_kept) * words;
+  SG_REQUIRE(tw < (1LL << 31), "sg_instance_runs: %d instances x %d points exceed the bitmap limit",
+             n_kept, n_points);
+  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_instance_runs_workspace_bytes(n_kept, n_points),
+             "sg_instance_runs: workspace too small");
+  Workspace a(ws, ws_bytes);
+  uint32_t *bits = a.take<uint32_t>(tw);
+  int32_t *base = a.take<int32_t>(tw);
+  const size_t sbytes = scan_workspace_bytes(tw);
+  void *sws = a.take<char>(sbytes);
+  int32_t *total = a.take<int32_t>(64);
+  hipMemsetAsync(bits, 0, static_cast<size_t>(tw) * 4, stream);
+  if (S > 0 && n_prop > 0) {
+    dim3 grid(grid_for(S, 256, 1024), n_classes);
+    instance_bitmap_kernel<<<grid, 256, 0, stream>>>(proposals_idx, mask_scores, S, stride, mask_thr,
+                                                    n_classes, inst_of, n_prop, words, bits);
+  }
+  const uint32_t *cb = bits;
+  const int w = words;
+  int rc = exclusive_scan(
+      [cb, w] __device__(int64_t t) { return __popc(run_starts(cb, t, static_cast<int>(t % w))); },
+      [base] __device__(int64_t t, int v) { base[t] = v; }, tw, total, sws, sbytes, stream);
+  if (rc != SG_OK) return rc;
+  instance_runs_emit_kernel<<<grid_for(tw, 256, 4096), 256, 0, stream>>>(bits, tw, words, base, starts,
+                                                                        ends, bounds, runs_capacity);
+  instance_runs_total_kernel<<<1, 1, 0, stream>>>(total, n_kept, bounds);
+  return check_launch("sg_instance_runs");
+}
+
+}  // extern "C"

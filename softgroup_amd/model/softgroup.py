@@ -117,7 +117,35 @@ class SoftGroup(nn.Module):
                 nn.init.normal_(lin.weight, 0, 0.01)
                 nn.init.constant_(lin.bias, 0)
 
+    # ---- derived state (packed weights, BatchNorm affines, native-executor descriptors, the
+    #      results stream) is rebuilt on demand and never copied / pickled with the module
+    _DERIVED = ('_backbone_exec', '_tiny_exec', '_results_stream', '_grouping_const')
+
+    def invalidate_caches(self):
+        """Call after writing parameters/buffers through ``tensor.data`` (EMA copies, custom
+        initialisers): such writes do not bump the tensors' version counters, so the cached
+        packed weights / BatchNorm affines would otherwise go stale.  load_state_dict, .to(),
+        train()/eval() and optimizer steps are covered without it."""
+        spconv.invalidate_caches()
+        for k in self._DERIVED:
+            self.__dict__.pop(k, None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._DERIVED:
+            state.pop(k, None)
+        return state
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_caches()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_caches()
+        return super().load_state_dict(*args, **kwargs)
+
     def train(self, mode=True):
+        self.invalidate_caches()
         super().train(mode)
         for name in self.fixed_modules:      # frozen parts keep BN statistics frozen too
             for m in getattr(self, name).modules():
@@ -484,26 +512,45 @@ class SoftGroup(nn.Module):
         n_out = v2p_map.numel() if lvl_fusion else n_pts
         cls_prob = cls_scores.softmax(1)
         prop, pt = proposals_idx[:, 0].long().to(dev), proposals_idx[:, 1].long().to(dev)
-        if not lvl_fusion and not self.sem2ins_classes:
-            # all instance classes in one pass: one sort, two host round trips
+        if not lvl_fusion and not self.sem2ins_classes and cls_scores.is_cuda:
+            # all instance classes in one pass on the GPU (csrc/instances.hip): per-(proposal,
+            # class) point counts, then one bit row per KEPT instance -> runs; two small read-backs
+            from .. import _lib as L
+            lib = L.lib()
             nc = self.instance_classes
-            on = mask_scores[:, :nc] > _cfg(tcfg, 'mask_score_thr')                 # [S, nc]
-            npoint = torch.zeros((n_inst, nc), dtype=torch.int32, device=dev)
-            npoint.index_add_(0, prop, on.int())
+            S = proposals_idx.size(0)
+            pairs = proposals_idx.int().contiguous()
+            ms = mask_scores.contiguous()
+            mthr = float(_cfg(tcfg, 'mask_score_thr'))
+            npoint = torch.empty((n_inst, nc), dtype=torch.int32, device=dev)
+            L.check(lib.sg_instance_npoint(L.ptr(pairs), L.ptr(ms), S, ms.size(1), nc, mthr, n_inst,
+                                           L.ptr(npoint), L.stream()), 'sg_instance_npoint')
             keep = (cls_prob[:, :nc] > _cfg(tcfg, 'cls_score_thr')) & \
                 (npoint >= _cfg(tcfg, 'min_npoint'))                                # [n_inst, nc]
             kept = keep.t().nonzero()                       # (class, proposal), class-major order
             n_kept = kept.size(0)
             if n_kept == 0:
                 return []
-            idmap = torch.full((nc, n_inst), -1, dtype=torch.long, device=dev)
-            idmap[kept[:, 0], kept[:, 1]] = torch.arange(n_kept, device=dev)
-            e, c = (on & keep[prop]).nonzero(as_tuple=True)
-            starts, lens, bounds = _runs_of_pairs(idmap[c, prop[e]], pt[e], n_kept)
+            inst_of = torch.full((nc, n_inst), -1, dtype=torch.int32, device=dev)
+            inst_of[kept[:, 0], kept[:, 1]] = torch.arange(n_kept, dtype=torch.int32, device=dev)
+            cap = int((npoint * keep).sum().item())         # every kept point is at most one run
+            starts = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            ends = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            bounds = torch.empty(n_kept + 1, dtype=torch.int64, device=dev)
+            ws = L.workspace(lib.sg_instance_runs_workspace_bytes(n_kept, n_out), dev)
+            L.check(lib.sg_instance_runs(L.ptr(pairs), L.ptr(ms), S, ms.size(1), nc, mthr,
+                                         L.ptr(inst_of), n_inst, n_kept, n_out, L.ptr(starts),
+                                         L.ptr(ends), L.ptr(bounds), cap, L.ptr(ws), ws.numel(),
+                                         L.stream()), 'sg_instance_runs')
             score = (cls_prob[:, :nc] * iou_scores[:, :nc].clamp(0, 1))[kept[:, 1], kept[:, 0]]
             cls_pred = (kept[:, 0] + 1).cpu().numpy()
             score_pred = score.cpu().numpy()
-            masks = rle_encode_many(n_out, starts, lens, bounds)
+            b = bounds.cpu().numpy()
+            n_runs = int(b[-1])
+            assert n_runs <= cap, (n_runs, cap)
+            st = starts[:n_runs].cpu().numpy().astype(np.int64)
+            ln = ends[:n_runs].cpu().numpy().astype(np.int64) - st
+            masks = rle_encode_many(n_out, st, ln, b)
             return [dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
                          pred_mask=masks[k]) for k in range(n_kept)]
         sem_pred = semantic_scores.max(1)[1]

@@ -392,10 +392,12 @@ class GetMaskIoUOnCluster(Function):
         assert instance_pointnum.is_contiguous() and instance_pointnum.is_cuda
         proposals_iou = torch.zeros((nProposal, nInstance), dtype=torch.float32,
                                     device=proposals_idx.device)
+        # converted copies are named locals: they must stay alive until the launch is enqueued
+        pidx, poff = proposals_idx.int(), proposals_offset.int()
+        ilab, ipn = instance_labels.long(), instance_pointnum.int()
         L.check(L.lib().sg_get_mask_iou_on_cluster(
-            L.ptr(proposals_idx.int()), L.ptr(proposals_offset.int()), L.ptr(instance_labels.long()),
-            L.ptr(instance_pointnum.int()), nInstance, nProposal, L.ptr(proposals_iou), L.stream()),
-            'sg_get_mask_iou_on_cluster')
+            L.ptr(pidx), L.ptr(poff), L.ptr(ilab), L.ptr(ipn), nInstance, nProposal,
+            L.ptr(proposals_iou), L.stream()), 'sg_get_mask_iou_on_cluster')
         return proposals_iou
 
     @staticmethod
@@ -421,10 +423,12 @@ class GetMaskIoUOnPred(Function):
         assert mask_scores_sigmoid.is_contiguous() and mask_scores_sigmoid.is_cuda
         proposals_iou = torch.zeros((nProposal, nInstance), dtype=torch.float32,
                                     device=proposals_idx.device)
+        pidx, poff = proposals_idx.int(), proposals_offset.int()
+        ilab, ipn = instance_labels.long(), instance_pointnum.int()
+        sig = mask_scores_sigmoid.float()
         L.check(L.lib().sg_get_mask_iou_on_pred(
-            L.ptr(proposals_idx.int()), L.ptr(proposals_offset.int()), L.ptr(instance_labels.long()),
-            L.ptr(instance_pointnum.int()), L.ptr(mask_scores_sigmoid.float()), nInstance,
-            nProposal, L.ptr(proposals_iou), L.stream()), 'sg_get_mask_iou_on_pred')
+            L.ptr(pidx), L.ptr(poff), L.ptr(ilab), L.ptr(ipn), L.ptr(sig), nInstance, nProposal,
+            L.ptr(proposals_iou), L.stream()), 'sg_get_mask_iou_on_pred')
         return proposals_iou
 
     @staticmethod
@@ -450,9 +454,11 @@ class GetMaskLabel(Function):
         assert instance_cls.is_contiguous() and instance_cls.is_cuda
         mask_label = torch.full(proposals_idx.shape, -1.0, dtype=torch.float32,
                                 device=proposals_idx.device)
+        pidx, poff = proposals_idx.int(), proposals_offset.int()
+        ilab, icls = instance_labels.long(), instance_cls.long()
+        iou = proposals_iou.float()
         L.check(L.lib().sg_get_mask_label(
-            L.ptr(proposals_idx.int()), L.ptr(proposals_offset.int()), L.ptr(instance_labels.long()),
-            L.ptr(instance_cls.long()), L.ptr(proposals_iou.float()), nInstance, nProposal,
+            L.ptr(pidx), L.ptr(poff), L.ptr(ilab), L.ptr(icls), L.ptr(iou), nInstance, nProposal,
             float(iou_thr), L.ptr(mask_label), L.stream()), 'sg_get_mask_label')
         return mask_label
 

@@ -256,6 +256,24 @@ class _GatherConvFn(torch.autograd.Function):
         return g_feats, g_weight, None, None, None, None
 
 
+# ---- derived-tensor caches (packed conv weights, eval-mode BatchNorm affines, executor
+# descriptors) are keyed on (tensor._version, data_ptr) of their sources PLUS this epoch.
+# load_state_dict / optimizer steps / .to() change the key by themselves; writes through
+# ``param.data`` (EMA copies, custom initialisers) do NOT bump ``_version`` -- after such writes
+# call ``invalidate_caches()`` (SoftGroup.train(), ._apply() and .load_state_dict() do it too).
+_CACHE_EPOCH = [0]
+
+
+def invalidate_caches():
+    """Drop every cached packed weight / BatchNorm affine / executor descriptor (they are rebuilt
+    on the next forward).  Needed after in-place writes through ``tensor.data``."""
+    _CACHE_EPOCH[0] += 1
+
+
+def cache_epoch():
+    return _CACHE_EPOCH[0]
+
+
 class SparseModule(nn.Module):
     """marker base class: SparseSequential hands these the SparseConvTensor itself"""
     pass
@@ -312,10 +330,27 @@ class SparseConvolution(SparseModule):
                 f'stride={self.stride}, subm={self.subm}, inverse={self.inverse}, '
                 f'indice_key={self.indice_key}')
 
+    def train(self, mode=True):
+        self._kio_cache = None          # weights may change while training: re-pack afterwards
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._kio_cache = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._kio_cache = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def __getstate__(self):             # the packed copy is derived data: not pickled / deep-copied
+        state = self.__dict__.copy()
+        state['_kio_cache'] = None
+        return state
+
     # [Cout, K, Cin] -> packed kernel layout, cached until the weight changes
     def weight_packed(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), w.device, w.dtype)
+        key = (_CACHE_EPOCH[0], w._version, w.data_ptr(), w.device, w.dtype)
         if self._kio_cache is None or self._kio_cache[0] != key:
             kvol = int(torch.tensor(self.kernel_size).prod())
             self._kio_cache = (key, pack_weight(w, self.out_channels, kvol, self.in_channels, False))
@@ -403,8 +438,9 @@ class SparseInverseConv3d(SparseConvolution):
 def _bn_affine(bn):
     """eval-mode BatchNorm1d as y = x*scale + shift; cached until any of its tensors changes"""
     tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t._version, t.data_ptr()) if t is not None else None for t in tensors)
-    cache = getattr(bn, '_sg_affine', None)
+    key = (_CACHE_EPOCH[0], ) + tuple((t._version, t.data_ptr()) if t is not None else None
+                                      for t in tensors)
+    cache = bn.__dict__.get('_sg_affine')
     if cache is None or cache[0] != key:
         with torch.no_grad():
             inv = torch.rsqrt(bn.running_var.float() + bn.eps)
@@ -413,7 +449,7 @@ def _bn_affine(bn):
             if bn.bias is not None:
                 shift = shift + bn.bias.float()
         cache = (key, scale.contiguous(), shift.contiguous())
-        bn._sg_affine = cache
+        bn.__dict__['_sg_affine'] = cache
     return cache[1], cache[2]
 
 

@@ -1,3 +1,3 @@
-from ..core import (SparseConv3d, SparseConvTensor, SparseConvolution, SparseInverseConv3d,  # noqa: F401
+from ..core import (invalidate_caches, SparseConv3d, SparseConvTensor, SparseConvolution, SparseInverseConv3d,  # noqa: F401
                     SparseModule, SparseSequential, SubMConv3d, is_spconv_module)
 from . import modules  # noqa: F401

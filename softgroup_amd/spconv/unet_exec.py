@@ -82,8 +82,10 @@ class UNetExecutor:
         ok = getattr(self, '_ok', None)
         if ok is None:
             try:
-                self._walk(self.unet, dry=True)
-                ok = True
+                levels = self._walk(self.unet, dry=True)
+                # sg_unet_forward moves rows as float4: every channel count a multiple of 4
+                # (anything else takes the module path, whose scalar kernel covers it)
+                ok = all(lv.planes % 4 == 0 for lv in levels)
             except (AssertionError, AttributeError, IndexError):
                 ok = False
             self._ok = ok
@@ -159,7 +161,7 @@ class UNetExecutor:
         return out
 
     def _state_key(self):
-        return tuple((t._version, t.data_ptr()) for t in self._tensors())
+        return (core.cache_epoch(), ) + tuple((t._version, t.data_ptr()) for t in self._tensors())
 
     def _descriptor(self):
         key = self._state_key()

@@ -314,3 +314,60 @@ def test_mask_iou_and_label():
         ml = ops.get_mask_label(t(pidx), t(off), t(inst), t(cls), t(pointnum), iou, thr)
         assert np.array_equal(ml.cpu().numpy(),
                               oracle.get_mask_label(pidx, off, inst, cls, pointnum, ref, thr))
+
+
+# ----------------------------------------------------------------------------- instance runs
+def test_instance_npoint_and_runs_vs_dense_masks():
+    """csrc/instances.hip against the reference's dense formulation (softgroup.py:566-590): per
+    class a [nProposal, N] 0/1 matrix, row sums, and the runs of each kept row (what rle_encode
+    turns into text).  Long runs that cross 32-bit word boundaries, empty and full rows."""
+    from softgroup_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(41)
+    N, nP, nc, stride = 5000, 23, 5, 6
+    # proposal p = a few contiguous point ranges (long runs) + scattered points; proposal-major pairs
+    pairs = []
+    for p in range(nP):
+        pts = set()
+        for _ in range(rng.integers(1, 4)):
+            a = int(rng.integers(0, N - 400))
+            pts.update(range(a, a + int(rng.integers(1, 400))))
+        pts.update(rng.integers(0, N, 30).tolist())
+        if p == 3:
+            pts = set(range(N))                        # a full row
+        q = rng.permutation(sorted(pts))               # BFS order is not sorted
+        pairs.append(np.stack([np.full(len(q), p), q], 1))
+    pairs = np.concatenate(pairs).astype(np.int32)
+    S = len(pairs)
+    ms = rng.standard_normal((S, stride)).astype(np.float32)
+    ms[pairs[:, 0] == 5] = -9.0                        # proposal 5: nothing above the threshold
+    thr = -0.5
+    npoint = torch.empty((nP, nc), dtype=torch.int32, device=DEV)
+    L.check(lib.sg_instance_npoint(L.ptr(t(pairs)), L.ptr(t(ms)), S, stride, nc, thr, nP, L.ptr(npoint),
+                                   L.stream()), 'sg_instance_npoint')
+    dense = np.zeros((nc, nP, N), np.int32)
+    for i in range(nc):
+        on = ms[:, i] > thr
+        dense[i, pairs[on, 0], pairs[on, 1]] = 1
+    assert np.array_equal(npoint.cpu().numpy(), dense.sum(2).T)
+    keep = dense.sum(2) >= 40                          # [nc, nP]
+    keep[1, 7] = False
+    kept = np.argwhere(keep)                           # class-major
+    inst_of = np.full((nc, nP), -1, np.int32)
+    inst_of[kept[:, 0], kept[:, 1]] = np.arange(len(kept))
+    cap = int(dense.sum(2)[keep].sum())
+    starts = torch.empty(cap, dtype=torch.int32, device=DEV)
+    ends = torch.empty(cap, dtype=torch.int32, device=DEV)
+    bounds = torch.empty(len(kept) + 1, dtype=torch.int64, device=DEV)
+    ws = L.workspace(lib.sg_instance_runs_workspace_bytes(len(kept), N), DEV)
+    L.check(lib.sg_instance_runs(L.ptr(t(pairs)), L.ptr(t(ms)), S, stride, nc, thr, L.ptr(t(inst_of)), nP,
+                                 len(kept), N, L.ptr(starts), L.ptr(ends), L.ptr(bounds), cap,
+                                 L.ptr(ws), ws.numel(), L.stream()), 'sg_instance_runs')
+    b = bounds.cpu().numpy()
+    st, en = starts.cpu().numpy(), ends.cpu().numpy()
+    assert b[0] == 0 and b[-1] <= cap
+    for k, (i, p) in enumerate(kept):
+        row = np.concatenate([[0], dense[i, p], [0]])
+        edges = np.flatnonzero(row[1:] != row[:-1])
+        assert np.array_equal(st[b[k]:b[k + 1]], edges[0::2]), k
+        assert np.array_equal(en[b[k]:b[k + 1]], edges[1::2]), k
