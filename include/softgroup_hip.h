@@ -212,13 +212,6 @@ size_t sg_spconv_hash_workspace_bytes(int num_rows);
 /* builds the coordinate hash in ws, then fills nbr[M,27] */
 int sg_spconv_subm_rulebook(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
                             int32_t *nbr, void *ws, size_t ws_bytes, sg_stream_t stream);
-/* Row counts of every level of an n_levels-deep U-Net (level l+1 = strided k2 s2 of level l, same
- * drop rule) from the finest coordinates alone: counts[0..n_levels) on the device (counts[0] is
- * left 0: it is num_rows).  Lets a caller size all levels with ONE read-back instead of one per
- * down-sampling (spconv sizes each strided conv's output by a device->host copy of its own). */
-size_t sg_spconv_level_rows_workspace_bytes(int num_rows, int n_levels);
-int sg_spconv_level_rows(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
-                         int n_levels, int32_t *counts, void *ws, size_t ws_bytes, sg_stream_t stream);
 /* pass 1: in2out[M] (-1 = dropped), meta[0] = M_out.  pass 2: out_indices[M_out,4], child[M_out,8] */
 int sg_spconv_down_build(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
                          int32_t *in2out, int32_t *meta, void *ws, size_t ws_bytes,
@@ -245,6 +238,47 @@ size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
 int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
                    uint32_t *tile_mask, int32_t *nbr_tiles, void *ws, size_t ws_bytes,
                    sg_stream_t stream);
+
+/* Whole-pyramid index build: all gather tables and tile plans of an n_levels-deep U-Net
+ * (level l+1 = SparseConv3d k2 s2 of level l) in a handful of launches and ONE host read-back,
+ * instead of one rulebook / plan call chain and one read-back per level (spconv sizes every strided
+ * conv's output by its own device->host copy; softgroup/model/blocks.py:131-143 is the UBlock
+ * recursion this serves).  Results per level are identical to the per-level entry points above
+ * (same first-seen numbering of the coarse sites, same tables, same tile plans).
+ *   1. sg_spconv_pyramid_rows : rows_dev[l] = number of sites of level l (rows_dev[0] = num_rows);
+ *      the caller reads them back (its only synchronisation) and allocates the per-level outputs;
+ *   2. sg_spconv_pyramid_build: fills every pointer of levels[0..n_levels) -- `ws` is the SAME
+ *      workspace as in step 1 (it carries the hash tables), `ws2` is scratch of
+ *      sg_spconv_pyramid_build_workspace_bytes(levels, n_levels).
+ * levels[l]: rows (in); indices [rows,4]; nbr [rows,27] + plan `subm`; and for l < n_levels-1:
+ * in2out [rows]; child [rows_{l+1},8] + plan `down` (strided conv l -> l+1); inv [rows,8] + plan
+ * `up` (inverse conv l+1 -> l).  A plan of a table with R rows: order [T*32], tile_mask [T],
+ * nbr_tiles [T*32*K], T = ceil(R/32) (see sg_spconv_plan). */
+#define SG_PYRAMID_MAX_LEVELS 10
+typedef struct sg_plan_ptrs {
+  int32_t *order;
+  uint32_t *tile_mask;
+  int32_t *nbr_tiles;
+} sg_plan_ptrs;
+typedef struct sg_pyramid_level {
+  int rows;
+  int32_t *indices;
+  int32_t *nbr;
+  sg_plan_ptrs subm;
+  int32_t *in2out;
+  int32_t *child;
+  sg_plan_ptrs down;
+  int32_t *inv;
+  sg_plan_ptrs up;
+} sg_pyramid_level;
+size_t sg_spconv_pyramid_workspace_bytes(int num_rows, int n_levels);
+int sg_spconv_pyramid_rows(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
+                           int n_levels, int32_t *rows_dev, void *ws, size_t ws_bytes,
+                           sg_stream_t stream);
+size_t sg_spconv_pyramid_build_workspace_bytes(const sg_pyramid_level *levels_host, int n_levels);
+int sg_spconv_pyramid_build(const int32_t *indices, int num_rows, const int32_t *spatial_shape_host,
+                            int n_levels, const sg_pyramid_level *levels_host, void *ws,
+                            size_t ws_bytes, void *ws2, size_t ws2_bytes, sg_stream_t stream);
 
 /* Weight packing for the conv kernel: src [Cout, K, Cin] (spconv "OKKKI", the checkpoint layout,
  * tools/convert_checkpoint.py:17-19; src_is_kio = 0) or [K, Cin, Cout] (src_is_kio = 1) ->

@@ -48,8 +48,10 @@ SIGNATURES = {
     'sg_get_mask_label': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     'sg_spconv_hash_workspace_bytes': (_sz, [_i]),
     'sg_spconv_subm_rulebook': (_i, [_vp, _i, _pi32, _vp, _vp, _sz, _vp]),
-    'sg_spconv_level_rows_workspace_bytes': (_sz, [_i, _i]),
-    'sg_spconv_level_rows': (_i, [_vp, _i, _pi32, _i, _vp, _vp, _sz, _vp]),
+    'sg_spconv_pyramid_workspace_bytes': (_sz, [_i, _i]),
+    'sg_spconv_pyramid_rows': (_i, [_vp, _i, _pi32, _i, _vp, _vp, _sz, _vp]),
+    'sg_spconv_pyramid_build_workspace_bytes': (_sz, [_vp, _i]),
+    'sg_spconv_pyramid_build': (_i, [_vp, _i, _pi32, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     'sg_spconv_down_build': (_i, [_vp, _i, _pi32, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_down_fill': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_inverse_rulebook': (_i, [_vp, _vp, _i, _vp, _vp]),

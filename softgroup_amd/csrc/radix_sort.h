@@ -22,15 +22,14 @@ inline size_t radix_sort_workspace_bytes(int64_t n) {
 }
 
 __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__restrict__ keys,
-                                                          int64_t n, int shift, int nblk,
+                                                          int64_t n, int shift, int nblk, int items,
                                                           int32_t *__restrict__ hist,
                                                           int32_t *totals) {
   __shared__ int h[kRsBuckets];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kRsTile;
-#pragma unroll
-  for (int r = 0; r < kRsItems; ++r) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * items * kRsBlock;
+  for (int r = 0; r < items; ++r) {
     const int64_t i = base + r * kRsBlock + threadIdx.x;
     if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xff], 1);
   }
@@ -41,7 +40,7 @@ __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__res
 
 __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__restrict__ keys,
                                                              const int32_t *__restrict__ vals,
-                                                             int64_t n, int shift, int nblk,
+                                                             int64_t n, int shift, int nblk, int items,
                                                              const int32_t *__restrict__ hist,
                                                              const int32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ keys_out,
@@ -62,8 +61,8 @@ __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__
   } else {
     base[threadIdx.x] = hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x];
   }
-  const int64_t tile = static_cast<int64_t>(blockIdx.x) * kRsTile;
-  for (int r = 0; r < kRsItems; ++r) {
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * items * kRsBlock;
+  for (int r = 0; r < items; ++r) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -106,7 +105,13 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
     set_error("radix_sort_pairs: workspace too small");
     return SG_ERR_WORKSPACE;
   }
-  const int nblk = static_cast<int>((n + kRsTile - 1) / kRsTile);
+  // keys per workgroup: 2048, doubled (up to 16k) while that keeps the sort at <= 256 workgroups,
+  // the size up to which a pass is 2 launches instead of 5 (see below)
+  int items = kRsItems;
+  while (items < 64 && (n + static_cast<int64_t>(items) * kRsBlock - 1) / (static_cast<int64_t>(items) * kRsBlock) > 256)
+    items *= 2;
+  const int64_t tile = static_cast<int64_t>(items) * kRsBlock;
+  const int nblk = static_cast<int>((n + tile - 1) / tile);
   const int64_t hist_n = static_cast<int64_t>(nblk) * kRsBuckets;
   Workspace a(ws, ws_bytes);
   int32_t *hist = a.take<int32_t>(hist_n + 1);
@@ -125,17 +130,17 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
   for (int shift = 0, pass = 0; shift < num_bits; shift += 8, ++pass) {
     if (local_scan) {
       int32_t *t = totals + pass * kRsBuckets;
-      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, hist, t);
-      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, hist, t, kout, vout);
+      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, t);
+      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, items, hist, t, kout, vout);
     } else {
-      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, hist, nullptr);
+      rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, nullptr);
       int32_t *h = hist;
       int rc = exclusive_scan([h] __device__(int64_t i) { return h[i]; },
                               [h] __device__(int64_t i, int v) { h[i] = v; }, hist_n, nullptr, sws,
                               sbytes, stream);
       if (rc != SG_OK) return rc;
-      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, hist, nullptr, kout,
-                                                       vout);
+      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, items, hist, nullptr,
+                                                       kout, vout);
     }
     uint32_t *tk = kin; kin = kout; kout = tk;
     int32_t *tv = vin; vin = vout; vout = tv;

@@ -159,45 +159,6 @@ __global__ void __launch_bounds__(256) inverse_rulebook_kernel(const int32_t *__
   }
 }
 
-// ---- active sites of EVERY level of a U-Net from the finest level's coordinates alone: level l+1
-// holds the distinct (c >> 1) of level l that fall inside shape_l / 2 (same drop rule as
-// down_insert_kernel), so one pass over the finest voxels with one small key-only hash table per
-// coarser level gives all the row counts at once.  The executor reads them back with a single
-// host sync and can then size and enqueue the whole U-Net without waiting for the GPU again.
-__global__ void __launch_bounds__(256) pyramid_count_kernel(const int32_t *__restrict__ indices, int M,
-                                                           Shape3 shape, int n_levels,
-                                                           uint64_t *__restrict__ keys, uint32_t cap,
-                                                           int32_t *__restrict__ counts) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool alive = i < M;
-  int4 c = make_int4(0, 0, 0, 0);
-  if (alive) c = reinterpret_cast<const int4 *>(indices)[i];
-  Shape3 s = shape;
-  const uint32_t mask = cap - 1;
-  for (int l = 1; l < n_levels; ++l) {
-    const Shape3 os{s.s0 / 2, s.s1 / 2, s.s2 / 2};
-    c.y >>= 1; c.z >>= 1; c.w >>= 1;
-    alive = alive && c.y < os.s0 && c.z < os.s1 && c.w < os.s2;
-    bool fresh = false;
-    if (alive) {
-      const uint64_t key = lin_key(c.x, c.y, c.z, c.w, os);
-      uint64_t *tab = keys + static_cast<size_t>(l - 1) * cap;
-      uint32_t slot = static_cast<uint32_t>(mix64(key)) & mask;
-      while (true) {
-        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
-                                                  static_cast<unsigned long long>(kKeyEmpty),
-                                                  static_cast<unsigned long long>(key));
-        if (prev == kKeyEmpty) { fresh = true; break; }
-        if (prev == key) break;
-        slot = (slot + 1) & mask;
-      }
-    }
-    const uint64_t b = __ballot(fresh);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[l], __popcll(b));
-    s = os;
-  }
-}
-
 // ---- tile plan
 // Rows are sorted by their neighbour mask so that the 32 rows of a tile share as many kernel
 // offsets as possible.  The sort key is the mask with its bits PERMUTED by how common each offset
@@ -323,6 +284,335 @@ __global__ void __launch_bounds__(256) plan_emit_kernel(const int32_t *__restric
   }
 }
 
+
+// =============================================================================================
+// Whole-pyramid index build: every level of a U-Net in a handful of launches.
+//
+// A U-Net over M0 voxels needs, per level, a SubM rulebook + tile plan, the strided-conv pairs to
+// the next level (+ plan) and the inverse-conv table (+ plan).  Built level by level that is ~55
+// small launches and a host read-back per level (what spconv does: each strided conv sizes its
+// output by a device->host copy); the deep levels hold 18..5000 voxels, so the forward is bound by
+// the HOST issuing those launches, not by the GPU.  Everything below works on ALL levels at once:
+//
+//   * level l's sites are the distinct (c >> l) of the level-0 coordinates that survive the
+//     odd-extent drop of every strided conv on the way (same rule as down_insert_kernel), and
+//     spconv-style first-seen numbering down a chain of strided convs is the same as numbering
+//     level l's sites by their smallest level-0 descendant.  So one pass over the level-0 voxels
+//     inserts into one hash table per level (value = min level-0 row), one device-wide scan over
+//     the [L][M0] owner flags numbers the sites of every level, and the row counts of all levels
+//     come back to the host in ONE read-back (sg_spconv_pyramid_rows);
+//   * coordinates, child / in2out / inverse tables of all levels are then written by two launches,
+//     the SubM tables of all levels by one (sg_spconv_pyramid_build);
+//   * the tile plans of all 3L-2 gather tables are ONE segmented problem: rows of all tables are
+//     concatenated, the sort key gets the segment id in its top 5 bits (27 mask bits + 5 = 32), one
+//     radix sort orders every segment, and the tile kernels run over the concatenation.  Within a
+//     segment the result is identical to sg_spconv_plan's (same keys, same stable order).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPyrMaxLevels = SG_PYRAMID_MAX_LEVELS;
+constexpr int kPyrMaxSegs = 3 * kPyrMaxLevels;      // <= 32: the segment id lives in key bits 27..31
+constexpr uint32_t kPlanKeyBits = 27;
+
+__global__ void __launch_bounds__(256) pyr_insert_kernel(const int32_t *__restrict__ indices, int M0,
+                                                        Shape3 shape, int L, uint64_t *keys,
+                                                        int32_t *vals, uint32_t cap,
+                                                        int32_t *__restrict__ slot) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M0) return;
+  int4 c = reinterpret_cast<const int4 *>(indices)[i];
+  Shape3 s = shape;
+  bool alive = true;
+  for (int l = 0; l < L; ++l) {
+    if (l > 0) {
+      const Shape3 os{s.s0 / 2, s.s1 / 2, s.s2 / 2};
+      c.y >>= 1; c.z >>= 1; c.w >>= 1;
+      alive = alive && c.y < os.s0 && c.z < os.s1 && c.w < os.s2;   // odd extent: last plane dropped
+      s = os;
+    }
+    int32_t sl = -1;
+    if (alive)
+      sl = static_cast<int32_t>(hash_insert_min(keys + static_cast<size_t>(l) * cap,
+                                                vals + static_cast<size_t>(l) * cap, cap - 1,
+                                                lin_key(c.x, c.y, c.z, c.w, s), i));
+    slot[static_cast<size_t>(l) * M0 + i] = sl;
+  }
+}
+
+__global__ void pyr_rows_kernel(const int32_t *__restrict__ pos, int M0, int L, int32_t *rows) {
+  const int l = threadIdx.x;
+  if (l < L) rows[l] = pos[static_cast<size_t>(l + 1) * M0] - pos[static_cast<size_t>(l) * M0];
+}
+
+struct PyrOut {
+  int32_t *indices[kPyrMaxLevels];
+  int32_t *nbr[kPyrMaxLevels];
+  int32_t *in2out[kPyrMaxLevels];
+  int32_t *child[kPyrMaxLevels];
+  int32_t *inv[kPyrMaxLevels];
+  long long pre27[kPyrMaxLevels + 1];     // prefix of rows_l * 27
+  Shape3 shape[kPyrMaxLevels];
+};
+
+// the owner (smallest level-0 descendant) of every site writes the site's row and coordinates
+__global__ void __launch_bounds__(256) pyr_emit_kernel(const int32_t *__restrict__ indices0, int M0,
+                                                      int L, const int32_t *__restrict__ vals,
+                                                      int32_t *__restrict__ rowtab, uint32_t cap,
+                                                      const int32_t *__restrict__ slot,
+                                                      const int32_t *__restrict__ pos, PyrOut o) {
+  const int64_t total = static_cast<int64_t>(L) * M0;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int l = static_cast<int>(t / M0), i = static_cast<int>(t - static_cast<int64_t>(l) * M0);
+    const int sl = slot[t];
+    if (sl < 0 || vals[static_cast<size_t>(l) * cap + sl] != i) continue;
+    const int r = pos[t] - pos[static_cast<size_t>(l) * M0];
+    rowtab[static_cast<size_t>(l) * cap + sl] = r;
+    const int4 c = reinterpret_cast<const int4 *>(indices0)[i];
+    if (o.indices[l] != nullptr)
+      reinterpret_cast<int4 *>(o.indices[l])[r] = make_int4(c.x, c.y >> l, c.z >> l, c.w >> l);
+  }
+}
+
+// strided-conv pairs between consecutive levels, from the owners of the finer level
+__global__ void __launch_bounds__(256) pyr_link_kernel(const int32_t *__restrict__ indices0, int M0,
+                                                      int L, const int32_t *__restrict__ vals,
+                                                      const int32_t *__restrict__ rowtab,
+                                                      uint32_t cap, const int32_t *__restrict__ slot,
+                                                      const int32_t *__restrict__ pos, PyrOut o) {
+  const int64_t total = static_cast<int64_t>(L - 1) * M0;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int l = static_cast<int>(t / M0), i = static_cast<int>(t - static_cast<int64_t>(l) * M0);
+    const int sl = slot[t];
+    if (sl < 0 || vals[static_cast<size_t>(l) * cap + sl] != i) continue;
+    const int j = pos[t] - pos[static_cast<size_t>(l) * M0];
+    const int s2 = slot[t + M0];
+    const int up = s2 >= 0 ? rowtab[static_cast<size_t>(l + 1) * cap + s2] : -1;
+    const int4 c = reinterpret_cast<const int4 *>(indices0)[i];
+    const int k = (((c.y >> l) & 1) << 2) | (((c.z >> l) & 1) << 1) | ((c.w >> l) & 1);
+    o.in2out[l][j] = up;
+    if (up >= 0) o.child[l][static_cast<int64_t>(up) * 8 + k] = j;
+    int4 a = make_int4(-1, -1, -1, -1), b = a;
+    (k < 4 ? (k == 0 ? a.x : k == 1 ? a.y : k == 2 ? a.z : a.w)
+           : (k == 4 ? b.x : k == 5 ? b.y : k == 6 ? b.z : b.w)) = up;
+    int4 *dst = reinterpret_cast<int4 *>(o.inv[l] + static_cast<int64_t>(j) * 8);
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+// SubM gather tables of all levels
+__global__ void __launch_bounds__(256) pyr_subm_kernel(int L, const uint64_t *__restrict__ keys,
+                                                      const int32_t *__restrict__ rowtab,
+                                                      uint32_t cap, PyrOut o) {
+  const long long total = o.pre27[L];
+  int l = 0;
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    while (t >= o.pre27[l + 1]) ++l;                       // t only grows
+    const long long e = t - o.pre27[l];
+    const int j = static_cast<int>(e / 27), k = static_cast<int>(e - static_cast<long long>(j) * 27);
+    const int4 c = reinterpret_cast<const int4 *>(o.indices[l])[j];
+    const Shape3 s = o.shape[l];
+    const int x = c.y + k / 9 - 1, y = c.z + (k / 3) % 3 - 1, z = c.w + k % 3 - 1;
+    int32_t r = -1;
+    if (k == 13) r = j;
+    else if (x >= 0 && y >= 0 && z >= 0 && x < s.s0 && y < s.s1 && z < s.s2)
+      r = hash_find(keys + static_cast<size_t>(l) * cap, rowtab + static_cast<size_t>(l) * cap, cap - 1,
+                    lin_key(c.x, x, y, z, s));
+    o.nbr[l][e] = r;
+  }
+}
+
+// ---- segmented tile plans
+struct PlanSeg {
+  const int32_t *nbr;
+  int32_t *order;
+  uint32_t *tile_mask;
+  int32_t *nbr_tiles;
+  int rows, K, row_base, tile_base;
+};
+struct PlanSegs {
+  int n, total_rows, total_tiles;
+  PlanSeg s[kPyrMaxSegs];
+};
+__device__ __forceinline__ int seg_of_row(const PlanSegs &P, int g) {
+  int s = 0;
+  while (s + 1 < P.n && g >= P.s[s + 1].row_base) ++s;
+  return s;
+}
+__device__ __forceinline__ int seg_of_tile(const PlanSegs &P, int t) {
+  int s = 0;
+  while (s + 1 < P.n && t >= P.s[s + 1].tile_base) ++s;
+  return s;
+}
+
+__global__ void __launch_bounds__(256) plan_mask_all_kernel(PlanSegs P, uint32_t *__restrict__ mask,
+                                                           int32_t *__restrict__ val,
+                                                           int32_t *__restrict__ freq) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = g < P.total_rows;
+  const int seg = valid ? seg_of_row(P, g) : -1;
+  uint32_t m = 0;
+  if (valid) {
+    const PlanSeg &S = P.s[seg];
+    const int32_t *row = S.nbr + static_cast<int64_t>(g - S.row_base) * S.K;
+    for (int k = 0; k < S.K; ++k) m |= (row[k] >= 0 ? 1u : 0u) << k;
+    mask[g] = m;
+    val[g] = g;
+  }
+  // offset frequencies per segment: one atomic per (wave, offset) when the wave lies inside one
+  // segment (all but <= n waves), per lane otherwise
+  const int seg0 = __builtin_amdgcn_readfirstlane(seg);
+  if (__all(seg == seg0 || !valid)) {
+    if (seg0 >= 0) {
+      for (int k = 0; k < 32; ++k) {
+        const int c = __popcll(__ballot((m >> k) & 1u));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&freq[seg0 * 32 + k], c);
+      }
+    }
+  } else if (valid) {
+    for (uint32_t mm = m; mm; mm &= mm - 1) atomicAdd(&freq[seg * 32 + (__ffs(static_cast<int>(mm)) - 1)], 1);
+  }
+}
+
+// bit position of offset k in the sort key of its segment (plan_bit_positions per segment)
+__global__ void plan_pos_all_kernel(PlanSegs P, const int32_t *__restrict__ freq, int32_t *__restrict__ bitpos) {
+  const int seg = blockIdx.x, k = threadIdx.x;     // 32 threads
+  const int K = P.s[seg].K;
+  int p = 0;
+  if (k < K) {
+    const int fk = freq[seg * 32 + k];
+    for (int o = 0; o < K; ++o) {
+      const int fo = freq[seg * 32 + o];
+      p += (fo > fk || (fo == fk && o < k)) ? 1 : 0;
+    }
+  }
+  bitpos[seg * 32 + k] = p;
+}
+
+__global__ void __launch_bounds__(256) plan_key_all_kernel(PlanSegs P, const int32_t *__restrict__ bitpos,
+                                                          uint32_t *__restrict__ mask_to_key) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= P.total_rows) return;
+  const int seg = seg_of_row(P, g);
+  const uint32_t m = mask_to_key[g];
+  uint32_t key = 0;
+  for (uint32_t mm = m; mm; mm &= mm - 1) {
+    const int k = __ffs(static_cast<int>(mm)) - 1;
+    key |= 1u << bitpos[seg * 32 + k];
+  }
+  mask_to_key[g] = key | (static_cast<uint32_t>(seg) << kPlanKeyBits);
+}
+
+__global__ void __launch_bounds__(256) plan_tiles_all_kernel(PlanSegs P, const uint32_t *__restrict__ key_sorted,
+                                                            const int32_t *__restrict__ bitpos,
+                                                            uint32_t *__restrict__ tmask) {
+  const int T = blockIdx.x * 256 + threadIdx.x;
+  if (T >= P.total_tiles) return;
+  const int seg = seg_of_tile(P, T);
+  const PlanSeg &S = P.s[seg];
+  const int t = T - S.tile_base;
+  const int lo = t * 32, hi = min(lo + 32, S.rows);
+  uint32_t key = 0;
+  for (int r = lo; r < hi; ++r) key |= key_sorted[S.row_base + r];
+  key &= (1u << kPlanKeyBits) - 1u;
+  uint32_t m = 0;
+  for (int k = 0; k < S.K; ++k) m |= ((key >> bitpos[seg * 32 + k]) & 1u) << k;
+  tmask[T] = m;
+}
+
+// per segment: tiles by descending number of offsets, ties in ascending tile order (stable,
+// deterministic): one workgroup per segment, ranks from ballot match-any like the radix scatter
+__global__ void __launch_bounds__(1024) plan_tile_order_all_kernel(PlanSegs P, const uint32_t *__restrict__ tmask,
+                                                                  int32_t *__restrict__ torder) {
+  __shared__ int hist[33], base[33];
+  __shared__ int wcnt[16][33];
+  const PlanSeg &S = P.s[blockIdx.x];
+  const int nt = (S.rows + 31) / 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < nt; t += 1024) atomicAdd(&hist[__popc(tmask[S.tile_base + t])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 32; b >= 0; --b) { base[b] = run; run += hist[b]; }
+  }
+  __syncthreads();
+  for (int t0 = 0; t0 < nt; t0 += 1024) {
+    if (threadIdx.x < 16 * 33) (&wcnt[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    const bool valid = t < nt;
+    const int b = valid ? __popc(tmask[S.tile_base + t]) : 0;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+      const uint64_t bal = __ballot((b >> bit) & 1);
+      peers &= ((b >> bit) & 1) ? bal : ~bal;
+    }
+    const int lane_rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && lane_rank == 0) wcnt[wave][b] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      int off = base[b] + lane_rank;
+      for (int w = 0; w < wave; ++w) off += wcnt[w][b];
+      torder[S.tile_base + off] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 33) {
+      int add = 0;
+      for (int w = 0; w < 16; ++w) add += wcnt[w][threadIdx.x];
+      base[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const int32_t *__restrict__ val_sorted,
+                                                           const uint32_t *__restrict__ tmask,
+                                                           const int32_t *__restrict__ torder) {
+  for (int T2 = blockIdx.x; T2 < P.total_tiles; T2 += gridDim.x) {
+    const int seg = seg_of_tile(P, T2);
+    const PlanSeg &S = P.s[seg];
+    const int t2 = T2 - S.tile_base;
+    const int t = torder[T2];
+    const int K = S.K, per_tile = 32 * K;
+    if (threadIdx.x == 0) S.tile_mask[t2] = tmask[S.tile_base + t];
+    if (threadIdx.x < 32) {
+      const int pos = t * 32 + threadIdx.x;
+      S.order[t2 * 32 + threadIdx.x] = pos < S.rows ? val_sorted[S.row_base + pos] - S.row_base : -1;
+    }
+    for (int e = threadIdx.x; e < per_tile; e += 256) {
+      const int r = e / K, k = e - r * K;
+      const int pos = t * 32 + r;
+      S.nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
+          pos < S.rows ? S.nbr[static_cast<int64_t>(val_sorted[S.row_base + pos] - S.row_base) * K + k] : -1;
+    }
+  }
+}
+
+struct PyrWs {
+  uint64_t *keys;     // [L][cap]
+  int32_t *vals;      // [L][cap] smallest level-0 row of the site
+  int32_t *rowtab;    // [L][cap] row of the site inside its level
+  int32_t *slot;      // [L][M0]
+  int32_t *pos;       // [L*M0 + 1]
+  void *scan_ws;
+  size_t scan_bytes;
+  uint32_t cap;
+};
+static bool pyr_carve(void *ws, size_t ws_bytes, int M0, int L, PyrWs *w) {
+  Workspace a(ws, ws_bytes);
+  const size_t nn = static_cast<size_t>(M0 > 0 ? M0 : 1);
+  w->cap = static_cast<uint32_t>(hash_cap(M0));
+  w->keys = a.take<uint64_t>(static_cast<size_t>(L) * w->cap);
+  w->vals = a.take<int32_t>(static_cast<size_t>(L) * w->cap);
+  w->rowtab = a.take<int32_t>(static_cast<size_t>(L) * w->cap);
+  w->slot = a.take<int32_t>(static_cast<size_t>(L) * nn);
+  w->pos = a.take<int32_t>(static_cast<size_t>(L) * nn + 1);
+  w->scan_bytes = scan_workspace_bytes(static_cast<int64_t>(L) * nn);
+  w->scan_ws = a.take<char>(w->scan_bytes);
+  return w->scan_ws != nullptr;
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -414,27 +704,167 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
   return check_launch("sg_spconv_inverse_rulebook");
 }
 
-size_t sg_spconv_level_rows_workspace_bytes(int M, int n_levels) {
-  return static_cast<size_t>(n_levels > 1 ? n_levels - 1 : 0) * align_up(hash_cap(M) * 8) + 256;
+
+// ---------------------------------------------------------------------------------------------
+// whole-pyramid entry points (see the comment block above pyr_insert_kernel)
+size_t sg_spconv_pyramid_workspace_bytes(int M0, int n_levels) {
+  const size_t nn = static_cast<size_t>(M0 > 0 ? M0 : 1), L = static_cast<size_t>(n_levels > 0 ? n_levels : 1);
+  const size_t cap = hash_cap(M0);
+  return align_up(L * cap * 8) + 2 * align_up(L * cap * 4) + align_up(L * nn * 4) +
+         align_up((L * nn + 1) * 4) + align_up(scan_workspace_bytes(static_cast<int64_t>(L * nn))) + 256;
 }
 
-int sg_spconv_level_rows(const int32_t *indices, int M, const int32_t *shape_host, int n_levels,
-                         int32_t *counts, void *ws, size_t ws_bytes, sg_stream_t stream_) {
-  SG_REQUIRE(M >= 0 && shape_host && n_levels >= 1 && n_levels <= 16 && counts,
-             "sg_spconv_level_rows: bad arguments");
+int sg_spconv_pyramid_rows(const int32_t *indices, int M0, const int32_t *shape_host, int n_levels,
+                           int32_t *rows_dev, void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(M0 >= 0 && shape_host && rows_dev && n_levels >= 1 && n_levels <= kPyrMaxLevels,
+             "sg_spconv_pyramid_rows: bad arguments (M0=%d n_levels=%d)", M0, n_levels);
   hipStream_t stream = as_stream(stream_);
-  hipMemsetAsync(counts, 0, static_cast<size_t>(n_levels) * 4, stream);
-  if (M == 0 || n_levels == 1) return check_launch("sg_spconv_level_rows");
-  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_spconv_level_rows_workspace_bytes(M, n_levels),
-             "sg_spconv_level_rows: workspace too small");
-  const size_t cap = hash_cap(M);
-  SG_REQUIRE(align_up(cap * 8) == cap * 8, "sg_spconv_level_rows: internal table alignment");
-  hipMemsetAsync(ws, 0xff, static_cast<size_t>(n_levels - 1) * cap * 8, stream);
+  if (M0 == 0) {
+    hipMemsetAsync(rows_dev, 0, static_cast<size_t>(n_levels) * 4, stream);
+    return check_launch("sg_spconv_pyramid_rows");
+  }
+  PyrWs w;
+  if (!pyr_carve(ws, ws_bytes, M0, n_levels, &w)) {
+    set_error("sg_spconv_pyramid_rows: workspace too small (%zu bytes)", ws_bytes);
+    return SG_ERR_WORKSPACE;
+  }
+  const int L = n_levels;
+  hipMemsetAsync(w.keys, 0xff, static_cast<size_t>(L) * w.cap * 8, stream);
+  hipMemsetAsync(w.vals, 0x7f, static_cast<size_t>(L) * w.cap * 4, stream);
   const Shape3 shape{shape_host[0], shape_host[1], shape_host[2]};
-  pyramid_count_kernel<<<(M + 255) / 256, 256, 0, stream>>>(indices, M, shape, n_levels,
-                                                           static_cast<uint64_t *>(ws),
-                                                           static_cast<uint32_t>(cap), counts);
-  return check_launch("sg_spconv_level_rows");
+  pyr_insert_kernel<<<(M0 + 255) / 256, 256, 0, stream>>>(indices, M0, shape, L, w.keys, w.vals, w.cap,
+                                                         w.slot);
+  const int32_t *slot = w.slot, *vals = w.vals;
+  int32_t *pos = w.pos;
+  const int m0 = M0;
+  const uint32_t cap = w.cap;
+  const int64_t n = static_cast<int64_t>(L) * M0;
+  int rc = exclusive_scan(
+      [slot, vals, m0, cap] __device__(int64_t t) {
+        const int64_t l = t / m0;
+        const int sl = slot[t];
+        return (sl >= 0 && vals[l * cap + sl] == static_cast<int32_t>(t - l * m0)) ? 1 : 0;
+      },
+      [pos] __device__(int64_t t, int v) { pos[t] = v; }, n, pos + n, w.scan_ws, w.scan_bytes, stream);
+  if (rc != SG_OK) return rc;
+  pyr_rows_kernel<<<1, 64, 0, stream>>>(w.pos, M0, L, rows_dev);
+  return check_launch("sg_spconv_pyramid_rows");
+}
+
+static long long pyr_seg_rows(const sg_pyramid_level *lv, int L, int seg_kind, int l) {
+  return seg_kind == 1 ? lv[l + 1].rows : lv[l].rows;   // 0 subm, 1 down (rows of the coarser level), 2 up
+}
+
+size_t sg_spconv_pyramid_build_workspace_bytes(const sg_pyramid_level *levels, int n_levels) {
+  long long total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    total += levels[l].rows;
+    if (l + 1 < n_levels) total += levels[l + 1].rows + levels[l].rows;
+  }
+  const size_t R = static_cast<size_t>(total > 0 ? total : 1);
+  const size_t T = R / 32 + static_cast<size_t>(3 * n_levels) + 1;
+  return 2 * align_up(R * 4) + 2 * align_up(T * 4) + 2 * align_up(kPyrMaxSegs * 32 * 4) +
+         radix_sort_workspace_bytes(static_cast<int64_t>(R)) + 512;
+}
+
+int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape_host, int n_levels,
+                            const sg_pyramid_level *levels, void *ws, size_t ws_bytes, void *ws2,
+                            size_t ws2_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(M0 >= 0 && shape_host && levels && n_levels >= 1 && n_levels <= kPyrMaxLevels,
+             "sg_spconv_pyramid_build: bad arguments (M0=%d n_levels=%d)", M0, n_levels);
+  SG_REQUIRE(levels[0].rows == M0, "sg_spconv_pyramid_build: levels[0].rows must be num_rows");
+  if (M0 == 0) return SG_OK;
+  hipStream_t stream = as_stream(stream_);
+  const int L = n_levels;
+  PyrWs w;
+  if (!pyr_carve(ws, ws_bytes, M0, L, &w)) {
+    set_error("sg_spconv_pyramid_build: workspace too small (%zu bytes)", ws_bytes);
+    return SG_ERR_WORKSPACE;
+  }
+  SG_REQUIRE(ws2 != nullptr && ws2_bytes >= sg_spconv_pyramid_build_workspace_bytes(levels, L),
+             "sg_spconv_pyramid_build: build workspace too small (%zu bytes)", ws2_bytes);
+  PyrOut o;
+  PlanSegs P;
+  P.n = 0;
+  int row_base = 0, tile_base = 0;
+  auto add_seg = [&](const int32_t *nbr, int rows, int K, const sg_plan_ptrs &pl) {
+    PlanSeg &S = P.s[P.n++];
+    S.nbr = nbr; S.order = pl.order; S.tile_mask = pl.tile_mask; S.nbr_tiles = pl.nbr_tiles;
+    S.rows = rows; S.K = K; S.row_base = row_base; S.tile_base = tile_base;
+    row_base += rows;
+    tile_base += (rows + 31) / 32;
+  };
+  Shape3 s{shape_host[0], shape_host[1], shape_host[2]};
+  o.pre27[0] = 0;
+  for (int l = 0; l < kPyrMaxLevels; ++l) {
+    const bool in = l < L;
+    o.indices[l] = in ? levels[l].indices : nullptr;
+    o.nbr[l] = in ? levels[l].nbr : nullptr;
+    o.in2out[l] = in ? levels[l].in2out : nullptr;
+    o.child[l] = in ? levels[l].child : nullptr;
+    o.inv[l] = in ? levels[l].inv : nullptr;
+    o.shape[l] = s;
+    o.pre27[l + 1] = o.pre27[l] + (in ? static_cast<long long>(levels[l].rows) * 27 : 0);
+    s = Shape3{s.s0 / 2, s.s1 / 2, s.s2 / 2};
+  }
+  for (int l = 0; l < L; ++l) {
+    SG_REQUIRE(levels[l].rows >= 0 && levels[l].nbr && levels[l].indices && levels[l].subm.order,
+               "sg_spconv_pyramid_build: level %d: missing output pointers", l);
+    if (l + 1 < L)
+      SG_REQUIRE(levels[l].in2out && levels[l].child && levels[l].inv && levels[l].down.order &&
+                     levels[l].up.order, "sg_spconv_pyramid_build: level %d: missing output pointers", l);
+  }
+  // ---- coordinates, strided pairs, SubM tables of all levels
+  const int g_all = grid_for(static_cast<int64_t>(L) * M0, 256, 4096);
+  pyr_emit_kernel<<<g_all, 256, 0, stream>>>(indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
+  if (L > 1) {
+    for (int l = 0; l + 1 < L; ++l)
+      if (levels[l + 1].rows > 0)
+        hipMemsetAsync(levels[l].child, 0xff, static_cast<size_t>(levels[l + 1].rows) * 8 * 4, stream);
+    pyr_link_kernel<<<grid_for(static_cast<int64_t>(L - 1) * M0, 256, 4096), 256, 0, stream>>>(
+        indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
+  }
+  pyr_subm_kernel<<<grid_for(o.pre27[L], 256, 8192), 256, 0, stream>>>(L, w.keys, w.rowtab, w.cap, o);
+  // ---- tile plans of all gather tables as one segmented problem
+  for (int l = 0; l < L; ++l) {
+    if (levels[l].rows > 0) add_seg(levels[l].nbr, levels[l].rows, 27, levels[l].subm);
+    if (l + 1 < L) {
+      if (levels[l + 1].rows > 0) add_seg(levels[l].child, levels[l + 1].rows, 8, levels[l].down);
+      if (levels[l].rows > 0) add_seg(levels[l].inv, levels[l].rows, 8, levels[l].up);
+    }
+  }
+  P.total_rows = row_base;
+  P.total_tiles = tile_base;
+  if (P.n == 0) return check_launch("sg_spconv_pyramid_build");
+  Workspace a(ws2, ws2_bytes);
+  const size_t R = static_cast<size_t>(P.total_rows);
+  uint32_t *mask = a.take<uint32_t>(R);
+  int32_t *val = a.take<int32_t>(R);
+  uint32_t *tmask = a.take<uint32_t>(P.total_tiles);
+  int32_t *torder = a.take<int32_t>(P.total_tiles);
+  int32_t *freq = a.take<int32_t>(kPyrMaxSegs * 32);
+  int32_t *bitpos = a.take<int32_t>(kPyrMaxSegs * 32);
+  const size_t rs_bytes = radix_sort_workspace_bytes(static_cast<int64_t>(R));
+  void *rs_ws = a.take<char>(rs_bytes);
+  if (!rs_ws) {
+    set_error("sg_spconv_pyramid_build: build workspace too small");
+    return SG_ERR_WORKSPACE;
+  }
+  const int grid = static_cast<int>((R + 255) / 256);
+  hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);
+  plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
+  plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
+  plan_key_all_kernel<<<grid, 256, 0, stream>>>(P, bitpos, mask);
+  uint32_t *ms;
+  int32_t *vs;
+  int nbits = kPlanKeyBits;
+  for (int n = P.n - 1; n > 0; n >>= 1) ++nbits;
+  int rc = radix_sort_pairs(mask, val, static_cast<int64_t>(R), nbits, rs_ws, rs_bytes, stream, &ms, &vs);
+  if (rc != SG_OK) return rc;
+  plan_tiles_all_kernel<<<(P.total_tiles + 255) / 256, 256, 0, stream>>>(P, ms, bitpos, tmask);
+  plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(P, tmask, torder);
+  plan_emit_all_kernel<<<min(P.total_tiles, 8192), 256, 0, stream>>>(P, vs, tmask, torder);
+  return check_launch("sg_spconv_pyramid_build");
 }
 
 size_t sg_spconv_plan_workspace_bytes(int M) {

@@ -6,12 +6,11 @@
 // The Python module path (softgroup_amd/spconv + model/blocks.py) launches the same kernels in
 // the same order; it stays the path for training.  Here nothing but kernel launches happens
 // between two layers: no interpreter, no allocator calls (a caller-provided arena, stack
-// discipline per level) and ONE host sync per forward: the row counts of all levels come from one
-// pass over the finest coordinates (sg_spconv_level_rows) and are read back right at the start.
-// Two streams: everything that depends only on voxel coordinates (rulebooks, plans) runs on an
-// internal index stream and races ahead of the convolutions on the caller's stream, which wait
-// per level on an event; index tables are never recycled inside a forward, so the only
-// cross-stream hazards are the read-after-write ones the events cover.
+// discipline per level) and ONE host sync per forward.  Everything that depends only on voxel
+// coordinates -- the gather tables and tile plans of ALL levels -- is built up front by the
+// whole-pyramid index build (sg_spconv_pyramid_rows / _build, spconv_rulebook.hip): ~30 launches
+// and one read-back of the level row counts for the entire U-Net, on an internal index stream;
+// the caller's stream waits for it once and then runs nothing but convolutions.
 // Runtime state (index stream, events, pinned read-back words) is kept per device; calls on one
 // device are serialised by a mutex (one forward owns the device's index stream at a time).
 #include <mutex>
@@ -87,59 +86,20 @@ struct Plan {
     return SG_ERR_WORKSPACE;                                                           \
   }
 
+struct LevelIdx {
+  int rows = 0;
+  int32_t shape[3] = {0, 0, 0};
+  Plan subm, down, up, ident;
+};
+
 struct Exec {
   const sg_unet_desc *d;
   Arena ar;             // features and conv scratch: caller's stream only
-  Arena ix;             // index tables and their scratch: index stream only (bump, no recycling)
   sg_stream_t stream;   // caller's stream (convolutions, elementwise)
-  sg_stream_t istream;  // index stream
-  const int32_t *level_rows;   // host: rows of every level (known before anything is enqueued)
-  hipEvent_t *events;
-  int n_events, next_event;
+  const LevelIdx *idx;  // per level: rows, tables and plans (complete before the first conv runs)
 
-  Exec(const sg_unet_desc *desc, void *arena, size_t bytes, size_t index_bytes, sg_stream_t s,
-       sg_stream_t is)
-      : d(desc), ar(static_cast<char *>(arena) + index_bytes, bytes - index_bytes),
-        ix(arena, index_bytes), stream(s), istream(is), level_rows(nullptr), events(nullptr),
-        n_events(0), next_event(0) {}
-
-  // the caller's stream may not run past this point before the index stream got here
-  int index_ready() {
-    if (next_event >= n_events) {
-      set_error("sg_unet_forward: out of events");
-      return SG_ERR_LAUNCH;
-    }
-    hipEvent_t e = events[next_event++];
-    if (hipEventRecord(e, as_stream(istream)) != hipSuccess ||
-        hipStreamWaitEvent(as_stream(stream), e, 0) != hipSuccess) {
-      set_error("sg_unet_forward: event record/wait failed");
-      return SG_ERR_LAUNCH;
-    }
-    return SG_OK;
-  }
-
-#define SG_IALLOC(var, T, count)                                                       \
-  T *var = ix.take<T>(count);                                                          \
-  if (var == nullptr) {                                                                \
-    set_error("sg_unet_forward: index arena too small (%zu bytes)", ix.cap);           \
-    return SG_ERR_WORKSPACE;                                                           \
-  }
-
-  int make_plan(const int32_t *nbr, int rows, int kvol, Plan &p) {
-    p.nbr = nbr; p.rows = rows; p.kvol = kvol;
-    const size_t nt = (static_cast<size_t>(rows) + 31) / 32;
-    SG_IALLOC(order, int32_t, nt * 32);
-    SG_IALLOC(tmask, uint32_t, nt ? nt : 1);
-    SG_IALLOC(ntiles, int32_t, nt * 32 * kvol);
-    p.order = order; p.tile_mask = tmask; p.nbr_tiles = ntiles;
-    if (rows == 0) return SG_OK;
-    const size_t m = ix.mark();
-    const size_t nb = sg_spconv_plan_workspace_bytes(rows);
-    SG_IALLOC(ws, char, nb);
-    SG_TRY(sg_spconv_plan(nbr, rows, kvol, order, tmask, ntiles, ws, nb, istream));
-    ix.release(m);     // scratch only: index-stream order keeps it alive until the plan kernels are done
-    return SG_OK;
-  }
+  Exec(const sg_unet_desc *desc, void *arena, size_t bytes, sg_stream_t s, const LevelIdx *li)
+      : d(desc), ar(arena, bytes), stream(s), idx(li) {}
 
   // BatchNorm1d + ReLU of a consumer, applied by the producer: (scale, shift) and where the
   // activated copy goes
@@ -187,32 +147,15 @@ struct Exec {
   // the first block's BatchNorm if the producer of x made it (else it is computed here); post =
   // BatchNorm+ReLU applied in place by the level's last conv (output_layer for the outermost
   // level, the parent's deconv BatchNorm for an inner one).
-  int level(int l, const float *x, const float *xa, const int32_t *indices, int rows,
-            const int32_t shape[3], const float *pre_in, int pre_cin, const float *post_s,
-            const float *post_b, float *out) {
+  int level(int l, const float *x, const float *xa, const float *pre_in, int pre_cin,
+            const float *post_s, const float *post_b, float *out) {
     const sg_unet_level &L = d->levels[l];
     const int c = L.planes;
     const bool deeper = l + 1 < d->n_levels;
     const size_t m0 = ar.mark();
-    // ---- index stream: SubM rulebook + plan of this level (indice_key 'subm<l>', shared by all
-    //      its blocks), identity table for the 1x1 convs of the tail
-    SG_IALLOC(nbr, int32_t, static_cast<size_t>(rows ? rows : 1) * 27);
-    if (rows) {
-      const size_t m = ix.mark();
-      const size_t nb = sg_spconv_hash_workspace_bytes(rows);
-      SG_IALLOC(ws, char, nb);
-      SG_TRY(sg_spconv_subm_rulebook(indices, rows, shape, nbr, ws, nb, istream));
-      ix.release(m);
-    }
-    Plan subm;
-    SG_TRY(make_plan(nbr, rows, 27, subm));
-    Plan ident;
-    if (deeper && rows) {
-      SG_IALLOC(iota, int32_t, rows);
-      iota_kernel<<<grid_for(rows, 256), 256, 0, as_stream(istream)>>>(iota, rows);
-      ident.nbr = iota; ident.rows = rows; ident.kvol = 1;
-    }
-    SG_TRY(index_ready());
+    const LevelIdx &I = idx[l];
+    const int rows = I.rows;
+    const Plan &subm = I.subm, &ident = I.ident;
     const size_t feat = static_cast<size_t>(rows ? rows : 1) * c;
     // optional input conv (outermost level only): SubMConv3d(in, planes) on the same rulebook
     if (pre_in != nullptr) {
@@ -249,25 +192,8 @@ struct Exec {
     }
     if (deeper) {
       const int c2 = d->levels[l + 1].planes;
-      // ---- index stream: strided-conv pairs (the number of coarse voxels is already known on the
-      //      host: level_rows), their plan, and the inverse table + plan the way back up will need
-      SG_IALLOC(in2out, int32_t, rows ? rows : 1);
-      SG_IALLOC(meta, int32_t, 64);
-      const size_t nbh = sg_spconv_hash_workspace_bytes(rows);
-      SG_IALLOC(hws, char, nbh);          // coordinate hash: built by down_build, read by down_fill
-      const int rows2 = rows ? level_rows[l + 1] : 0;
-      if (rows) SG_TRY(sg_spconv_down_build(indices, rows, shape, in2out, meta, hws, nbh, istream));
-      SG_IALLOC(idx2, int32_t, static_cast<size_t>(rows2 ? rows2 : 1) * 4);
-      SG_IALLOC(child, int32_t, static_cast<size_t>(rows2 ? rows2 : 1) * 8);
-      if (rows) SG_TRY(sg_spconv_down_fill(indices, rows, in2out, rows2, idx2, child, hws, nbh, istream));
-      Plan down;
-      SG_TRY(make_plan(child, rows2, 8, down));
-      SG_IALLOC(inv, int32_t, static_cast<size_t>(rows ? rows : 1) * 8);
-      if (rows) SG_TRY(sg_spconv_inverse_rulebook(indices, in2out, rows, inv, istream));
-      Plan up;
-      SG_TRY(make_plan(inv, rows, 8, up));
-      SG_TRY(index_ready());
-      const int32_t shape2[3] = {shape[0] / 2, shape[1] / 2, shape[2] / 2};
+      const int rows2 = idx[l + 1].rows;
+      const Plan &down = I.down, &up = I.up;
       // ---- (BN -> ReLU done by the last block) -> SparseConv3d(c, c2, k2 s2); its second output
       //      feeds the first BatchNorm of the inner level
       const sg_unet_level &L2 = d->levels[l + 1];
@@ -278,7 +204,7 @@ struct Exec {
       SG_TRY(conv(cur_a, rows, down, c, c2, L.down_w, nullptr, nullptr, nullptr, ay, y));
       // ---- inner UBlock; its last conv applies this level's deconv BatchNorm + ReLU in place
       SG_ALLOC(z, float, feat2);
-      SG_TRY(level(l + 1, y, ya, idx2, rows2, shape2, nullptr, 0, L.up_bn_scale, L.up_bn_shift, z));
+      SG_TRY(level(l + 1, y, ya, nullptr, 0, L.up_bn_scale, L.up_bn_shift, z));
       // ---- SparseInverseConv3d(c2, c): gather table = parent row per fine voxel (plan `up`, built
       //      on the index stream before the descent), then the skip concat (blocks.py:135-139)
       //      with the first tail block's BatchNorm + ReLU as a second output
@@ -326,16 +252,29 @@ using namespace sg;
 
 extern "C" {
 
-// index part of the arena: tables are never recycled inside a forward, so every level is priced
-// with all `num_rows` voxels (they can only shrink): gather tables 27 + 8 + 8 ints per row, their
-// plan copies (27 + 8 + 8), rows / orders / maps (~12), hash tables, plan scratch
+// index part of the arena (the pyramid's hash workspace, every level's tables and plans, the plan
+// build scratch): priced with all `num_rows` voxels on every level (levels can only shrink)
+static size_t level_index_bytes(size_t rows, size_t rows_next, bool deeper) {
+  const size_t t = (rows + 31) / 32, t2 = (rows_next + 31) / 32;
+  size_t b = align_up(rows * 4 * 4) + align_up(rows * 27 * 4) +                       // indices, nbr
+             align_up(t * 32 * 4) + align_up((t + 1) * 4) + align_up(t * 32 * 27 * 4);  // subm plan
+  if (deeper)
+    b += align_up(rows * 4) + align_up(rows_next * 8 * 4) + align_up(rows * 8 * 4) +   // in2out, child, inv
+         align_up(t2 * 32 * 4) + align_up((t2 + 1) * 4) + align_up(t2 * 32 * 8 * 4) +   // down plan
+         align_up(t * 32 * 4) + align_up((t + 1) * 4) + align_up(t * 32 * 8 * 4);       // up plan
+  return b + 4096;
+}
 static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
-  size_t total = 1 << 20;
-  for (int l = 0; l < d->n_levels; ++l)
-    total += rows * (2 * 43 + 16) * 4 + 2 * sg_spconv_hash_workspace_bytes(num_rows) + (256 << 10);
-  return align_up(total + sg_spconv_plan_workspace_bytes(num_rows) +
-                  sg_spconv_level_rows_workspace_bytes(num_rows, d->n_levels), 4096);
+  const int L = d->n_levels;
+  size_t total = (1 << 20) + sg_spconv_pyramid_workspace_bytes(num_rows, L) + align_up(rows * 4);
+  sg_pyramid_level bound[SG_PYRAMID_MAX_LEVELS];
+  for (int l = 0; l < L && l < SG_PYRAMID_MAX_LEVELS; ++l) {
+    total += level_index_bytes(rows, rows, l + 1 < L);
+    bound[l].rows = num_rows;
+  }
+  total += sg_spconv_pyramid_build_workspace_bytes(bound, L < SG_PYRAMID_MAX_LEVELS ? L : SG_PYRAMID_MAX_LEVELS);
+  return align_up(total, 4096);
 }
 
 size_t sg_unet_arena_bytes(const sg_unet_desc *d, int num_rows) {
@@ -351,80 +290,141 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
                     const int32_t *spatial_shape_host, float *out, void *arena, size_t arena_bytes,
                     sg_stream_t stream) {
   SG_REQUIRE(d != nullptr && d->n_levels >= 1 && d->levels != nullptr, "sg_unet_forward: bad descriptor");
+  SG_REQUIRE(d->n_levels <= SG_PYRAMID_MAX_LEVELS, "sg_unet_forward: at most %d levels", SG_PYRAMID_MAX_LEVELS);
   SG_REQUIRE(num_rows >= 0, "sg_unet_forward: bad num_rows");
   for (int l = 0; l < d->n_levels; ++l)
     SG_REQUIRE(d->levels[l].planes % 4 == 0 && d->levels[l].n_blocks >= 1,
                "sg_unet_forward: level %d: planes must be a multiple of 4", l);
   if (num_rows == 0) return SG_OK;
-  const size_t index_bytes = unet_index_bytes(d, num_rows);
-  SG_REQUIRE(arena != nullptr && arena_bytes > index_bytes,
-             "sg_unet_forward: arena of %zu bytes, need sg_unet_arena_bytes()", arena_bytes);
+  const int L = d->n_levels;
   // ---- per-device runtime state
-  constexpr int kEvents = 64, kMaxDev = 64, kMaxLevels = 16;
+  constexpr int kMaxDev = 64;
   struct DeviceState {
     std::mutex mu;
-    int32_t *host_rows = nullptr;     // pinned [kMaxLevels]
-    int32_t *dev_rows = nullptr;      // device [kMaxLevels]
+    int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
+    int32_t *dev_rows = nullptr;      // device
     hipStream_t istream = nullptr;
-    hipEvent_t events[kEvents];
+    hipEvent_t ev_start = nullptr, ev_index = nullptr;
     bool ready = false;
   };
   static DeviceState states[kMaxDev];
-  SG_REQUIRE(d->n_levels <= kMaxLevels, "sg_unet_forward: at most %d levels", kMaxLevels);
   int dev = 0;
   SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev,
              "sg_unet_forward: no current device");
   DeviceState &st = states[dev];
   std::lock_guard<std::mutex> guard(st.mu);
   if (!st.ready) {
-    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), kMaxLevels * 4) == hipSuccess,
+    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
                "sg_unet_forward: pinned allocation failed");
-    SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), kMaxLevels * 4) == hipSuccess,
+    SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
                "sg_unet_forward: device allocation failed");
     SG_REQUIRE(hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
                "sg_unet_forward: stream creation failed");
-    for (int i = 0; i < kEvents; ++i)
-      SG_REQUIRE(hipEventCreateWithFlags(&st.events[i], hipEventDisableTiming) == hipSuccess,
-                 "sg_unet_forward: event creation failed");
+    SG_REQUIRE(hipEventCreateWithFlags(&st.ev_start, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&st.ev_index, hipEventDisableTiming) == hipSuccess,
+               "sg_unet_forward: event creation failed");
     st.ready = true;
   }
   hipStream_t istream = st.istream;
-  hipEvent_t *events = st.events;
-  Exec ex(d, arena, arena_bytes, index_bytes, stream, reinterpret_cast<sg_stream_t>(istream));
-  ex.events = events;
-  ex.n_events = kEvents;
+  sg_stream_t is = reinterpret_cast<sg_stream_t>(istream);
   // the index stream starts where the caller's stream is now: the coordinates are ready, and the
   // previous forward's convolutions no longer read the tables about to be overwritten
-  if (hipEventRecord(events[0], as_stream(stream)) != hipSuccess ||
-      hipStreamWaitEvent(istream, events[0], 0) != hipSuccess) {
+  if (hipEventRecord(st.ev_start, as_stream(stream)) != hipSuccess ||
+      hipStreamWaitEvent(istream, st.ev_start, 0) != hipSuccess) {
     set_error("sg_unet_forward: event record/wait failed");
     return SG_ERR_LAUNCH;
   }
-  ex.next_event = 1;
-  // ---- rows of every level, one read-back (the only host sync of the forward; it waits for the
-  //      index stream only -- whatever the caller's stream still has queued keeps running)
-  int32_t level_rows[kMaxLevels];
-  level_rows[0] = num_rows;
-  if (d->n_levels > 1) {
-    const size_t m = ex.ix.mark();
-    const size_t nb = sg_spconv_level_rows_workspace_bytes(num_rows, d->n_levels);
-    char *ws = ex.ix.take<char>(nb);
-    SG_REQUIRE(ws != nullptr, "sg_unet_forward: index arena too small (%zu bytes)", ex.ix.cap);
-    SG_TRY(sg_spconv_level_rows(indices, num_rows, spatial_shape_host, d->n_levels, st.dev_rows, ws, nb,
-                                reinterpret_cast<sg_stream_t>(istream)));
-    if (hipMemcpyAsync(st.host_rows, st.dev_rows, sizeof(int32_t) * d->n_levels, hipMemcpyDeviceToHost,
-                       istream) != hipSuccess ||
-        hipStreamSynchronize(istream) != hipSuccess) {
-      set_error("sg_unet_forward: reading the level row counts failed");
-      return SG_ERR_LAUNCH;
-    }
-    for (int l = 1; l < d->n_levels; ++l) level_rows[l] = st.host_rows[l];
-    ex.ix.release(m);
+  // ---- index part of the arena (bump, never recycled inside a forward)
+  Arena ix(arena, arena_bytes);
+#define SG_IALLOC(var, T, count)                                                       \
+  T *var = ix.take<T>(count);                                                          \
+  if (var == nullptr) {                                                                \
+    set_error("sg_unet_forward: arena too small (%zu bytes) for the index tables", arena_bytes); \
+    return SG_ERR_WORKSPACE;                                                           \
   }
-  ex.level_rows = level_rows;
+  // ---- rows of every level: one pass + one read-back (the only host sync of the forward; it
+  //      waits for the index stream only -- whatever the caller's stream has queued keeps running)
+  const size_t pws_bytes = sg_spconv_pyramid_workspace_bytes(num_rows, L);
+  SG_IALLOC(pws, char, pws_bytes);
+  SG_TRY(sg_spconv_pyramid_rows(indices, num_rows, spatial_shape_host, L, st.dev_rows, pws, pws_bytes, is));
+  if (hipMemcpyAsync(st.host_rows, st.dev_rows, sizeof(int32_t) * L, hipMemcpyDeviceToHost, istream) != hipSuccess ||
+      hipStreamSynchronize(istream) != hipSuccess) {
+    set_error("sg_unet_forward: reading the level row counts failed");
+    return SG_ERR_LAUNCH;
+  }
+  SG_REQUIRE(st.host_rows[0] == num_rows, "sg_unet_forward: duplicate voxel coordinates in the input "
+             "(%d distinct of %d rows)", st.host_rows[0], num_rows);
+  // ---- tables and plans of all levels
+  sg_pyramid_level pl[SG_PYRAMID_MAX_LEVELS];
+  LevelIdx li[SG_PYRAMID_MAX_LEVELS];
+  for (int l = 0; l < L; ++l) {
+    const int rows = st.host_rows[l];
+    const int rows2 = l + 1 < L ? st.host_rows[l + 1] : 0;
+    const size_t r = static_cast<size_t>(rows ? rows : 1), r2 = static_cast<size_t>(rows2 ? rows2 : 1);
+    const size_t t = (r + 31) / 32, t2 = (r2 + 31) / 32;
+    sg_pyramid_level &P = pl[l];
+    P = sg_pyramid_level();
+    P.rows = rows;
+    SG_IALLOC(indices_l, int32_t, r * 4);
+    SG_IALLOC(nbr, int32_t, r * 27);
+    SG_IALLOC(so, int32_t, t * 32);
+    SG_IALLOC(sm, uint32_t, t + 1);
+    SG_IALLOC(sn, int32_t, t * 32 * 27);
+    P.indices = indices_l; P.nbr = nbr;
+    P.subm = sg_plan_ptrs{so, sm, sn};
+    LevelIdx &I = li[l];
+    I.rows = rows;
+    for (int a = 0; a < 3; ++a) I.shape[a] = spatial_shape_host[a] >> l;
+    I.subm.nbr = nbr; I.subm.order = so; I.subm.tile_mask = sm; I.subm.nbr_tiles = sn;
+    I.subm.rows = rows; I.subm.kvol = 27;
+    if (l + 1 < L) {
+      SG_IALLOC(in2out, int32_t, r);
+      SG_IALLOC(child, int32_t, r2 * 8);
+      SG_IALLOC(inv, int32_t, r * 8);
+      SG_IALLOC(dord, int32_t, t2 * 32);
+      SG_IALLOC(dm, uint32_t, t2 + 1);
+      SG_IALLOC(dn, int32_t, t2 * 32 * 8);
+      SG_IALLOC(uo, int32_t, t * 32);
+      SG_IALLOC(um, uint32_t, t + 1);
+      SG_IALLOC(un, int32_t, t * 32 * 8);
+      P.in2out = in2out; P.child = child; P.inv = inv;
+      P.down = sg_plan_ptrs{dord, dm, dn};
+      P.up = sg_plan_ptrs{uo, um, un};
+      I.down.nbr = child; I.down.order = dord; I.down.tile_mask = dm; I.down.nbr_tiles = dn;
+      I.down.rows = rows2; I.down.kvol = 8;
+      I.up.nbr = inv; I.up.order = uo; I.up.tile_mask = um; I.up.nbr_tiles = un;
+      I.up.rows = rows; I.up.kvol = 8;
+    }
+  }
+  {
+    const size_t nb = sg_spconv_pyramid_build_workspace_bytes(pl, L);
+    SG_IALLOC(ws2, char, nb);
+    SG_TRY(sg_spconv_pyramid_build(indices, num_rows, spatial_shape_host, L, pl, pws, pws_bytes, ws2, nb, is));
+  }
+  if (L > 1) {      // identity table of the 1x1 convs on the tail's identity branches (any level: a prefix)
+    SG_IALLOC(iota, int32_t, num_rows);
+    iota_kernel<<<grid_for(num_rows, 256), 256, 0, istream>>>(iota, num_rows);
+    for (int l = 0; l + 1 < L; ++l) {
+      li[l].ident.nbr = iota; li[l].ident.rows = li[l].rows; li[l].ident.kvol = 1;
+    }
+  }
+#undef SG_IALLOC
+  if (hipEventRecord(st.ev_index, istream) != hipSuccess ||
+      hipStreamWaitEvent(as_stream(stream), st.ev_index, 0) != hipSuccess) {
+    set_error("sg_unet_forward: event record/wait failed");
+    return SG_ERR_LAUNCH;
+  }
+  // ---- the convolutions: feature part of the arena
+  const size_t used = align_up(ix.off, 4096);
+  if (arena_bytes <= used) {
+    set_error("sg_unet_forward: arena too small (%zu bytes)", arena_bytes);
+    return SG_ERR_WORKSPACE;
+  }
+  Exec ex(d, static_cast<char *>(arena) + used, arena_bytes - used, stream, li);
   const bool pre = d->input_w != nullptr;
-  return ex.level(0, pre ? nullptr : feats, nullptr, indices, num_rows, spatial_shape_host,
-                  pre ? feats : nullptr, d->input_cin, d->out_bn_scale, d->out_bn_shift, out);
+  const int rc = ex.level(0, pre ? nullptr : feats, nullptr, pre ? feats : nullptr, d->input_cin,
+                          d->out_bn_scale, d->out_bn_shift, out);
+  return rc;
 }
 
 }  // extern "C"

@@ -92,27 +92,113 @@ def test_down_rulebook_exact_incl_odd_extent_drop():
     assert np.array_equal(inv, exp)
 
 
-def test_level_rows_of_all_levels_in_one_pass():
-    """sg_spconv_level_rows: the row count of every U-Net level from the finest coordinates alone
-    (what lets sg_unet_forward run with a single host sync) == the chain of strided rulebooks of
-    the oracle, including the odd-extent drops at every level."""
+def _pyramid(idx, shape, n_levels):
+    """sg_spconv_pyramid_rows + _build through the C ABI -> per-level dict of numpy arrays"""
+    import ctypes as C
     from softgroup_amd import _lib as L
+    lib = L.lib()
+
+    class PlanPtrs(C.Structure):
+        _fields_ = [('order', C.c_void_p), ('tile_mask', C.c_void_p), ('nbr_tiles', C.c_void_p)]
+
+    class Level(C.Structure):
+        _fields_ = [('rows', C.c_int), ('indices', C.c_void_p), ('nbr', C.c_void_p), ('subm', PlanPtrs),
+                    ('in2out', C.c_void_p), ('child', C.c_void_p), ('down', PlanPtrs),
+                    ('inv', C.c_void_p), ('up', PlanPtrs)]
+
+    M0 = len(idx)
+    d_idx = t(idx)
+    shp = (C.c_int32 * 3)(*shape)
+    ws = L.workspace(lib.sg_spconv_pyramid_workspace_bytes(M0, n_levels), DEV)
+    rows_dev = torch.full((n_levels, ), -7, dtype=torch.int32, device=DEV)
+    L.check(lib.sg_spconv_pyramid_rows(L.ptr(d_idx), M0, shp, n_levels, L.ptr(rows_dev), L.ptr(ws),
+                                       ws.numel(), L.stream()), 'sg_spconv_pyramid_rows')
+    rows = rows_dev.tolist()
+    lv = (Level * n_levels)()
+    keep = []
+
+    def buf(n, dtype=torch.int32):
+        b = torch.full((max(int(n), 1), ), -99, dtype=dtype, device=DEV)
+        keep.append(b)
+        return b
+
+    out = []
+    for l in range(n_levels):
+        r, r2 = rows[l], rows[l + 1] if l + 1 < n_levels else 0
+        T, T2 = (r + 31) // 32, (r2 + 31) // 32
+        d = dict(rows=r, indices=buf(r * 4), nbr=buf(r * 27), subm=(buf(T * 32), buf(T), buf(T * 32 * 27)))
+        lv[l].rows = r
+        lv[l].indices, lv[l].nbr = d['indices'].data_ptr(), d['nbr'].data_ptr()
+        lv[l].subm = PlanPtrs(*[x.data_ptr() for x in d['subm']])
+        if l + 1 < n_levels:
+            d.update(in2out=buf(r), child=buf(r2 * 8), inv=buf(r * 8),
+                     down=(buf(T2 * 32), buf(T2), buf(T2 * 32 * 8)), up=(buf(T * 32), buf(T), buf(T * 32 * 8)))
+            lv[l].in2out, lv[l].child, lv[l].inv = (d[k].data_ptr() for k in ('in2out', 'child', 'inv'))
+            lv[l].down = PlanPtrs(*[x.data_ptr() for x in d['down']])
+            lv[l].up = PlanPtrs(*[x.data_ptr() for x in d['up']])
+        out.append(d)
+    ws2 = L.workspace(lib.sg_spconv_pyramid_build_workspace_bytes(C.byref(lv), n_levels), DEV)
+    L.check(lib.sg_spconv_pyramid_build(L.ptr(d_idx), M0, shp, n_levels, C.byref(lv), L.ptr(ws), ws.numel(),
+                                        L.ptr(ws2), ws2.numel(), L.stream()), 'sg_spconv_pyramid_build')
+    torch.cuda.synchronize()
+    return rows, out
+
+
+def _check_plan(plan, nbr, rows, K):
+    """a tile plan is valid for its table and equals the per-level planner's (same keys, stable)"""
+    order, tmask, ntiles = (x.cpu().numpy() for x in plan)
+    T = (rows + 31) // 32
+    if rows == 0:
+        return
+    order = order[:T * 32].reshape(T, 32)
+    valid = order >= 0
+    assert valid.sum() == rows and np.array_equal(np.sort(order[valid]), np.arange(rows))
+    mask = ((nbr >= 0) << np.arange(K)).sum(1).astype(np.uint32)
+    row_mask = np.where(valid, mask[np.clip(order, 0, None)], 0).astype(np.uint32)
+    tm = tmask[:T].view(np.uint32)
+    assert np.array_equal(tm, np.bitwise_or.reduce(row_mask, 1))
+    pop = np.array([bin(int(x)).count('1') for x in tm])
+    assert (np.diff(pop) <= 0).all()                                    # heaviest tiles first
+    exp = np.where(valid[:, :, None], nbr[np.clip(order, 0, None)], -1)
+    assert np.array_equal(ntiles[:T * 32 * K].reshape(T, 32, K), exp)
+    # identical row sequence to sg_spconv_plan (tiles of equal weight may be emitted in another order)
+    ref = core._Plan(t(nbr.astype(np.int32)), rows, K)
+    ro = ref.order.cpu().numpy().reshape(T, 32)
+    assert sorted(map(tuple, ro.tolist())) == sorted(map(tuple, order.tolist()))
+
+
+def test_whole_pyramid_index_build_equals_the_per_level_chain():
+    """sg_spconv_pyramid_rows / _build (all levels of a U-Net in a handful of launches, what
+    sg_unet_forward uses) against the per-level chain of the oracle: row counts, coordinates,
+    in2out / child / inverse tables, SubM tables bit-exact -- including the odd-extent drops at
+    every level -- and every tile plan valid and equal to the per-level planner's."""
     rng = np.random.default_rng(4)
-    for shape, n, B in (([129, 67, 35], 40000, 3), ([300, 250, 135], 120000, 1), ([20, 20, 20], 3000, 7),
-                        ([5, 3, 2], 30, 1)):
+    for shape, n, B, n_levels in (([129, 67, 35], 40000, 3, 5), ([300, 250, 135], 90000, 1, 7),
+                                  ([20, 20, 20], 3000, 7, 2), ([5, 3, 2], 30, 1, 4)):
         idx = _scene(rng, n, shape, B=B)
-        n_levels = 7
-        exp, cur, sh = [len(idx)], idx, list(shape)
-        for _ in range(n_levels - 1):
-            if len(cur):
-                cur, _, _, sh = oracle.down_rulebook(cur, sh)
-            exp.append(len(cur))
-        counts = torch.full((n_levels, ), -7, dtype=torch.int32, device=DEV)
-        ws = L.workspace(L.lib().sg_spconv_level_rows_workspace_bytes(len(idx), n_levels), DEV)
-        shp = (L.C.c_int32 * 3)(*shape)
-        L.check(L.lib().sg_spconv_level_rows(L.ptr(t(idx)), len(idx), shp, n_levels, L.ptr(counts),
-                                             L.ptr(ws), ws.numel(), L.stream()), 'sg_spconv_level_rows')
-        assert counts.tolist()[1:] == exp[1:], (shape, counts.tolist(), exp)
+        rows, lv = _pyramid(idx, shape, n_levels)
+        cur, sh = idx, list(shape)
+        for l in range(n_levels):
+            d = lv[l]
+            assert rows[l] == len(cur), (shape, l, rows, len(cur))
+            if len(cur) == 0:
+                break
+            assert np.array_equal(d['indices'].cpu().numpy()[:len(cur) * 4].reshape(-1, 4), cur)
+            nbr = oracle.subm_rulebook(cur, sh)
+            assert np.array_equal(d['nbr'].cpu().numpy()[:len(cur) * 27].reshape(-1, 27), nbr)
+            _check_plan(d['subm'], nbr, len(cur), 27)
+            if l + 1 == n_levels:
+                break
+            oi, in2out, child, osh = oracle.down_rulebook(cur, sh)
+            assert np.array_equal(d['in2out'].cpu().numpy()[:len(cur)], in2out)
+            assert np.array_equal(d['child'].cpu().numpy()[:len(oi) * 8].reshape(-1, 8), child)
+            k = (cur[:, 1] & 1) * 4 + (cur[:, 2] & 1) * 2 + (cur[:, 3] & 1)
+            inv = np.full((len(cur), 8), -1, np.int32)
+            inv[np.arange(len(cur)), k] = in2out
+            assert np.array_equal(d['inv'].cpu().numpy()[:len(cur) * 8].reshape(-1, 8), inv)
+            _check_plan(d['down'], child, len(oi), 8)
+            _check_plan(d['up'], inv, len(cur), 8)
+            cur, sh = oi, osh
 
 
 @pytest.mark.parametrize('cin,cout', [(6, 32), (32, 32), (64, 32), (64, 64), (96, 224), (32, 16), (3, 48)])
