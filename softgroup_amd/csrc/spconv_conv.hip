@@ -246,9 +246,9 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kMetaInts = kTileRows * kMaxK + kTileRows + 4;   // gather block, rows, mask
 
-template <int CK, int DEPTH, int TRACE>
-__global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
-                                                                    unsigned w_bytes) {
+template <int CK, int DEPTH, int TRACE, int WPE>
+__global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
+                                                                         unsigned w_bytes) {
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
   constexpr int NQ = HC / 4;   // dwordx4 loads per lane per operand per slice
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -257,8 +257,7 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int arow = lane & 31, ahalf = lane >> 5;
   float *red = reinterpret_cast<float *>(smem_raw);                  // [4 waves][16][64]
-  float *res_lds = red + kWavesPerWg * 16 * 64;                       // [16][64]
-  int32_t *meta_lds = reinterpret_cast<int32_t *>(res_lds + 16 * 64);   // [2][kMetaInts]
+  int32_t *meta_lds = reinterpret_cast<int32_t *>(red + kWavesPerWg * 16 * 64);   // [2][kMetaInts]
 
   const int G = gridDim.x;
   const int units_per_tile = p.col_units * p.ksplit;
@@ -522,8 +521,6 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
     mark(2);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) res_lds[(wave * 4 + rr) * 64 + lane] = resv[rr];
     publish(m, buf ^ 1);
     __syncthreads();
     mark(3);
@@ -536,18 +533,17 @@ __global__ void __launch_bounds__(256) gather_conv_persistent_kernel(ConvArgs p,
     {
       const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
       const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
-      float part[4][5];
+      float part[4][4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int reg = wave * 4 + rr;
 #pragma unroll
         for (int w = 0; w < kWavesPerWg; ++w) part[rr][w] = red[(w * 16 + reg) * 64 + lane];
-        part[rr][4] = res_lds[reg * 64 + lane];
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         float t = ((part[rr][0] + part[rr][1]) + part[rr][2]) + part[rr][3];
-        t += part[rr][4];
+        t += resv[rr];       // residual rows of THIS unit (requested by its setup, one unit ago)
         if (post) t = fmaxf(fmaf(t, c.ps, c.pb), 0.f);
         v[rr] = t;
         va[rr] = fmaxf(fmaf(t, c.as, c.ab), 0.f);
@@ -879,7 +875,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   if (persistent) {
     // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
     // XCD u % 8)
-    const size_t lds = (static_cast<size_t>(kWavesPerWg) * 16 * 64 + 16 * 64) * sizeof(float) +
+    const size_t lds = static_cast<size_t>(kWavesPerWg) * 16 * 64 * sizeof(float) +
                        2 * kMetaInts * sizeof(int32_t);
     static int num_cu = 0;
     if (num_cu == 0) {
@@ -894,28 +890,34 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // wave's time is the chain of its dependent memory round trips, not the matrix pipe.
     constexpr int kSliceCh = 16;
     static const int ring_small_env = getenv("SG_CONV_RING_SMALL") ? atoi(getenv("SG_CONV_RING_SMALL")) : 2;   // developer knob
-    static int occ_tab[3] = {0, 0, 0};     // resident workgroups per CU for ring depth 2, 4, 8
+    // register budget: 5 waves per SIMD (<= 96 VGPRs) by default; SG_CONV_WPE=6 selects the build
+    // held to 80 VGPRs, 6 workgroups per CU (developer knob for the occupancy A/B)
+    static const int wpe_env = getenv("SG_CONV_WPE") ? atoi(getenv("SG_CONV_WPE")) : 5;
+    const bool wpe6 = wpe_env >= 6;
+    static int occ_tab[4] = {0, 0, 0, 0};     // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves
     auto occupancy = [&](int which) {
       if (occ_tab[which] == 0) {
         int o = 0;
-        if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0>, 256, lds);
-        else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0>, 256, lds);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0>, 256, lds);
+        if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 5>, 256, lds);
+        else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0, 4>, 256, lds);
+        else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0, 2>, 256, lds);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
         if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
         occ_tab[which] = o < 1 ? 1 : o;
       }
       return occ_tab[which];
     };
-    int which = 0;
-    if (units <= static_cast<long long>(num_cu) * occupancy(0))      // single round of units
-      which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : 0;
+    int which = wpe6 ? 3 : 0;
+    if (units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
+      which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : which;
     const int occ = occupancy(which);
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 1) gather_conv_persistent_kernel<kSliceCh, 4, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else gather_conv_persistent_kernel<kSliceCh, 2, 0><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 3) gather_conv_persistent_kernel<kSliceCh, 2, 0, 6><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 1) gather_conv_persistent_kernel<kSliceCh, 4, 0, 4><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else gather_conv_persistent_kernel<kSliceCh, 2, 0, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
     };
     a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
     long long g = static_cast<long long>(num_cu) * occ;

@@ -389,12 +389,9 @@ __global__ void __launch_bounds__(256) pyr_link_kernel(const int32_t *__restrict
     const int k = (((c.y >> l) & 1) << 2) | (((c.z >> l) & 1) << 1) | ((c.w >> l) & 1);
     o.in2out[l][j] = up;
     if (up >= 0) o.child[l][static_cast<int64_t>(up) * 8 + k] = j;
-    int4 a = make_int4(-1, -1, -1, -1), b = a;
-    (k < 4 ? (k == 0 ? a.x : k == 1 ? a.y : k == 2 ? a.z : a.w)
-           : (k == 4 ? b.x : k == 5 ? b.y : k == 6 ? b.z : b.w)) = up;
     int4 *dst = reinterpret_cast<int4 *>(o.inv[l] + static_cast<int64_t>(j) * 8);
-    dst[0] = a;
-    dst[1] = b;
+    dst[0] = make_int4(k == 0 ? up : -1, k == 1 ? up : -1, k == 2 ? up : -1, k == 3 ? up : -1);
+    dst[1] = make_int4(k == 4 ? up : -1, k == 5 ? up : -1, k == 6 ? up : -1, k == 7 ? up : -1);
   }
 }
 
@@ -432,44 +429,32 @@ struct PlanSegs {
   int n, total_rows, total_tiles;
   PlanSeg s[kPyrMaxSegs];
 };
-__device__ __forceinline__ int seg_of_row(const PlanSegs &P, int g) {
-  int s = 0;
-  while (s + 1 < P.n && g >= P.s[s + 1].row_base) ++s;
-  return s;
-}
-__device__ __forceinline__ int seg_of_tile(const PlanSegs &P, int t) {
-  int s = 0;
-  while (s + 1 < P.n && t >= P.s[s + 1].tile_base) ++s;
-  return s;
-}
-
+// grid.y = segment (blocks past the segment's rows exit at once): the segment is block-uniform,
+// its descriptor comes straight from the kernel arguments through scalar loads
 __global__ void __launch_bounds__(256) plan_mask_all_kernel(PlanSegs P, uint32_t *__restrict__ mask,
                                                            int32_t *__restrict__ val,
                                                            int32_t *__restrict__ freq) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = g < P.total_rows;
-  const int seg = valid ? seg_of_row(P, g) : -1;
+  __shared__ int cnt[32];
+  const int seg = blockIdx.y;
+  const int rows = P.s[seg].rows, K = P.s[seg].K, row_base = P.s[seg].row_base;
+  if (blockIdx.x * 256 >= rows) return;
+  const int32_t *nbr = P.s[seg].nbr;
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
   uint32_t m = 0;
-  if (valid) {
-    const PlanSeg &S = P.s[seg];
-    const int32_t *row = S.nbr + static_cast<int64_t>(g - S.row_base) * S.K;
-    for (int k = 0; k < S.K; ++k) m |= (row[k] >= 0 ? 1u : 0u) << k;
-    mask[g] = m;
-    val[g] = g;
+  if (j < rows) {
+    const int32_t *row = nbr + static_cast<int64_t>(j) * K;
+    for (int k = 0; k < K; ++k) m |= (row[k] >= 0 ? 1u : 0u) << k;
+    mask[row_base + j] = m;
+    val[row_base + j] = row_base + j;
   }
-  // offset frequencies per segment: one atomic per (wave, offset) when the wave lies inside one
-  // segment (all but <= n waves), per lane otherwise
-  const int seg0 = __builtin_amdgcn_readfirstlane(seg);
-  if (__all(seg == seg0 || !valid)) {
-    if (seg0 >= 0) {
-      for (int k = 0; k < 32; ++k) {
-        const int c = __popcll(__ballot((m >> k) & 1u));
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&freq[seg0 * 32 + k], c);
-      }
-    }
-  } else if (valid) {
-    for (uint32_t mm = m; mm; mm &= mm - 1) atomicAdd(&freq[seg * 32 + (__ffs(static_cast<int>(mm)) - 1)], 1);
+  for (int k = 0; k < K; ++k) {
+    const int c = __popcll(__ballot((m >> k) & 1u));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[k], c);
   }
+  __syncthreads();
+  if (threadIdx.x < K && cnt[threadIdx.x]) atomicAdd(&freq[seg * 32 + threadIdx.x], cnt[threadIdx.x]);
 }
 
 // bit position of offset k in the sort key of its segment (plan_bit_positions per segment)
@@ -489,33 +474,39 @@ __global__ void plan_pos_all_kernel(PlanSegs P, const int32_t *__restrict__ freq
 
 __global__ void __launch_bounds__(256) plan_key_all_kernel(PlanSegs P, const int32_t *__restrict__ bitpos,
                                                           uint32_t *__restrict__ mask_to_key) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= P.total_rows) return;
-  const int seg = seg_of_row(P, g);
-  const uint32_t m = mask_to_key[g];
+  __shared__ int pos[32];
+  const int seg = blockIdx.y;
+  const int rows = P.s[seg].rows;
+  if (blockIdx.x * 256 >= rows) return;
+  if (threadIdx.x < 32) pos[threadIdx.x] = bitpos[seg * 32 + threadIdx.x];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= rows) return;
+  const int g = P.s[seg].row_base + j;
   uint32_t key = 0;
-  for (uint32_t mm = m; mm; mm &= mm - 1) {
-    const int k = __ffs(static_cast<int>(mm)) - 1;
-    key |= 1u << bitpos[seg * 32 + k];
-  }
+  for (uint32_t mm = mask_to_key[g]; mm; mm &= mm - 1) key |= 1u << pos[__ffs(static_cast<int>(mm)) - 1];
   mask_to_key[g] = key | (static_cast<uint32_t>(seg) << kPlanKeyBits);
 }
 
+// 256 sorted rows = 8 tiles per block, OR over each aligned 32-lane group (as plan_tiles_kernel)
 __global__ void __launch_bounds__(256) plan_tiles_all_kernel(PlanSegs P, const uint32_t *__restrict__ key_sorted,
                                                             const int32_t *__restrict__ bitpos,
                                                             uint32_t *__restrict__ tmask) {
-  const int T = blockIdx.x * 256 + threadIdx.x;
-  if (T >= P.total_tiles) return;
-  const int seg = seg_of_tile(P, T);
-  const PlanSeg &S = P.s[seg];
-  const int t = T - S.tile_base;
-  const int lo = t * 32, hi = min(lo + 32, S.rows);
-  uint32_t key = 0;
-  for (int r = lo; r < hi; ++r) key |= key_sorted[S.row_base + r];
-  key &= (1u << kPlanKeyBits) - 1u;
-  uint32_t m = 0;
-  for (int k = 0; k < S.K; ++k) m |= ((key >> bitpos[seg * 32 + k]) & 1u) << k;
-  tmask[T] = m;
+  __shared__ int pos[32];
+  const int seg = blockIdx.y;
+  const int rows = P.s[seg].rows, K = P.s[seg].K;
+  if (blockIdx.x * 256 >= rows) return;
+  if (threadIdx.x < 32) pos[threadIdx.x] = bitpos[seg * 32 + threadIdx.x];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  uint32_t key = j < rows ? key_sorted[P.s[seg].row_base + j] & ((1u << kPlanKeyBits) - 1u) : 0u;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) key |= __shfl_xor(key, o, 64);
+  if ((threadIdx.x & 31) == 0 && j < rows) {
+    uint32_t m = 0;
+    for (int k = 0; k < K; ++k) m |= ((key >> pos[k]) & 1u) << k;
+    tmask[P.s[seg].tile_base + (j >> 5)] = m;
+  }
 }
 
 // per segment: tiles by descending number of offsets, ties in ascending tile order (stable,
@@ -566,25 +557,29 @@ __global__ void __launch_bounds__(1024) plan_tile_order_all_kernel(PlanSegs P, c
   }
 }
 
+// grid = (tile blocks, segments)
 __global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const int32_t *__restrict__ val_sorted,
                                                            const uint32_t *__restrict__ tmask,
                                                            const int32_t *__restrict__ torder) {
-  for (int T2 = blockIdx.x; T2 < P.total_tiles; T2 += gridDim.x) {
-    const int seg = seg_of_tile(P, T2);
-    const PlanSeg &S = P.s[seg];
-    const int t2 = T2 - S.tile_base;
-    const int t = torder[T2];
-    const int K = S.K, per_tile = 32 * K;
-    if (threadIdx.x == 0) S.tile_mask[t2] = tmask[S.tile_base + t];
+  const int seg = blockIdx.y;
+  const int rows = P.s[seg].rows, K = P.s[seg].K, row_base = P.s[seg].row_base,
+            tile_base = P.s[seg].tile_base;
+  const int nt = (rows + 31) / 32, per_tile = 32 * K;
+  const int32_t *nbr = P.s[seg].nbr;
+  int32_t *order = P.s[seg].order, *nbr_tiles = P.s[seg].nbr_tiles;
+  uint32_t *tile_mask = P.s[seg].tile_mask;
+  for (int t2 = blockIdx.x; t2 < nt; t2 += gridDim.x) {
+    const int t = torder[tile_base + t2];
+    if (threadIdx.x == 0) tile_mask[t2] = tmask[tile_base + t];
     if (threadIdx.x < 32) {
       const int pos = t * 32 + threadIdx.x;
-      S.order[t2 * 32 + threadIdx.x] = pos < S.rows ? val_sorted[S.row_base + pos] - S.row_base : -1;
+      order[t2 * 32 + threadIdx.x] = pos < rows ? val_sorted[row_base + pos] - row_base : -1;
     }
     for (int e = threadIdx.x; e < per_tile; e += 256) {
       const int r = e / K, k = e - r * K;
       const int pos = t * 32 + r;
-      S.nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
-          pos < S.rows ? S.nbr[static_cast<int64_t>(val_sorted[S.row_base + pos] - S.row_base) * K + k] : -1;
+      nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
+          pos < rows ? nbr[static_cast<int64_t>(val_sorted[row_base + pos] - row_base) * K + k] : -1;
     }
   }
 }
@@ -850,7 +845,9 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
     set_error("sg_spconv_pyramid_build: build workspace too small");
     return SG_ERR_WORKSPACE;
   }
-  const int grid = static_cast<int>((R + 255) / 256);
+  int max_rows = 0;
+  for (int i = 0; i < P.n; ++i) max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
+  const dim3 grid((max_rows + 255) / 256, P.n);
   hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);
   plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
   plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
@@ -861,9 +858,9 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
   for (int n = P.n - 1; n > 0; n >>= 1) ++nbits;
   int rc = radix_sort_pairs(mask, val, static_cast<int64_t>(R), nbits, rs_ws, rs_bytes, stream, &ms, &vs);
   if (rc != SG_OK) return rc;
-  plan_tiles_all_kernel<<<(P.total_tiles + 255) / 256, 256, 0, stream>>>(P, ms, bitpos, tmask);
+  plan_tiles_all_kernel<<<grid, 256, 0, stream>>>(P, ms, bitpos, tmask);
   plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(P, tmask, torder);
-  plan_emit_all_kernel<<<min(P.total_tiles, 8192), 256, 0, stream>>>(P, vs, tmask, torder);
+  plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, vs, tmask, torder);
   return check_launch("sg_spconv_pyramid_build");
 }
 

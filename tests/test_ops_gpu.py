@@ -342,8 +342,9 @@ def test_instance_npoint_and_runs_vs_dense_masks():
     ms = rng.standard_normal((S, stride)).astype(np.float32)
     ms[pairs[:, 0] == 5] = -9.0                        # proposal 5: nothing above the threshold
     thr = -0.5
+    d_pairs, d_ms = t(pairs), t(ms)                    # named: alive until the launches are enqueued
     npoint = torch.empty((nP, nc), dtype=torch.int32, device=DEV)
-    L.check(lib.sg_instance_npoint(L.ptr(t(pairs)), L.ptr(t(ms)), S, stride, nc, thr, nP, L.ptr(npoint),
+    L.check(lib.sg_instance_npoint(L.ptr(d_pairs), L.ptr(d_ms), S, stride, nc, thr, nP, L.ptr(npoint),
                                    L.stream()), 'sg_instance_npoint')
     dense = np.zeros((nc, nP, N), np.int32)
     for i in range(nc):
@@ -360,7 +361,8 @@ def test_instance_npoint_and_runs_vs_dense_masks():
     ends = torch.empty(cap, dtype=torch.int32, device=DEV)
     bounds = torch.empty(len(kept) + 1, dtype=torch.int64, device=DEV)
     ws = L.workspace(lib.sg_instance_runs_workspace_bytes(len(kept), N), DEV)
-    L.check(lib.sg_instance_runs(L.ptr(t(pairs)), L.ptr(t(ms)), S, stride, nc, thr, L.ptr(t(inst_of)), nP,
+    d_inst = t(inst_of)
+    L.check(lib.sg_instance_runs(L.ptr(d_pairs), L.ptr(d_ms), S, stride, nc, thr, L.ptr(d_inst), nP,
                                  len(kept), N, L.ptr(starts), L.ptr(ends), L.ptr(bounds), cap,
                                  L.ptr(ws), ws.numel(), L.stream()), 'sg_instance_runs')
     b = bounds.cpu().numpy()
