@@ -11,9 +11,11 @@
 // whole-pyramid index build (sg_spconv_pyramid_rows / _build, spconv_rulebook.hip): ~30 launches
 // and one read-back of the level row counts for the entire U-Net, on an internal index stream;
 // the caller's stream waits for it once and then runs nothing but convolutions.
-// Runtime state (index stream, events, pinned read-back words) is kept per device; calls on one
-// device are serialised by a mutex (one forward owns the device's index stream at a time).
+// Runtime state (index stream, events, pinned read-back words) is kept per (device, caller
+// stream): concurrent scans on different streams do not share any of it.
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -297,9 +299,10 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
                "sg_unet_forward: level %d: planes must be a multiple of 4", l);
   if (num_rows == 0) return SG_OK;
   const int L = d->n_levels;
-  // ---- per-device runtime state
-  constexpr int kMaxDev = 64;
-  struct DeviceState {
+  // ---- runtime state per (device, caller's stream): callers that run scans concurrently on
+  //      several streams (one host thread each) get an index stream of their own and never wait for
+  //      each other; calls on the same stream are serialised by the state's mutex
+  struct StreamState {
     std::mutex mu;
     int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
     int32_t *dev_rows = nullptr;      // device
@@ -307,11 +310,18 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     hipEvent_t ev_start = nullptr, ev_index = nullptr;
     bool ready = false;
   };
-  static DeviceState states[kMaxDev];
+  static std::mutex table_mu;
+  static std::map<std::pair<int, hipStream_t>, StreamState *> table;
   int dev = 0;
-  SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev,
-             "sg_unet_forward: no current device");
-  DeviceState &st = states[dev];
+  SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "sg_unet_forward: no current device");
+  StreamState *stp = nullptr;
+  {
+    std::lock_guard<std::mutex> g(table_mu);
+    StreamState *&slot = table[std::make_pair(dev, as_stream(stream))];
+    if (slot == nullptr) slot = new StreamState();     // lives as long as the process
+    stp = slot;
+  }
+  StreamState &st = *stp;
   std::lock_guard<std::mutex> guard(st.mu);
   if (!st.ready) {
     SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,

@@ -14,6 +14,7 @@ What differs is how the forward is driven:
     [nProposal, N] int masks (reference softgroup.py:568-603).
 """
 import functools
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -28,6 +29,9 @@ from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encod
 from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
 from .blocks import MLP, ResidualBlock, UBlock
+
+
+_scan_local = threading.local()      # per worker thread: its HIP stream
 
 
 def _cfg(cfg, key, default=None):
@@ -75,6 +79,10 @@ class SoftGroup(nn.Module):
         self.fixed_modules = fixed_modules
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
         self.async_results = True    # host-side result formatting overlaps the next forward
+        self.scan_contexts = 1       # > 1: model(batch) hands the scan to one of that many worker
+        #                              threads (own HIP stream each) and returns at once -- several
+        #                              scans in flight keep the GPU busy across the host round trips
+        #                              and the latency-bound kernels of a single scan
 
         norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
 
@@ -119,7 +127,7 @@ class SoftGroup(nn.Module):
 
     # ---- derived state (packed weights, BatchNorm affines, native-executor descriptors, the
     #      results stream) is rebuilt on demand and never copied / pickled with the module
-    _DERIVED = ('_backbone_exec', '_tiny_exec', '_results_stream', '_grouping_const')
+    _DERIVED = ('_backbone_exec', '_tiny_exec', '_results_stream', '_grouping_const', '_scan_pool')
 
     def invalidate_caches(self):
         """Call after writing parameters/buffers through ``tensor.data`` (EMA copies, custom
@@ -154,13 +162,45 @@ class SoftGroup(nn.Module):
         return self
 
     def forward(self, batch, return_loss=False):
-        return self.forward_train(**batch) if return_loss else self.forward_test(**batch)
+        if return_loss:
+            return self.forward_train(**batch)
+        if self.scan_contexts > 1 and torch.cuda.is_available() and not torch.is_grad_enabled():
+            return self._submit_scan(batch)
+        return self.forward_test(**batch)
+
+    def _submit_scan(self, batch):
+        """Run forward_test for this batch on a worker thread with its own stream; the returned
+        dict resolves (waits) on first access, like the lazily formatted results."""
+        pool = self.__dict__.get('_scan_pool')
+        if pool is None or pool._max_workers != self.scan_contexts:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self.__dict__['_scan_pool'] = ThreadPoolExecutor(
+                max_workers=self.scan_contexts, thread_name_prefix='softgroup-scan')
+        dev = torch.cuda.current_device()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())        # the batch tensors are ready from here on
+        local = _scan_local
+
+        def job():
+            with torch.cuda.device(dev):
+                st = getattr(local, 'stream', None)
+                if st is None:
+                    st = local.stream = torch.cuda.Stream()
+                with torch.cuda.stream(st), torch.no_grad():
+                    st.wait_event(ready)
+                    out = self.forward_test(**batch, _inline_results=True)
+                    st.synchronize()
+            return dict(out)
+
+        ret = LazyResults(scan_id=batch['scan_ids'][0])
+        ret.defer(pool.submit(job))
+        return ret
 
     # ------------------------------------------------------------------ inference
     @cuda_cast
     def forward_test(self, batch_idxs, voxel_coords, p2v_map, v2p_map, coords_float, feats,
                      semantic_labels, instance_labels, pt_offset_labels, spatial_shape, batch_size,
-                     scan_ids, **kwargs):
+                     scan_ids, _inline_results=False, **kwargs):
         tcfg = self.test_cfg
         color_feats = feats
         if self.with_coords:
@@ -218,7 +258,7 @@ class SoftGroup(nn.Module):
                                                                    pred_instances))
             return out
 
-        if not (self.async_results and semantic_scores.is_cuda):
+        if _inline_results or not (self.async_results and semantic_scores.is_cuda):
             ret.update(finish())
             return ret
         main = torch.cuda.current_stream()
@@ -322,6 +362,7 @@ class SoftGroup(nn.Module):
             const[ck] = (torch.tensor(classes, device=dev),
                          torch.from_numpy(thr.astype(np.float32)).to(dev),
                          torch.zeros(2, dtype=torch.int32, device=dev))
+            torch.cuda.current_stream().synchronize()      # once: other streams may use them next
         cls_t, seg_thr, dummy_offsets = const[ck]
         sel = scores[:, cls_t].t() > _cfg(g, 'score_thr')                  # [n_seg, N]
         sel &= (sel.sum(1, keepdim=True) >= min_npoint)                    # small classes are skipped

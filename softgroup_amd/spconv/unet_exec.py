@@ -6,6 +6,7 @@ packed weights, eval-mode BatchNorm as scale/shift -- and runs it with one call 
 Used for inference only (no autograd through it); the module path launches the same kernels and
 remains the training path."""
 import ctypes as C
+import threading
 
 import torch
 from torch import nn
@@ -34,14 +35,17 @@ class _Desc(C.Structure):
                 ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p)]
 
 
+_desc_lock = threading.Lock()
 _ERR_WORKSPACE = -2     # SG_ERR_WORKSPACE (include/softgroup_hip.h)
-_arena = {}      # device -> uint8 tensor, grow-only
+_arena = {}      # (device, stream) -> uint8 tensor, grow-only: concurrent scans on different
+                 # streams never share an arena
 
 
 def _get_arena(nbytes, device):
-    t = _arena.get(device)
+    key = (device, L.stream())
+    t = _arena.get(key)
     if t is None or t.numel() < nbytes:
-        _arena[device] = t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _arena[key] = t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     return t
 
 
@@ -164,6 +168,10 @@ class UNetExecutor:
         return (core.cache_epoch(), ) + tuple((t._version, t.data_ptr()) for t in self._tensors())
 
     def _descriptor(self):
+        with _desc_lock:          # concurrent scans share the executor: build the descriptor once
+            return self._descriptor_locked()
+
+    def _descriptor_locked(self):
         key = self._state_key()
         if self._desc is None or key != self._key:
             self._keep = []
@@ -182,6 +190,9 @@ class UNetExecutor:
                 d.out_bn_scale, d.out_bn_shift = self._bn(ol[0])
             self._keep.append(larr)
             self._desc, self._key = d, key
+            # packed weights / affines were just written on THIS thread's stream; other streams
+            # (concurrent scans) will read them without an event in between: finish them now (once)
+            torch.cuda.current_stream().synchronize()
         return self._desc
 
     # ---- run
