@@ -410,6 +410,10 @@ int64_t sg_rle_format_bound(int64_t total_runs, int digits);
 int sg_rle_format_host(const int64_t *starts_host, const int64_t *lens_host,
                        const int64_t *bounds_host, int n_groups, char *out_host,
                        int64_t out_capacity, int64_t *out_offsets_host);
+/* same text from the output of sg_instance_runs (int32 starts and exclusive ends, copied to the host) */
+int sg_rle_format_runs_host(const int32_t *starts_host, const int32_t *ends_host,
+                            const int64_t *bounds_host, int n_groups, char *out_host,
+                            int64_t out_capacity, int64_t *out_offsets_host);
 
 #ifdef __cplusplus
 }

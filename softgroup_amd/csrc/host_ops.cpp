@@ -206,8 +206,11 @@ static inline char *put_dec(char *p, int64_t v) {
   }
   return e;
 }
-int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t *bounds,
-                       int n_groups, char *out, int64_t out_capacity, int64_t *out_offsets) {
+}  // extern "C"
+
+template <typename StartFn, typename LenFn>
+static int rle_format_impl(StartFn start_of, LenFn len_of, const int64_t *bounds, int n_groups, char *out,
+                           int64_t out_capacity, int64_t *out_offsets) {
   // One parallel region: every thread sizes its contiguous range of groups, the ranges' byte
   // totals are prefix-summed after a rendezvous, then every thread writes its groups.
   // out_capacity must be >= sg_rle_format_bound(total_runs); out_offsets[n_groups+1].
@@ -227,7 +230,7 @@ int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t
     for (int g = lo; g < hi; ++g) {
       int64_t bytes = 0;
       for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r)
-        bytes += dec_len(starts[r] + 1) + dec_len(lens[r]) + 2;
+        bytes += dec_len(start_of(r) + 1) + dec_len(len_of(r)) + 2;
       bytes = bytes > 0 ? bytes - 1 : 0;  // no trailing space
       out_offsets[g + 1] = bytes;          // local size, turned into an offset below
       total += bytes;
@@ -243,9 +246,9 @@ int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t
       char *p = out + base;
       for (int64_t r = bounds[g]; r < bounds[g + 1]; ++r) {
         if (r != bounds[g]) *p++ = ' ';
-        p = put_dec(p, starts[r] + 1);
+        p = put_dec(p, start_of(r) + 1);
         *p++ = ' ';
-        p = put_dec(p, lens[r]);
+        p = put_dec(p, len_of(r));
       }
       base += bytes;
       out_offsets[g + 1] = base;           // end offset of group g
@@ -265,6 +268,22 @@ int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t
     return SG_ERR_WORKSPACE;
   }
   return SG_OK;
+}
+
+extern "C" {
+
+int sg_rle_format_host(const int64_t *starts, const int64_t *lens, const int64_t *bounds,
+                       int n_groups, char *out, int64_t out_capacity, int64_t *out_offsets) {
+  return rle_format_impl([starts](int64_t r) { return starts[r]; }, [lens](int64_t r) { return lens[r]; },
+                         bounds, n_groups, out, out_capacity, out_offsets);
+}
+
+// the same from what sg_instance_runs produces: int32 run starts and exclusive ends
+int sg_rle_format_runs_host(const int32_t *starts, const int32_t *ends, const int64_t *bounds,
+                            int n_groups, char *out, int64_t out_capacity, int64_t *out_offsets) {
+  return rle_format_impl([starts](int64_t r) { return static_cast<int64_t>(starts[r]); },
+                         [starts, ends](int64_t r) { return static_cast<int64_t>(ends[r]) - starts[r]; },
+                         bounds, n_groups, out, out_capacity, out_offsets);
 }
 
 // upper bound of the text size for `total_runs` runs whose numbers are < 10^digits

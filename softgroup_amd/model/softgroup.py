@@ -589,9 +589,8 @@ class SoftGroup(nn.Module):
             b = bounds.cpu().numpy()
             n_runs = int(b[-1])
             assert n_runs <= cap, (n_runs, cap)
-            st = starts[:n_runs].cpu().numpy().astype(np.int64)
-            ln = ends[:n_runs].cpu().numpy().astype(np.int64) - st
-            masks = rle_encode_many(n_out, st, ln, b)
+            masks = rle_encode_many(n_out, starts[:n_runs].cpu().numpy(), None, b,
+                                    ends32=ends[:n_runs].cpu().numpy())
             return [dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
                          pred_mask=masks[k]) for k in range(n_kept)]
         sem_pred = semantic_scores.max(1)[1]

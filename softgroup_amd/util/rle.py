@@ -30,14 +30,19 @@ def rle_decode(rle):
     return mask
 
 
-def rle_encode_many(length, starts, lens, bounds):
+def rle_encode_many(length, starts, lens, bounds, ends32=None):
     """RLE dicts of many masks at once through the native formatter (sg_rle_format_host).
-    starts/lens: int64 arrays of all runs, bounds[g]..bounds[g+1] = runs of mask g."""
+    starts/lens: int64 arrays of all runs, bounds[g]..bounds[g+1] = runs of mask g.
+    With ``ends32``: starts / ends32 are the int32 arrays of sg_instance_runs (lens ignored)."""
     import ctypes as C
 
     from .. import _lib as L
-    starts = np.ascontiguousarray(starts, dtype=np.int64)
-    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    if ends32 is None:
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+    else:
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        lens = np.ascontiguousarray(ends32, dtype=np.int32)
     bounds = np.ascontiguousarray(bounds, dtype=np.int64)
     n = len(bounds) - 1
     offs = np.zeros(n + 1, dtype=np.int64)
@@ -45,8 +50,8 @@ def rle_encode_many(length, starts, lens, bounds):
     cap = int(lib.sg_rle_format_bound(len(starts), len(str(int(length) + 1))))
     buf = np.empty(cap, dtype=np.uint8)
     vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
-    L.check(lib.sg_rle_format_host(vp(starts), vp(lens), vp(bounds), n, vp(buf), cap, vp(offs)),
-            'sg_rle_format_host')
+    fmt = lib.sg_rle_format_host if ends32 is None else lib.sg_rle_format_runs_host
+    L.check(fmt(vp(starts), vp(lens), vp(bounds), n, vp(buf), cap, vp(offs)), 'sg_rle_format_host')
     o = offs.tolist()
     text = buf[:o[n]].tobytes().decode('ascii')        # one decode, then plain string slices
     length = int(length)

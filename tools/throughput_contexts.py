@@ -17,24 +17,26 @@ def main():
     batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     model = synthetic.build_model(seed=0)
-    K = 30
+    K = 60
     with torch.no_grad():
         model(batch).resolve()
         ref = model(batch)
         ref_masks = [p['pred_mask']['counts'] for p in ref['pred_instances']]
-        for c in ctxs:
-            model.scan_contexts = c
-            for r in [model(batch) for _ in range(2 * c)]:
-                r.resolve()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rets = [model(batch) for _ in range(K)]
-            for r in rets:
-                r.resolve()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            same = all([p['pred_mask']['counts'] for p in r['pred_instances']] == ref_masks for r in rets)
-            print(f'contexts {c}: {dt / K * 1e3:.2f} ms/scan, {K / dt:.1f} scans/s, results identical: {same}')
+        for rep in range(3):            # interleaved repetitions: run-to-run noise shows
+            for c in ctxs:
+                model.scan_contexts = c
+                for r in [model(batch) for _ in range(2 * c)]:
+                    r.resolve()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rets = [model(batch) for _ in range(K)]
+                for r in rets:
+                    r.resolve()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                same = all([p['pred_mask']['counts'] for p in r['pred_instances']] == ref_masks for r in rets)
+                print(f'rep {rep} contexts {c}: {dt / K * 1e3:.2f} ms/scan, {K / dt:.1f} scans/s, '
+                      f'results identical: {same}', flush=True)
 
 
 if __name__ == '__main__':
