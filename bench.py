@@ -15,6 +15,17 @@ Besides the headline line the JSON carries
   cpu_baseline  the CPU restatement of the reference model (oracle/, kind "port") timed on the
                 host cores of the same box on one scan of the same scene (rank 0, N=1 only)
   stages        per-stage milliseconds of the GPU path (HIP events), for orientation
+  parity_at_bench  the oracle's outputs on this very scene compared with the GPU's (not discarded)
+  legs          SURVEY 8(d)'s other measurement legs (rank 0, N=1): G1 grouping-head input with
+                roofline entries for the ball query and the BFS clustering, a 2x denser 300k-point
+                scene, the S1 config-1 backbone on the CPU (all cores and OMP_NUM_THREADS=1), and
+                the host-to-device inclusive rate of the S2 scan (device-side collate)
+
+The timed region keeps ``--contexts`` scans in flight (model.scan_contexts worker threads, one HIP
+stream each): a single scan has ~7 host<->device round trips and several latency-bound kernels
+(one workgroup replaying a BFS, 18-voxel U-Net levels), so the GPU is kept busy by overlapping
+scans, as a serving deployment would.  ``ms_per_step_unpipelined`` is one scan at a time with all
+result formatting in line (the latency figure).
 """
 import argparse
 import json
@@ -39,8 +50,10 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--points', type=int, default=150000)
+    ap.add_argument('--contexts', type=int, default=4, help='scans in flight in the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-legs', action='store_true')
     return ap.parse_args()
 
 
@@ -79,6 +92,133 @@ def stage_times(model, batch, reps=5):
     return {n: round(t, 3) for n, t in zip(names, acc)}, info
 
 
+
+def _events_ms(fn, reps=5, warm=2):
+    """mean milliseconds of fn() on the current stream (HIP events)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measurement_legs(args, model, batch, xyz, rgb, inst):
+    """SURVEY 8(d)'s other legs.  Bounded: a few seconds of GPU work, ~20 s of CPU work."""
+    import numpy as np
+    from softgroup_amd import ops, synthetic
+    legs = {}
+
+    # ---- G1: the grouping head on its own input (40 blobs x 1000 pts + 10 000 noise points,
+    #      r = 0.04, ~6.9 M neighbour pairs).  Algorithmic bytes of SURVEY 8(d):
+    #      ball query >= n*20 + nActive*4, BFS clustering >= nActive*12 + n*16 + S*8.
+    g1 = torch.from_numpy(synthetic.scene_g1(seed=2)).cuda()
+    n = g1.shape[0]
+    bi = torch.zeros(n, dtype=torch.int32, device='cuda')
+    bo = torch.tensor([0, n], dtype=torch.int32, device='cuda')
+    mean = torch.tensor([-1.0])
+    with torch.no_grad():
+        idx, sl = ops.ballquery_batch_p(g1, bi, bo, 0.04, 300)
+        ci, co = ops.bfs_cluster(mean, idx, sl, 100.0, 0)
+        n_active, S = int(idx.numel()), int(ci.shape[0])
+        t_bq = _events_ms(lambda: ops.ballquery_batch_p(g1, bi, bo, 0.04, 300))
+        t_bfs = _events_ms(lambda: ops.bfs_cluster(mean, idx, sl, 100.0, 0))
+    b_bq = n * 20 + n_active * 4
+    b_bfs = n_active * 12 + n * 16 + S * 8
+    legs['G1_grouping'] = {
+        'points': n, 'neighbour_pairs': n_active, 'clusters': int(co.numel() - 1), 'cluster_points': S,
+        'ball_query_ms': round(t_bq, 3), 'bfs_cluster_ms': round(t_bfs, 3),
+        'roofline': [
+            {'kernel': 'bq_* (hashed-grid ball query: grid build + count + fill)', 'bound': 'hbm',
+             'achieved': round(b_bq / t_bq / 1e6, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+             'frac': round(b_bq / t_bq / 1e6 / HBM_PEAK_GBPS, 4), 'algorithmic_bytes': b_bq},
+            {'kernel': 'bfs_* (union-find labelling + ordered emission)', 'bound': 'hbm',
+             'achieved': round(b_bfs / t_bfs / 1e6, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+             'frac': round(b_bfs / t_bfs / 1e6 / HBM_PEAK_GBPS, 4), 'algorithmic_bytes': b_bfs,
+             'note': 'the ordered emission replays the BFS level by level: bound by the number of '
+                     'levels of the largest cluster (latency), not by bytes'}],
+    }
+
+    # ---- a scene twice as dense (300k points in the same room): giant clusters, 5x the proposal
+    #      points -- the load real rooms with wall/floor-sized clusters put on the grouping head
+    dx, dr, di = synthetic.scene_s2(seed=1, n=2 * args.points)
+    dbatch = synthetic.make_batch(dx, dr, instance_labels=di)
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in dbatch.items()}
+    model.async_results = False
+    with torch.no_grad():
+        for _ in range(2):
+            model(dbatch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model(dbatch)
+        torch.cuda.synchronize()
+        dense_ms = (time.perf_counter() - t0) / 5 * 1e3
+        dstages, dinfo = stage_times(model, dbatch, reps=2)
+    model.async_results = True
+    legs['dense_scene'] = {'ms_per_scan_unpipelined': round(dense_ms, 3), 'stages_ms': dstages,
+                           'scene': dinfo}
+
+    # ---- host-to-device inclusive rate of the bench scan: raw points arrive in pinned host memory,
+    #      the voxel index is built on the device (data side of the reference: collate_fn's CPU
+    #      voxelization_idx + cuda_cast, data/custom.py:196-256, util/utils.py:157-173)
+    from softgroup_amd.data import collate_device, make_item
+    sample = make_item(xyz, rgb, 50, None, inst, 'synthetic_0000')
+    with torch.no_grad():
+        for _ in range(2):
+            model(collate_device([sample])).resolve()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rets = [model(collate_device([sample])) for _ in range(10)]
+        for r in rets:
+            r.resolve()
+        torch.cuda.synchronize()
+        legs['with_h2d'] = {'ms_per_step_with_h2d': round((time.perf_counter() - t0) / 10 * 1e3, 3),
+                            'note': 'one scan at a time; raw points pinned on the host -> async H2D -> '
+                                    'device voxel index (ops.voxelization_idx CUDA path) -> forward_test'}
+
+    # ---- S1 (BASELINE config 1): 20k-point cloud, 0.02 m voxels, backbone-only forward on the CPU
+    #      (the oracle's C/OpenMP sparse conv = the "port" of the spconv CPU path), all cores and
+    #      OMP_NUM_THREADS=1 (what tools/dist_test.sh:7 runs the reference with)
+    if not args.no_cpu_baseline:
+        import ctypes
+        import oracle
+        from oracle.model import OracleSoftGroup
+        oracle.build()
+        sx, sr = synthetic.scene_s1(seed=0)
+        sbatch = synthetic.make_batch(sx, sr)
+        cfg = dict(synthetic.SCANNET_MODEL_CFG, semantic_only=True)
+        ora = OracleSoftGroup(model.state_dict(), cfg)
+        t0 = time.perf_counter()
+        ora.point_wise(sbatch)
+        all_cores = time.perf_counter() - t0
+        one = None
+        try:
+            gomp = ctypes.CDLL('libgomp.so.1')
+            gomp.omp_set_num_threads(1)
+            t0 = time.perf_counter()
+            ora.point_wise(sbatch)
+            one = time.perf_counter() - t0
+            gomp.omp_set_num_threads(os.cpu_count())
+        except OSError:
+            pass
+        sb = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in sbatch.items()}
+        import softgroup_amd.spconv.pytorch as spconv
+        with torch.no_grad():
+            vf = ops.voxelization(torch.cat((sb['feats'], sb['coords_float']), 1), sb['p2v_map'])
+            x = spconv.SparseConvTensor(vf, sb['voxel_coords'].int(), sb['spatial_shape'], 1)
+            gpu_ms = _events_ms(lambda: model.forward_backbone(x, sb['v2p_map']))
+        legs['S1_backbone'] = {'points': int(sx.shape[0]), 'voxels': int(sb['voxel_coords'].shape[0]),
+                               'cpu_all_cores_s': round(all_cores, 3), 'cores': os.cpu_count(),
+                               'cpu_1_thread_s': None if one is None else round(one, 3),
+                               'gpu_ms': round(gpu_ms, 3), 'kind': 'port'}
+    return legs
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -109,9 +249,10 @@ def main():
     # forward_test returns as soon as the scan's GPU work is enqueued; turning its results into host
     # objects (numpy arrays, RLE mask strings) runs on the model's results thread and overlaps the
     # next scan.  Every one of the K result dicts is fully materialised inside the timed region.
+    model.scan_contexts = max(1, args.contexts)
     with torch.no_grad():
-        for _ in range(args.warmup):
-            model(batch).resolve()
+        for r in [model(batch) for _ in range(max(args.warmup, 1))]:
+            r.resolve()
         sync_all()
         t0 = time.perf_counter()
         rets = [model(batch) for _ in range(args.steps)]
@@ -142,12 +283,23 @@ def main():
             'baseline_note': 'vs_baseline = per-GPU scans/s / (1000/288): 288 ms/scan is the '
                              'reference README number on 1x Titan X with real ScanNet v2 data',
             'parallelism': f'scenes sharded one per GPU x{world}, no data-path collective',
+            'scans_in_flight': model.scan_contexts,
         },
     }
+    model.scan_contexts = 1
 
     if rank == 0:
-        # the same K scans with result formatting done in line (no overlap with the next scan), for
-        # reference next to the pipelined figure above
+        # one scan at a time: (a) with the result formatting of scan i overlapping scan i+1 on the
+        # results thread, (b) with everything in line -- the latency of a single scan
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rets = [model(batch) for _ in range(min(args.steps, 10))]
+            for r in rets:
+                r.resolve()
+            torch.cuda.synchronize()
+            out['ms_per_step_one_scan_at_a_time'] = round((time.perf_counter() - t1) / len(rets) * 1e3, 3)
+            del rets
         model.async_results = False
         with torch.no_grad():
             torch.cuda.synchronize()
@@ -198,13 +350,22 @@ def main():
         # passes, collected by the recipe in profiles/README.md on this workload and committed as
         # profiles/r01_conv_pmc.json).  FETCH_SIZE x2 is the guide's gfx950 correction for 16-B/lane
         # reads (MI355X_MICROARCH.md "HBM"); null when the file is not there.
-        traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv_pmc.json')
-        try:
-            pmc = json.load(open(pmc_path))['counters']
-            traffic = int((2 * pmc['FETCH_SIZE']['per_dispatch'] + pmc['WRITE_SIZE']['per_dispatch']) * 1024)
-        except (OSError, ValueError, KeyError):
-            pass
+        # NOT measured in this run (PMC needs rocprofv3 around the process): `traffic_source` says
+        # which committed counter file the figure comes from and which FETCH_SIZE factor was applied.
+        traffic, traffic_source = None, None
+        here = os.path.dirname(os.path.abspath(__file__))
+        for fn in ('r02_conv_pmc.json', 'r01_conv_pmc.json'):
+            try:
+                rec = json.load(open(os.path.join(here, 'profiles', fn)))
+                pmc = rec['counters']
+                factor = float(rec.get('fetch_size_factor', 2.0))
+                traffic = int((factor * pmc['FETCH_SIZE']['per_dispatch'] +
+                               pmc['WRITE_SIZE']['per_dispatch']) * 1024)
+                traffic_source = (f'profiles/{fn} (separate rocprofv3 --pmc run of the same workload; '
+                                  f'FETCH_SIZE x {factor:g} + WRITE_SIZE, per dispatch)')
+                break
+            except (OSError, ValueError, KeyError):
+                continue
         hbm = {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                'frac': round(gbps / HBM_PEAK_GBPS, 4)}
         mfma = {'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -215,7 +376,7 @@ def main():
         out['roofline'] = {
             'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv, fp32 MFMA)',
             'bound': bound, **(mfma if bound == 'mfma' else hbm),
-            'traffic': traffic,
+            'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_scan': s['launches'] // n_pass,
             'kernel_ms_per_scan': round(s['ms'] / n_pass, 3),
             'avg_launch_us': round(s['ms'] * 1e3 / launches, 2),
@@ -244,6 +405,9 @@ def main():
                       f'cores, single-thread brute-force ball query + BFS like the reference CPU ops; '
                       f'{cpu_s:.1f} s',
         }
+
+    if rank == 0 and world == 1 and not args.no_legs:
+        out['legs'] = measurement_legs(args, model, batch, xyz, rgb, inst)
 
     if rank == 0:
         print(json.dumps(out))

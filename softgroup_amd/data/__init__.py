@@ -1,0 +1,119 @@
+"""Data side of the hot path: the step right BEFORE ``forward_test``.
+
+The reference collates on the CPU -- ``collate_fn`` concatenates the samples, runs the
+single-threaded CPU ``voxelization_idx`` (data/custom.py:196-256, the call at :239) -- and then
+``@cuda_cast`` copies every tensor of the batch dict to the GPU with blocking, pageable
+``.cuda()`` calls (util/utils.py:157-173).  ``collate_device`` takes the SAME list of items
+(what ``CustomDataset.__getitem__`` returns, data/custom.py:170-194) and returns the SAME batch
+dict (keys, dtypes, values), but
+
+  * the per-field concatenation lands in pinned staging buffers (grow-only, reused) and goes to
+    the device with asynchronous copies on the current stream;
+  * the voxel index (``voxel_coords``, ``v2p_map``, ``p2v_map``) is built on the device by
+    ``ops.voxelization_idx`` (HIP path, bit-identical to the CPU op);
+  * ``spatial_shape`` comes from the host copy of the coordinates, so nothing is read back.
+
+Every tensor of the result is already resident: ``forward_test``'s ``cuda_cast`` is a no-op.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+_staging = {}     # (key, dtype) -> pinned tensor, grow-only
+
+
+def _pinned(key, shape, dtype):
+    n = int(np.prod(shape)) if len(shape) else 1
+    buf = _staging.get((key, dtype))
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+        _staging[(key, dtype)] = buf
+    return buf[:n].view(*shape)
+
+
+def _to_device(key, parts, dtype, device):
+    """torch.cat(parts) -> pinned staging -> async copy; returns the device tensor"""
+    parts = [p if p.dtype == dtype else p.to(dtype) for p in parts]
+    shape = (sum(p.shape[0] for p in parts), ) + tuple(parts[0].shape[1:])
+    host = _pinned(key, shape, dtype)
+    if len(parts) == 1:
+        host.copy_(parts[0])
+    else:
+        torch.cat(parts, 0, out=host)
+    dev = torch.empty(shape, dtype=dtype, device=device)
+    dev.copy_(host, non_blocking=True)
+    return dev
+
+
+def make_item(xyz, rgb, scale=50, semantic_label=None, instance_label=None, scan_id='scan'):
+    """The item tuple of ``CustomDataset.__getitem__`` for test-time data (transform_test without
+    the empirical rotation, data/custom.py:162-194): coordinates scaled and shifted to >= 0,
+    instance statistics (getInstanceInfo, :115-135)."""
+    n = xyz.shape[0]
+    xyz_middle = np.ascontiguousarray(xyz, dtype=np.float32)
+    v = xyz_middle.astype(np.float64) * scale
+    v -= v.min(0)
+    if instance_label is None:
+        instance_label = np.full(n, -100, np.int64)
+    if semantic_label is None:
+        semantic_label = np.where(instance_label >= 0, 2 + instance_label % 18, 0).astype(np.int64)
+    inst_ids = np.unique(instance_label[instance_label >= 0])
+    pointnum = [int((instance_label == i).sum()) for i in inst_ids]
+    inst_cls = [int(semantic_label[instance_label == i][0]) - 2 for i in inst_ids]
+    center = np.zeros((n, 3), np.float32)
+    for i in inst_ids:
+        m = instance_label == i
+        center[m] = xyz_middle[m].mean(0)
+    pt_offset = np.where((instance_label >= 0)[:, None], center - xyz_middle, 0).astype(np.float32)
+    return (scan_id, torch.from_numpy(v).long(), torch.from_numpy(xyz_middle),
+            torch.from_numpy(np.ascontiguousarray(rgb)).float(), torch.from_numpy(semantic_label),
+            torch.from_numpy(instance_label.astype(np.int64)), len(inst_ids), pointnum, inst_cls,
+            torch.from_numpy(pt_offset))
+
+
+def collate_device(batch, min_spatial=128, device='cuda'):
+    """Device-side ``collate_fn`` (data/custom.py:196-256): same input items, same batch dict."""
+    scan_ids, coords, coords_float, feats, sem, ins, pointnum, cls, offs = [], [], [], [], [], [], [], [], []
+    total_inst, batch_id = 0, 0
+    cmax = np.zeros(3, np.int64)
+    for data in batch:
+        if data is None:
+            continue
+        (scan_id, coord, coord_float, feat, semantic_label, instance_label, inst_num, inst_pointnum,
+         inst_cls, pt_offset_label) = data
+        if total_inst:
+            instance_label = instance_label.clone()
+            instance_label[instance_label != -100] += total_inst
+        total_inst += inst_num
+        scan_ids.append(scan_id)
+        coords.append(torch.cat([coord.new_full((coord.size(0), 1), batch_id), coord], 1))
+        cmax = np.maximum(cmax, coord.max(0)[0].numpy()) if coord.numel() else cmax
+        coords_float.append(coord_float)
+        feats.append(feat)
+        sem.append(semantic_label)
+        ins.append(instance_label)
+        pointnum.extend(inst_pointnum)
+        cls.extend(inst_cls)
+        offs.append(pt_offset_label)
+        batch_id += 1
+    assert batch_id > 0, 'empty batch'
+    dev = torch.device(device)
+    d_coords = _to_device('coords', coords, torch.int64, dev)
+    out = {
+        'scan_ids': scan_ids,
+        'coords': d_coords,
+        'batch_idxs': d_coords[:, 0].int(),
+        'coords_float': _to_device('coords_float', coords_float, torch.float32, dev),
+        'feats': _to_device('feats', feats, torch.float32, dev),
+        'semantic_labels': _to_device('semantic_labels', sem, torch.int64, dev),
+        'instance_labels': _to_device('instance_labels', ins, torch.int64, dev),
+        'instance_pointnum': torch.tensor(pointnum, dtype=torch.int).to(dev, non_blocking=True),
+        'instance_cls': torch.tensor(cls, dtype=torch.long).to(dev, non_blocking=True),
+        'pt_offset_labels': _to_device('pt_offset_labels', offs, torch.float32, dev),
+        'spatial_shape': np.clip(cmax + 1, min_spatial, None),
+        'batch_size': batch_id,
+    }
+    voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(d_coords, batch_id)   # device path
+    out.update(voxel_coords=voxel_coords, v2p_map=v2p_map, p2v_map=p2v_map)
+    return out

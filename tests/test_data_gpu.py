@@ -1,0 +1,65 @@
+"""Device-side collate (softgroup_amd.data.collate_device) against the reference's
+CPU collate semantics: same items in, same batch dict out -- every key, dtype and value -- with
+the voxel index built by the HIP voxelization_idx instead of the CPU op (data/custom.py:239)."""
+import numpy as np
+import pytest
+import torch
+
+from softgroup_amd import ops, synthetic
+from softgroup_amd.data import collate_device, make_item
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_collate(items, min_spatial=128):
+    """collate_fn as the reference runs it (data/custom.py:196-256), on the CPU"""
+    coords, total, bid = [], 0, 0
+    cf, ft, sem, ins, pn, cl, off = [], [], [], [], [], [], []
+    for (sid, coord, coord_float, feat, s, i, inum, ipn, icl, po) in items:
+        i = i.clone()
+        i[np.where(i != -100)] += total
+        total += inum
+        coords.append(torch.cat([coord.new_full((coord.size(0), 1), bid), coord], 1))
+        cf.append(coord_float); ft.append(feat); sem.append(s); ins.append(i)
+        pn.extend(ipn); cl.extend(icl); off.append(po)
+        bid += 1
+    coords = torch.cat(coords, 0)
+    vc, v2p, p2v = ops.voxelization_idx(coords, bid)           # CPU tensors -> host op
+    return dict(coords=coords, batch_idxs=coords[:, 0].int(), voxel_coords=vc, p2v_map=p2v, v2p_map=v2p,
+                coords_float=torch.cat(cf).float(), feats=torch.cat(ft), semantic_labels=torch.cat(sem).long(),
+                instance_labels=torch.cat(ins).long(), instance_pointnum=torch.tensor(pn, dtype=torch.int),
+                instance_cls=torch.tensor(cl, dtype=torch.long), pt_offset_labels=torch.cat(off).float(),
+                spatial_shape=np.clip(coords.max(0)[0][1:].numpy() + 1, min_spatial, None), batch_size=bid)
+
+
+def test_collate_device_equals_cpu_collate_two_scenes():
+    items = []
+    for seed, n in ((3, 20000), (4, 12000)):
+        xyz, rgb, inst = synthetic.scene_s2(seed=seed, n=n, room_scale=0.4)
+        items.append(make_item(xyz, rgb, 50, None, inst, f'scene{seed}'))
+    ref = _cpu_collate(items)
+    got = collate_device(items)
+    assert got['scan_ids'] == ['scene3', 'scene4'] and got['batch_size'] == 2
+    assert np.array_equal(got['spatial_shape'], ref['spatial_shape'])
+    for k, v in ref.items():
+        if isinstance(v, torch.Tensor):
+            g = got[k]
+            assert g.is_cuda and g.dtype == v.dtype and g.shape == v.shape, k
+            assert torch.equal(g.cpu(), v), k
+    # second call reuses the pinned staging buffers: results must not alias the first call's
+    again = collate_device(items[:1])
+    assert again['batch_size'] == 1 and torch.equal(got['coords'].cpu(), ref['coords'])
+
+
+def test_make_item_matches_make_batch_and_runs_the_model():
+    xyz, rgb, inst = synthetic.scene_s2(seed=5, n=20000, room_scale=0.37)
+    b_dev = collate_device([make_item(xyz, rgb, 50, None, inst, 'synthetic_0000')])
+    b_cpu = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    for k in ('coords', 'voxel_coords', 'p2v_map', 'v2p_map', 'coords_float', 'feats', 'instance_labels',
+              'semantic_labels', 'instance_pointnum', 'instance_cls', 'pt_offset_labels'):
+        assert torch.equal(b_dev[k].cpu(), b_cpu[k]), k
+    model = synthetic.build_model(seed=0)
+    with torch.no_grad():
+        a, b = model(b_dev), model(b_cpu)
+    assert len(a['pred_instances']) == len(b['pred_instances']) > 0
+    assert all(x['pred_mask'] == y['pred_mask'] for x, y in zip(a['pred_instances'], b['pred_instances']))

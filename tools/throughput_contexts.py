@@ -18,6 +18,9 @@ def main():
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     model = synthetic.build_model(seed=0)
     K = 60
+    if os.environ.get('SG_SWITCH'):
+        sys.setswitchinterval(float(os.environ['SG_SWITCH']))
+        print('switch interval', sys.getswitchinterval())
     with torch.no_grad():
         model(batch).resolve()
         ref = model(batch)
