@@ -415,6 +415,17 @@ int sg_rle_format_runs_host(const int32_t *starts_host, const int32_t *ends_host
                             const int64_t *bounds_host, int n_groups, char *out_host,
                             int64_t out_capacity, int64_t *out_offsets_host);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluation (ScanNetEval.assign_instances_for_scan, softgroup/evaluation/instance_eval.py:228-309):
+ * counts[p*n_slots + s] = number of points of prediction p's mask whose ground-truth slot is s.
+ * Masks come as runs: run r covers points run_start[r] .. run_start[r] + len(r) - 1 of prediction
+ * run_pred[r]; run_off[r] = sum of the lengths of runs < r (run_off[n_runs] = total_points).
+ * gt_slot[point] in [0, n_slots): index of the point's GT instance, n_slots-1 = void.
+ * ---------------------------------------------------------------------------------------- */
+int sg_eval_intersections(const int32_t *run_start, const int64_t *run_off, const int32_t *run_pred,
+                          int n_runs, int64_t total_points, const int32_t *gt_slot, int n_pred,
+                          int n_slots, int32_t *counts, sg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ SIGNATURES = {
     'sg_rle_format_bound': (_i64, [_i64, _i]),
     'sg_rle_format_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
     'sg_rle_format_runs_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    'sg_eval_intersections': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'sg_gather_rows_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     'sg_gather_rows_i64idx_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),

@@ -24,6 +24,7 @@ SOURCES = [
     ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
+    ('eval_ops.hip', ['-ffp-contract=off']),
     ('host_ops.cpp', ['-ffp-contract=off']),
 ]
 COMMON = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wall', '-Wno-unused-function',

@@ -20,29 +20,33 @@ import torch
 
 from .. import ops
 
-_staging = {}     # (key, dtype) -> pinned tensor, grow-only
+_staging = {}     # (key, dtype) -> [pinned tensor (grow-only), event of the last copy out of it]
 
 
 def _pinned(key, shape, dtype):
     n = int(np.prod(shape)) if len(shape) else 1
-    buf = _staging.get((key, dtype))
-    if buf is None or buf.numel() < n:
-        buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
-        _staging[(key, dtype)] = buf
-    return buf[:n].view(*shape)
+    slot = _staging.get((key, dtype))
+    if slot is None or slot[0].numel() < n:
+        slot = _staging[(key, dtype)] = [torch.empty(max(n, 1), dtype=dtype).pin_memory(), None]
+    if slot[1] is not None:
+        slot[1].synchronize()        # the previous batch's async copy has left the buffer
+    return slot, slot[0][:n].view(*shape)
 
 
 def _to_device(key, parts, dtype, device):
     """torch.cat(parts) -> pinned staging -> async copy; returns the device tensor"""
     parts = [p if p.dtype == dtype else p.to(dtype) for p in parts]
     shape = (sum(p.shape[0] for p in parts), ) + tuple(parts[0].shape[1:])
-    host = _pinned(key, shape, dtype)
+    slot, host = _pinned(key, shape, dtype)
     if len(parts) == 1:
         host.copy_(parts[0])
     else:
         torch.cat(parts, 0, out=host)
     dev = torch.empty(shape, dtype=dtype, device=device)
     dev.copy_(host, non_blocking=True)
+    if slot[1] is None:
+        slot[1] = torch.cuda.Event()
+    slot[1].record()
     return dev
 
 
