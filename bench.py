@@ -177,7 +177,16 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
         for r in rets:
             r.resolve()
         torch.cuda.synchronize()
-        legs['with_h2d'] = {'ms_per_step_with_h2d': round((time.perf_counter() - t0) / 10 * 1e3, 3),
+        ms_h2d = (time.perf_counter() - t0) / 10 * 1e3
+        del rets
+        # the host link of this box, for reading the figure: pinned -> device copy rate
+        hbuf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        dbuf = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+        link_ms = _events_ms(lambda: dbuf.copy_(hbuf, non_blocking=True), reps=5, warm=1)
+        scan_bytes = sum(v.numel() * v.element_size() for v in sample if isinstance(v, torch.Tensor))
+        legs['with_h2d'] = {'ms_per_step_with_h2d': round(ms_h2d, 3),
+                            'host_bytes_per_scan': int(scan_bytes),
+                            'pinned_h2d_GBps_on_this_box': round((64 << 20) / link_ms / 1e6, 2),
                             'note': 'one scan at a time; raw points pinned on the host -> async H2D -> '
                                     'device voxel index (ops.voxelization_idx CUDA path) -> forward_test'}
 

@@ -91,7 +91,7 @@ def collate_device(batch, min_spatial=128, device='cuda'):
             instance_label[instance_label != -100] += total_inst
         total_inst += inst_num
         scan_ids.append(scan_id)
-        coords.append(torch.cat([coord.new_full((coord.size(0), 1), batch_id), coord], 1))
+        coords.append(coord)
         cmax = np.maximum(cmax, coord.max(0)[0].numpy()) if coord.numel() else cmax
         coords_float.append(coord_float)
         feats.append(feat)
@@ -103,7 +103,19 @@ def collate_device(batch, min_spatial=128, device='cuda'):
         batch_id += 1
     assert batch_id > 0, 'empty batch'
     dev = torch.device(device)
-    d_coords = _to_device('coords', coords, torch.int64, dev)
+    # coords [N, 1+3] with the batch index in column 0, assembled directly in the staging buffer
+    n_total = sum(c.shape[0] for c in coords)
+    slot, host = _pinned('coords', (n_total, 4), torch.int64)
+    row = 0
+    for b, c in enumerate(coords):
+        host[row:row + c.shape[0], 0] = b
+        host[row:row + c.shape[0], 1:] = c
+        row += c.shape[0]
+    d_coords = torch.empty((n_total, 4), dtype=torch.int64, device=dev)
+    d_coords.copy_(host, non_blocking=True)
+    if slot[1] is None:
+        slot[1] = torch.cuda.Event()
+    slot[1].record()
     out = {
         'scan_ids': scan_ids,
         'coords': d_coords,

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects the round's measurement set on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r02
+# -> gpurun_out/<tag>_bench.json, _bench_under_rocprof.json, _kernel_stats.csv, _conv_by_grid.txt,
+#    _conv_pmc.{txt,json} (separate --pmc passes, --kernel-trace only), _calib.txt (FETCH/WRITE_SIZE
+#    on known byte counts).  Copy what should be judged into profiles/.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r02}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+rm -rf /tmp/prof
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof.err
+cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv 44 60 > $OUT/${TAG}_kernel_top.txt 2>&1
+python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) 44 > $OUT/${TAG}_conv_by_grid.txt 2>&1
+rm -f $OUT/${TAG}_conv_pmc.txt $OUT/${TAG}_conv_pmc.json
+for S in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD"; do
+  rm -rf /tmp/pmc
+  rocprofv3 --pmc $S --kernel-trace --output-format csv -d /tmp/pmc -- python $R/tools/conv_layers.py 150000 > /tmp/pmc.log 2>&1
+  echo "== $S" >> $OUT/${TAG}_conv_pmc.txt
+  python $R/tools/pmc_summary.py /tmp/pmc gather_conv_persistent_kernel --json $OUT/${TAG}_conv_pmc.json --scans 8 >> $OUT/${TAG}_conv_pmc.txt 2>&1
+done
+rm -f $OUT/${TAG}_calib.txt
+for S in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/cal
+  rocprofv3 --pmc $S --kernel-trace --output-format csv -d /tmp/cal -- $R/tools/micro/fetch_calib >> $OUT/${TAG}_calib.txt 2>/dev/null
+  echo "== $S" >> $OUT/${TAG}_calib.txt
+  python $R/tools/pmc_summary.py /tmp/cal _kernel >> $OUT/${TAG}_calib.txt 2>&1
+done
+rocprofv3 -L 2>/dev/null | grep -o "TA_[A-Z_a-z]*\|TCP_[A-Z_a-z]*" | sort -u | head -80 > $OUT/${TAG}_counters_ta_tcp.txt
+echo done
