@@ -606,7 +606,9 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
   bfs_flatten_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab);
   bfs_store_root_kernel<<<grid, 256, 0, stream>>>(n, w.lab, w.parent);  // parent := root_of
 
-  int32_t host_counters[4] = {0, 0, 0, 0};
+  int32_t *host_counters = pinned_words();      // [0..3] counters, [8] propagation flag
+  SG_REQUIRE(host_counters != nullptr, "sg_bfs_cluster_label: pinned allocation failed");
+  for (int i = 0; i < 4; ++i) host_counters[i] = 0;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1) {
       // asymmetric edges exist: propagate min labels to the fixed point, then redo the sizes
@@ -615,10 +617,10 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
         hipMemsetAsync(w.counters + 1, 0, 4, stream);
         bfs_propagate_kernel<<<grid_for(n_asym, 4, 256 * 16), 256, 0, stream>>>(
             bq_idxs, start_len, w.asym_nodes, n_asym, w.parent, w.lab, w.counters);
-        int32_t changed = 0;
-        hipMemcpyAsync(&changed, w.counters + 1, 4, hipMemcpyDeviceToHost, stream);
+        host_counters[8] = 0;
+        hipMemcpyAsync(host_counters + 8, w.counters + 1, 4, hipMemcpyDeviceToHost, stream);
         if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("bfs propagate");
-        if (!changed) break;
+        if (!host_counters[8]) break;
       }
       bfs_zero_size_kernel<<<grid, 256, 0, stream>>>(n, w.size);
     }
@@ -639,7 +641,7 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
     rc = exclusive_scan(keep_size, [coff] __device__(int64_t i, int v) { coff[i] = v; }, n,
                         w.counters + 3, w.scan_ws, w.scan_bytes, stream);
     if (rc != SG_OK) return rc;
-    hipMemcpyAsync(host_counters, w.counters, sizeof(host_counters), hipMemcpyDeviceToHost, stream);
+    hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
     if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("sg_bfs_cluster_label");
     if (host_counters[0] == 0) break;
   }

@@ -11,6 +11,7 @@ namespace sg {
 constexpr int kWave = 64;
 
 void set_error(const char *fmt, ...);
+int32_t *pinned_words();   // 64 pinned int32 of the calling host thread (core.hip), or null
 
 inline hipStream_t as_stream(sg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

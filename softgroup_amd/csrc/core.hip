@@ -9,6 +9,15 @@ namespace sg {
 
 static thread_local char g_err[512] = "";
 
+// per host thread: a small pinned buffer for device->host read-backs (a pageable destination makes
+// the runtime lock user pages for every copy, which was measured to cost milliseconds per call in
+// processes that also hold large pinned staging areas)
+int32_t *pinned_words() {
+  static thread_local int32_t *p = nullptr;
+  if (p == nullptr && hipHostMalloc(reinterpret_cast<void **>(&p), 256) != hipSuccess) p = nullptr;
+  return p;
+}
+
 void set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

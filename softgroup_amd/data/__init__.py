@@ -35,13 +35,14 @@ def _pinned(key, shape, dtype):
 
 def _to_device(key, parts, dtype, device):
     """torch.cat(parts) -> pinned staging -> async copy; returns the device tensor"""
-    parts = [p if p.dtype == dtype else p.to(dtype) for p in parts]
     shape = (sum(p.shape[0] for p in parts), ) + tuple(parts[0].shape[1:])
     slot, host = _pinned(key, shape, dtype)
-    if len(parts) == 1:
-        host.copy_(parts[0])
-    else:
-        torch.cat(parts, 0, out=host)
+    # plain single-threaded numpy copies: a torch CPU op would wake the whole intra-op thread pool
+    # (one thread per core) for a few MB and leave it spinning next to the launch thread
+    dst, row = host.numpy(), 0
+    for p in parts:
+        dst[row:row + p.shape[0]] = p.numpy()          # casts when the dtypes differ
+        row += p.shape[0]
     dev = torch.empty(shape, dtype=dtype, device=device)
     dev.copy_(host, non_blocking=True)
     if slot[1] is None:
@@ -87,12 +88,13 @@ def collate_device(batch, min_spatial=128, device='cuda'):
         (scan_id, coord, coord_float, feat, semantic_label, instance_label, inst_num, inst_pointnum,
          inst_cls, pt_offset_label) = data
         if total_inst:
-            instance_label = instance_label.clone()
-            instance_label[instance_label != -100] += total_inst
+            lab = instance_label.numpy().copy()
+            lab[lab != -100] += total_inst
+            instance_label = torch.from_numpy(lab)
         total_inst += inst_num
         scan_ids.append(scan_id)
         coords.append(coord)
-        cmax = np.maximum(cmax, coord.max(0)[0].numpy()) if coord.numel() else cmax
+        cmax = np.maximum(cmax, coord.numpy().max(0)) if coord.numel() else cmax
         coords_float.append(coord_float)
         feats.append(feat)
         sem.append(semantic_label)
@@ -106,10 +108,10 @@ def collate_device(batch, min_spatial=128, device='cuda'):
     # coords [N, 1+3] with the batch index in column 0, assembled directly in the staging buffer
     n_total = sum(c.shape[0] for c in coords)
     slot, host = _pinned('coords', (n_total, 4), torch.int64)
-    row = 0
+    dst, row = host.numpy(), 0
     for b, c in enumerate(coords):
-        host[row:row + c.shape[0], 0] = b
-        host[row:row + c.shape[0], 1:] = c
+        dst[row:row + c.shape[0], 0] = b
+        dst[row:row + c.shape[0], 1:] = c.numpy()
         row += c.shape[0]
     d_coords = torch.empty((n_total, 4), dtype=torch.int64, device=dev)
     d_coords.copy_(host, non_blocking=True)

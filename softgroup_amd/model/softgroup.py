@@ -438,16 +438,20 @@ class SoftGroup(nn.Module):
     def pyramid_inverse_map(self, proposals_idx, proposals_offset, num_points, l2p_map):
         """expand level voxels back to the class's points: proposal p contains point j iff it
         contains voxel l2p_map[j]; rows ordered (proposal, point) ascending like the reference's
-        dense nonzero (softgroup.py:500-507)."""
+        dense nonzero (softgroup.py:500-507).  The reference builds an int [nProposal, n] matrix
+        for this (GBs at STPLS3D scale); clusters of one class are disjoint, so a voxel -> proposal
+        table and one stable sort of the points by proposal give the same rows in O(n) memory."""
         dev = proposals_idx.device
         n_prop = proposals_offset.numel() - 1
-        n_orig = l2p_map.numel()
-        member = torch.zeros((n_prop, num_points), dtype=torch.bool, device=dev)
-        member[proposals_idx[:, 0].long(), proposals_idx[:, 1].long()] = True
-        expanded = member[:, l2p_map.long().to(dev)]
-        assert expanded.shape[1] == n_orig
-        pidx = expanded.nonzero().int()
-        counts = expanded.sum(1)
+        prop_of_voxel = torch.full((num_points, ), -1, dtype=torch.long, device=dev)
+        prop_of_voxel[proposals_idx[:, 1].long()] = proposals_idx[:, 0].long()
+        prop_of_point = prop_of_voxel[l2p_map.long().to(dev)]              # [n_orig]
+        pts = (prop_of_point >= 0).nonzero().view(-1)                       # ascending point index
+        order = torch.argsort(prop_of_point[pts], stable=True)              # proposal-major, points ascending
+        pts = pts[order]
+        prop = prop_of_point[pts]
+        pidx = torch.stack([prop, pts], 1).int()
+        counts = torch.bincount(prop, minlength=n_prop)
         poff = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
         return pidx, poff
 
