@@ -281,22 +281,10 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       const_cast<float *>(add_res ? p.residual : p.in), 0, add_res ? out_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ps = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(post ? p.post_scale : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(post ? p.post_shift : p.in), 0, post ? p.Cout * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_as = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(act ? p.act_scale : p.in), 0, act ? p.Cout * 4u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ab = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(act ? p.act_shift : p.in), 0, act ? p.Cout * 4u : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
       act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int32_t *>(p.nbr_tiles), 0, static_cast<unsigned>(num_tiles) * tileK * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ord = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int32_t *>(p.order), 0, static_cast<unsigned>(num_tiles) * kTileRows * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint32_t *>(p.tile_mask), 0, static_cast<unsigned>(num_tiles) * 4u, 0x00020000);
 
   // x / d for the few small wave-uniform divisors of the unit arithmetic: one s_mul_hi with a
   // host-made reciprocal (exact for x * d < 2^32; magic 0 means d == 1)
@@ -335,9 +323,10 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       const unsigned off = e < tileK ? static_cast<unsigned>(d.tile * tileK + e) * 4u : kOob;
       m.nbr[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, off, 0, 0);
     }
-    m.row = __builtin_amdgcn_raw_buffer_load_b32(
-        rs_ord, threadIdx.x < kTileRows ? static_cast<unsigned>(d.tile * kTileRows + threadIdx.x) * 4u : kOob, 0, 0);
-    m.mask = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, static_cast<unsigned>(d.tile) * 4u, 0, 0);
+    // row ids and the mask through plain loads: epilogue-only / per-unit data does not need buffer
+    // descriptors (every descriptor is 4 SGPRs of a kernel that was spilling SGPRs)
+    m.row = threadIdx.x < kTileRows ? p.order[d.tile * kTileRows + threadIdx.x] : 0;
+    m.mask = static_cast<int>(p.tile_mask[d.tile]);
   };
   // LDS block of a unit: [0, 32*K) gather block as fetched (stride K), then 32 rows, then the mask
   constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
@@ -432,10 +421,15 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
                                ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
       resv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
     }
-    c.ps = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ps, colc * 4, 0, 0));
-    c.pb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pb, colc * 4, 0, 0));
-    c.as = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_as, colc * 4, 0, 0));
-    c.ab = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ab, colc * 4, 0, 0));
+    c.ps = c.pb = c.as = c.ab = 0.f;
+    if (post) {            // uniform
+      c.ps = p.post_scale[colc];
+      c.pb = p.post_shift[colc];
+    }
+    if (act) {
+      c.as = p.act_scale[colc];
+      c.ab = p.act_shift[colc];
+    }
   };
 
   f32x16 acc;
