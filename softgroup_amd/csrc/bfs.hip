@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
     const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
-    int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats) {
+    int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats, int skip_above) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
   __shared__ int f_st[2][kFrontChunk], f_ln[2][kFrontChunk];
@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int seed = seeds[c];
     const int off = cluster_offsets[c];
     const int size = cluster_offsets[c + 1] - off;
+    if (size > skip_above) continue;        // giant clusters: bfs_emit_big_kernel (all workgroups)
     const bool own_in_lds = size <= kOwnCap;
     int32_t *Q = cluster_idxs + 2LL * off;  // pairs (cluster id, point); queue = column 1
     if (own_in_lds)
@@ -568,6 +569,178 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------- D'. giant clusters
+// A cluster with tens of thousands of points (a floor, a wall) has BFS levels with 10^4..10^5
+// edges; replayed by ONE workgroup such a level is bound by a single CU's memory pipe (~45 us).
+// Here kBigWgs workgroups replay the cluster together, level by level, with a grid barrier
+// (agent-scope release / counter / acquire, cdna_hip_programming.md Guideline 16) between the
+// three phases of a level:
+//   claim   every edge (frontier rank q, list position p) proposes pos = q*1024 + p (p < 1000) to
+//           its unvisited target with a device-scope atomicMin -- the same total order as the
+//           sequential queue, so the winner of a node is its BFS parent edge;
+//   count   winners per frontier node (each workgroup owns a contiguous range of the frontier),
+//           one total per workgroup;
+//   append  workgroup b starts at tail + (totals of workgroups < b): winners in (node, position)
+//           order go to the queue and become visited.
+// Every spin is bounded: a barrier that does not complete sets `fail` and all workgroups leave
+// (the host then reports an error instead of hanging the GPU).
+constexpr int kBigWgs = 64;
+constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
+
+__device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *fail, int *lds_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = (epoch + 1) * static_cast<int>(gridDim.x);
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if ((++spins & 255u) == 0u) {
+        if (spins > (1u << 22) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = ok;
+  }
+  ++epoch;
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+__global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
+    const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
+    const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
+    int32_t *owner_g, int32_t *wcnt, int32_t *cluster_idxs, int32_t *sync /* [0] barrier [1] fail [2..] totals */) {
+  __shared__ int lds_scan[kEmitWaves];
+  __shared__ int lds_flag, lds_base, lds_total;
+  __shared__ int node_off[kEmitThreads];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int G = gridDim.x, b = blockIdx.x;
+  int32_t *bar = sync, *fail = sync + 1, *tot = sync + 64;      // tot[2][G]
+  int epoch = 0, parity = 0;
+  for (int c = 0; c < n_cluster; ++c) {
+    const int off = cluster_offsets[c];
+    const int size = cluster_offsets[c + 1] - off;
+    if (size <= kBigMin) continue;                               // uniform over the grid
+    const int seed = seeds[c];
+    int32_t *Q = cluster_idxs + 2LL * off;
+    if (b == 0 && threadIdx.x == 0) {
+      SG_ST(&Q[0], c);
+      SG_ST(&Q[1], seed);
+      SG_ST(&owner_g[seed], -1);
+    }
+    if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+    int head = 0, tail = 1;
+    while (head < tail) {
+      const int L = tail - head;
+      const int lo = static_cast<int>(static_cast<long long>(L) * b / G);
+      const int hi = static_cast<int>(static_cast<long long>(L) * (b + 1) / G);
+      // ---- claim
+      for (int q = lo + wave; q < hi; q += kEmitWaves) {
+        const int v = SG_LD(&Q[2 * (head + q) + 1]);
+        const int4 rec = node_rec[v];
+        for (int p = lane; p < rec.w; p += 64) {
+          const int g = rec.z + p;
+          if ((erec[g].x & 0xffff) == 0xffff) continue;          // target in another cluster
+          const int t = idx[g];
+          const int pos = (q << 10) | p;
+          if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+        }
+      }
+      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      // ---- count
+      int my_total = 0;
+      for (int q = lo + wave; q < hi; q += kEmitWaves) {
+        const int v = SG_LD(&Q[2 * (head + q) + 1]);
+        const int4 rec = node_rec[v];
+        int wins = 0;
+        for (int p0 = 0; p0 < rec.w; p0 += 64) {
+          const int p = p0 + lane;
+          bool win = false;
+          if (p < rec.w) {
+            const int g = rec.z + p;
+            if ((erec[g].x & 0xffff) != 0xffff) win = SG_LD(&owner_g[idx[g]]) == ((q << 10) | p);
+          }
+          wins += __popcll(__ballot(win));
+        }
+        if (lane == 0) SG_ST(&wcnt[q], wins);
+        my_total += wins;                                        // per wave (uniform over its lanes)
+      }
+      if (lane == 0) lds_scan[wave] = my_total;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kEmitWaves; ++w) t += lds_scan[w];
+        SG_ST(&tot[parity * G + b], t);
+      }
+      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      // ---- append
+      if (threadIdx.x == 0) {
+        int base = 0, total = 0;
+        for (int w = 0; w < G; ++w) {
+          const int t = SG_LD(&tot[parity * G + w]);
+          if (w < b) base += t;
+          total += t;
+        }
+        lds_base = base;
+        lds_total = total;
+      }
+      __syncthreads();
+      const int total_new = lds_total;
+      int carry = tail + lds_base;
+      for (int c0 = lo; c0 < hi; c0 += kEmitThreads) {            // this workgroup's nodes, 512 at a time
+        const int q_mine = c0 + threadIdx.x;
+        const int cnt = q_mine < hi ? SG_LD(&wcnt[q_mine]) : 0;
+        int chunk_total;
+        const int ex = wg_excl_scan(cnt, lds_scan, &chunk_total);
+        node_off[threadIdx.x] = carry + ex;
+        __syncthreads();
+        const int n_here = min(kEmitThreads, hi - c0);
+        for (int j = wave; j < n_here; j += kEmitWaves) {
+          const int q = c0 + j;
+          const int v = SG_LD(&Q[2 * (head + q) + 1]);
+          const int4 rec = node_rec[v];
+          int o = node_off[j];
+          for (int p0 = 0; p0 < rec.w; p0 += 64) {
+            const int p = p0 + lane;
+            bool win = false;
+            int t = 0;
+            if (p < rec.w) {
+              const int g = rec.z + p;
+              if ((erec[g].x & 0xffff) != 0xffff) {
+                t = idx[g];
+                win = SG_LD(&owner_g[t]) == ((q << 10) | p);
+              }
+            }
+            const uint64_t bal = __ballot(win);
+            if (win) {
+              const int dst = o + mask_prefix(bal);
+              SG_ST(&Q[2 * dst], c);
+              SG_ST(&Q[2 * dst + 1], t);
+              SG_ST(&owner_g[t], -1);                            // only this edge matches pos
+            }
+            o += __popcll(bal);
+          }
+        }
+        carry += chunk_total;
+        __syncthreads();
+      }
+      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      head = tail;
+      tail += total_new;
+      parity ^= 1;
+    }
+  }
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -676,9 +849,21 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
     hipMalloc(&stats, 256 * 8 * 4);
     hipMemsetAsync(stats, 0, 256 * 8 * 4, stream);
   }
+  // giant clusters (> kBigMin points) are replayed by kBigWgs workgroups together; the per-cluster
+  // kernel skips them.  SG_BFS_BIG=0 (developer knob) keeps everything on the per-cluster kernel.
+  static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
-      stats);
+      stats, big_on ? kBigMin : 0x7fffffff);
+  if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
+    int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 2 * kBigWgs ints
+    if (static_cast<size_t>(n) >= 64 + 2 * kBigWgs) {
+      hipMemsetAsync(sync, 0, (64 + 2 * kBigWgs) * 4, stream);
+      bfs_emit_big_kernel<<<kBigWgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
+                                                              cluster_offsets, n_cluster, w.owner,
+                                                              w.wcnt, cluster_idxs, sync);
+    }
+  }
   if (want_stats) {
     int32_t h[256 * 8];
     hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost);
