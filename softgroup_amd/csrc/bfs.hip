@@ -585,29 +585,31 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
 //           order go to the queue and become visited.
 // Every spin is bounded: a barrier that does not complete sets `fail` and all workgroups leave
 // (the host then reports an error instead of hanging the GPU).
-constexpr int kBigWgs = 64;
+constexpr int kBigWgs = 32;
 constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
 
+// Everything the workgroups exchange (queue, claims, per-node counts, per-workgroup totals) is
+// written with device-scope write-through stores / atomics and read with sc1 loads that bypass the
+// CU's L1 (SG_ST / SG_LD / atomicMin), so the barrier needs no L2 write-back or L1 invalidate
+// (Guideline 16, form R1): every wave drains its stores, one lane arrives and polls.
 __device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *fail, int *lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int target = (epoch + 1) * static_cast<int>(gridDim.x);
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(4);
-      if ((++spins & 255u) == 0u) {
-        if (spins > (1u << 22) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u) {
+        if (spins > (1u << 24) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *lds_flag = ok;
   }
   ++epoch;
