@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
 // ---------------------------------------------------------------- D'. giant clusters
 // A cluster with tens of thousands of points (a floor, a wall) has BFS levels with 10^4..10^5
 // edges; replayed by ONE workgroup such a level is bound by a single CU's memory pipe (~45 us).
-// Here kBigWgs workgroups replay the cluster together, level by level, with a grid barrier
+// Here `big_wgs` workgroups (32: measured best on a 300k-point room, the barrier grows with the count) replay the cluster together, level by level, with a grid barrier
 // (agent-scope release / counter / acquire, cdna_hip_programming.md Guideline 16) between the
 // three phases of a level:
 //   claim   every edge (frontier rank q, list position p) proposes pos = q*1024 + p (p < 1000) to
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
 //           order go to the queue and become visited.
 // Every spin is bounded: a barrier that does not complete sets `fail` and all workgroups leave
 // (the host then reports an error instead of hanging the GPU).
-constexpr int kBigWgs = 32;
+constexpr int kBigWgsMax = 256;
 constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
 
 // Everything the workgroups exchange (queue, claims, per-node counts, per-workgroup totals) is
@@ -851,17 +851,19 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
     hipMalloc(&stats, 256 * 8 * 4);
     hipMemsetAsync(stats, 0, 256 * 8 * 4, stream);
   }
-  // giant clusters (> kBigMin points) are replayed by kBigWgs workgroups together; the per-cluster
+  // giant clusters (> kBigMin points) are replayed by many workgroups together; the per-cluster
   // kernel skips them.  SG_BFS_BIG=0 (developer knob) keeps everything on the per-cluster kernel.
   static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
       stats, big_on ? kBigMin : 0x7fffffff);
   if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
-    int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 2 * kBigWgs ints
-    if (static_cast<size_t>(n) >= 64 + 2 * kBigWgs) {
-      hipMemsetAsync(sync, 0, (64 + 2 * kBigWgs) * 4, stream);
-      bfs_emit_big_kernel<<<kBigWgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
+    static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 32;   // developer knob
+    const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
+    int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 2 * kBigWgsMax ints
+    if (static_cast<size_t>(n) >= 64 + 2 * kBigWgsMax) {
+      hipMemsetAsync(sync, 0, (64 + 2 * kBigWgsMax) * 4, stream);
+      bfs_emit_big_kernel<<<big_wgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
                                                               cluster_offsets, n_cluster, w.owner,
                                                               w.wcnt, cluster_idxs, sync);
     }
