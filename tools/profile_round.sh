@@ -10,11 +10,18 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# kernel trace + stats of the same command, one scan at a time (--contexts 1: kernel durations are
+# not stretched by overlapping scans, so the conv kernel's average agrees with roofline.avg_launch_us);
+# forwards in the trace: 8 warm-up + 10 timed + 10 + 10 + 5 stage + 1 + 5 roofline = 49
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --contexts 1 --steps 10 --warmup 8 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof.err
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv 49 60 > $OUT/${TAG}_kernel_top.txt 2>&1
 python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) 49 > $OUT/${TAG}_conv_by_grid.txt 2>&1
+# the same with 4 scans in flight (the timed region's mode): kernels of different scans overlap
+rm -rf /tmp/prof4
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof4 -o r -- python $R/bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-legs --no-roofline > $OUT/${TAG}_bench_under_rocprof_4ctx.json 2> /tmp/prof4.err
+cp $(find /tmp/prof4 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_4ctx.csv
 rm -f $OUT/${TAG}_conv_pmc.txt $OUT/${TAG}_conv_pmc.json
 for S in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD"; do
   rm -rf /tmp/pmc
