@@ -410,6 +410,17 @@ int64_t sg_rle_format_bound(int64_t total_runs, int digits);
 int sg_rle_format_host(const int64_t *starts_host, const int64_t *lens_host,
                        const int64_t *bounds_host, int n_groups, char *out_host,
                        int64_t out_capacity, int64_t *out_offsets_host);
+/* The same text produced on the device from the output of sg_instance_runs, without a host round trip
+ * in between (the run count is read from bounds[n_inst] on the device; run_capacity = the capacity
+ * given to sg_instance_runs, length = mask length): text (uint8, >= sg_rle_format_device_text_bytes)
+ * holds "start len " for every run in order; instance g's string is
+ * text[text_off[g] .. text_off[g+1] - 1) (the space after its last run excluded; empty when it has
+ * no run).  Only text[0 .. text_off[n_inst]) and the n_inst+1 offsets have to travel to the host. */
+size_t sg_rle_format_device_workspace_bytes(int64_t run_capacity);
+int64_t sg_rle_format_device_text_bytes(int64_t run_capacity, int64_t length);
+int sg_rle_format_device(const int32_t *starts, const int32_t *ends, const int64_t *bounds, int n_inst,
+                         int64_t run_capacity, int64_t length, uint8_t *text, int64_t text_capacity,
+                         int64_t *text_off, void *ws, size_t ws_bytes, sg_stream_t stream);
 /* same text from the output of sg_instance_runs (int32 starts and exclusive ends, copied to the host) */
 int sg_rle_format_runs_host(const int32_t *starts_host, const int32_t *ends_host,
                             const int64_t *bounds_host, int n_groups, char *out_host,

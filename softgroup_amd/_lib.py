@@ -72,6 +72,9 @@ SIGNATURES = {
     'sg_instance_runs': (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     'sg_rle_format_bound': (_i64, [_i64, _i]),
     'sg_rle_format_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    'sg_rle_format_device_workspace_bytes': (_sz, [_i64]),
+    'sg_rle_format_device_text_bytes': (_i64, [_i64, _i64]),
+    'sg_rle_format_device': (_i, [_vp, _vp, _vp, _i, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     'sg_rle_format_runs_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
     'sg_eval_intersections': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),

@@ -107,6 +107,52 @@ __global__ void __launch_bounds__(256) instance_runs_emit_kernel(const uint32_t 
   }
 }
 
+
+// ---- RLE text on the device: "start len start len ..." (1-based starts, util/rle.py:5-19) of every
+// kept instance straight from the run arrays, so that neither the runs (8 B each) nor a host-side
+// integer formatter are on the result path: one length pass, one scan, one digit pass, and the
+// text + one offset per instance go to the host.
+__device__ __forceinline__ int dec_digits(uint32_t v) {
+  return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5
+       : v < 1000000u ? 6 : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
+__device__ __forceinline__ void put_digits(uint8_t *p, uint32_t v, int n) {
+  for (int i = n - 1; i >= 0; --i) {
+    p[i] = static_cast<uint8_t>('0' + v % 10u);
+    v /= 10u;
+  }
+}
+// every run takes digits(start+1) + 1 + digits(len) + 1 bytes (a space after both numbers; the
+// space after an instance's last run is not part of its text)
+__device__ __forceinline__ int run_text_len(const int32_t *starts, const int32_t *ends, int64_t r) {
+  return dec_digits(static_cast<uint32_t>(starts[r] + 1)) + dec_digits(static_cast<uint32_t>(ends[r] - starts[r])) + 2;
+}
+__global__ void __launch_bounds__(256) rle_text_kernel(const int32_t *__restrict__ starts,
+                                                      const int32_t *__restrict__ ends,
+                                                      const int32_t *__restrict__ off,
+                                                      const int64_t *__restrict__ n_runs_p,
+                                                      int64_t capacity, uint8_t *__restrict__ text) {
+  const int64_t n_runs = *n_runs_p < capacity ? *n_runs_p : capacity;
+  for (int64_t r = blockIdx.x * 256LL + threadIdx.x; r < n_runs; r += gridDim.x * 256LL) {
+    const uint32_t s = static_cast<uint32_t>(starts[r] + 1), l = static_cast<uint32_t>(ends[r] - starts[r]);
+    const int ds = dec_digits(s), dl = dec_digits(l);
+    uint8_t *p = text + off[r];
+    put_digits(p, s, ds);
+    p[ds] = ' ';
+    put_digits(p + ds + 1, l, dl);
+    p[ds + 1 + dl] = ' ';
+  }
+}
+__global__ void __launch_bounds__(256) rle_offsets_kernel(const int64_t *__restrict__ bounds, int n_inst,
+                                                         const int32_t *__restrict__ off,
+                                                         const int32_t *__restrict__ total,
+                                                         int64_t *__restrict__ text_off) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g > n_inst) return;
+  const int64_t b = bounds[g];
+  text_off[g] = b < bounds[n_inst] ? off[b] : *total;
+}
+
 __global__ void instance_runs_total_kernel(const int32_t *__restrict__ total, int n_kept,
                                            int64_t *__restrict__ bounds) {
   bounds[n_kept] = *total;
@@ -176,6 +222,50 @@ int sg_instance_runs(const int32_t *proposals_idx, const float *mask_scores, int
                                                                         ends, bounds, runs_capacity);
   instance_runs_total_kernel<<<1, 1, 0, stream>>>(total, n_kept, bounds);
   return check_launch("sg_instance_runs");
+}
+
+
+size_t sg_rle_format_device_workspace_bytes(int64_t run_capacity) {
+  const int64_t n = run_capacity > 0 ? run_capacity : 1;
+  return align_up(static_cast<size_t>(n) * 4) + align_up(scan_workspace_bytes(n)) + 512;
+}
+
+int64_t sg_rle_format_device_text_bytes(int64_t run_capacity, int64_t length) {
+  int d = 1;
+  for (int64_t v = length + 1; v >= 10; v /= 10) ++d;
+  return (run_capacity > 0 ? run_capacity : 1) * (2LL * d + 2);
+}
+
+// the run count is read on the device (bounds[n_inst]): nothing has to come back to the host
+// between sg_instance_runs and this call
+int sg_rle_format_device(const int32_t *starts, const int32_t *ends, const int64_t *bounds, int n_inst,
+                         int64_t run_capacity, int64_t length, uint8_t *text, int64_t text_capacity,
+                         int64_t *text_off, void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(n_inst >= 0 && run_capacity >= 0 && bounds && text_off && length >= 0 && length < (1LL << 31),
+             "sg_rle_format_device: bad arguments");
+  const int64_t need = sg_rle_format_device_text_bytes(run_capacity, length);
+  SG_REQUIRE(need < (1LL << 31), "sg_rle_format_device: %lld runs exceed the 2 GiB text limit",
+             static_cast<long long>(run_capacity));
+  SG_REQUIRE(text != nullptr && text_capacity >= need,
+             "sg_rle_format_device: text buffer %lld < %lld bytes (sg_rle_format_device_text_bytes)",
+             static_cast<long long>(text_capacity), static_cast<long long>(need));
+  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_rle_format_device_workspace_bytes(run_capacity),
+             "sg_rle_format_device: workspace too small");
+  hipStream_t stream = as_stream(stream_);
+  const int64_t n = run_capacity > 0 ? run_capacity : 1;
+  Workspace a(ws, ws_bytes);
+  int32_t *off = a.take<int32_t>(n);
+  const size_t sbytes = scan_workspace_bytes(n);
+  void *sws = a.take<char>(sbytes);
+  int32_t *total = a.take<int32_t>(64);
+  const int64_t *n_runs_p = bounds + n_inst;
+  int rc = exclusive_scan(
+      [starts, ends, n_runs_p] __device__(int64_t r) { return r < *n_runs_p ? run_text_len(starts, ends, r) : 0; },
+      [off] __device__(int64_t r, int v) { off[r] = v; }, n, total, sws, sbytes, stream);
+  if (rc != SG_OK) return rc;
+  rle_text_kernel<<<grid_for(n, 256, 4096), 256, 0, stream>>>(starts, ends, off, n_runs_p, n, text);
+  rle_offsets_kernel<<<(n_inst + 256) / 256, 256, 0, stream>>>(bounds, n_inst, off, total, text_off);
+  return check_launch("sg_rle_format_device");
 }
 
 }  // extern "C"

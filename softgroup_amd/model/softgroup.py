@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..spconv import pytorch as spconv
-from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs
+from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs, rle_text_to_dicts
 from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
 from .blocks import MLP, ResidualBlock, UBlock
@@ -587,14 +587,20 @@ class SoftGroup(nn.Module):
                                          L.ptr(inst_of), n_inst, n_kept, n_out, L.ptr(starts),
                                          L.ptr(ends), L.ptr(bounds), cap, L.ptr(ws), ws.numel(),
                                          L.stream()), 'sg_instance_runs')
+            # the "start len ..." text is written on the device too: what travels to the host is the
+            # text itself and one offset per instance
+            tcap = int(lib.sg_rle_format_device_text_bytes(cap, n_out))
+            text = torch.empty(tcap, dtype=torch.uint8, device=dev)
+            text_off = torch.empty(n_kept + 1, dtype=torch.int64, device=dev)
+            ws = L.workspace(lib.sg_rle_format_device_workspace_bytes(cap), dev)
+            L.check(lib.sg_rle_format_device(L.ptr(starts), L.ptr(ends), L.ptr(bounds), n_kept, cap,
+                                             n_out, L.ptr(text), tcap, L.ptr(text_off), L.ptr(ws),
+                                             ws.numel(), L.stream()), 'sg_rle_format_device')
             score = (cls_prob[:, :nc] * iou_scores[:, :nc].clamp(0, 1))[kept[:, 1], kept[:, 0]]
             cls_pred = (kept[:, 0] + 1).cpu().numpy()
             score_pred = score.cpu().numpy()
-            b = bounds.cpu().numpy()
-            n_runs = int(b[-1])
-            assert n_runs <= cap, (n_runs, cap)
-            masks = rle_encode_many(n_out, starts[:n_runs].cpu().numpy(), None, b,
-                                    ends32=ends[:n_runs].cpu().numpy())
+            o = text_off.cpu().tolist()
+            masks = rle_text_to_dicts(n_out, text, o)
             return [dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
                          pred_mask=masks[k]) for k in range(n_kept)]
         sem_pred = semantic_scores.max(1)[1]

@@ -56,3 +56,30 @@ def rle_encode_many(length, starts, lens, bounds, ends32=None):
     text = buf[:o[n]].tobytes().decode('ascii')        # one decode, then plain string slices
     length = int(length)
     return [dict(length=length, counts=text[o[g]:o[g + 1]]) for g in range(n)]
+
+
+_TEXT_STAGE = {}
+
+
+def rle_text_to_dicts(length, text, offsets):
+    """RLE dicts from the device text of sg_rle_format_device: ``text`` is the uint8 CUDA tensor,
+    ``offsets`` the n+1 host offsets; mask g is text[offsets[g] : offsets[g+1] - 1] (the space
+    after its last run dropped).  One pinned copy of the used part of the text, one decode."""
+    import threading
+
+    import torch
+    n = len(offsets) - 1
+    total = int(offsets[n])
+    length = int(length)
+    if total == 0:
+        return [dict(length=length, counts='') for _ in range(n)]
+    key = (threading.get_ident(), text.device)
+    stage = _TEXT_STAGE.get(key)
+    if stage is None or stage.numel() < total:
+        stage = torch.empty(max(total * 2, 1 << 22), dtype=torch.uint8, pin_memory=True)
+        _TEXT_STAGE[key] = stage
+    stage[:total].copy_(text[:total], non_blocking=True)
+    torch.cuda.current_stream(text.device).synchronize()
+    s = str(memoryview(stage.numpy())[:total], 'ascii')
+    return [dict(length=length, counts=s[offsets[g]:max(offsets[g + 1] - 1, offsets[g])])
+            for g in range(n)]

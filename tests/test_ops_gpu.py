@@ -373,3 +373,65 @@ def test_instance_npoint_and_runs_vs_dense_masks():
         edges = np.flatnonzero(row[1:] != row[:-1])
         assert np.array_equal(st[b[k]:b[k + 1]], edges[0::2]), k
         assert np.array_equal(en[b[k]:b[k + 1]], edges[1::2]), k
+    # the text of the same runs, written on the device, equals rle_encode of the dense rows
+    from softgroup_amd.util import rle_encode, rle_text_to_dicts
+    tcap = int(lib.sg_rle_format_device_text_bytes(cap, N))
+    text = torch.empty(tcap, dtype=torch.uint8, device=DEV)
+    text_off = torch.empty(len(kept) + 1, dtype=torch.int64, device=DEV)
+    ws2 = L.workspace(lib.sg_rle_format_device_workspace_bytes(cap), DEV)
+    L.check(lib.sg_rle_format_device(L.ptr(starts), L.ptr(ends), L.ptr(bounds), len(kept), cap, N,
+                                     L.ptr(text), tcap, L.ptr(text_off), L.ptr(ws2), ws2.numel(),
+                                     L.stream()), 'sg_rle_format_device')
+    got = rle_text_to_dicts(N, text, text_off.cpu().tolist())
+    for k, (i, p) in enumerate(kept):
+        assert got[k] == rle_encode(dense[i, p]), k
+
+
+def test_rle_text_on_device_digit_boundaries_and_empty_instances():
+    """sg_rle_format_device on hand-made runs: starts / lengths at every power of ten, instances
+    without runs (first, middle, last), run capacity larger than the run count."""
+    from softgroup_amd import _lib as L
+    from softgroup_amd.util import rle_encode_runs, rle_text_to_dicts
+    lib = L.lib()
+    length = 2_000_000_000
+    st, ln = [], []
+    pos = 0
+    for d in range(0, 9):
+        for v in (10 ** d - 1, 10 ** d):              # start+1 = 10^d and 10^d + 1 -> digit steps
+            if v < pos:
+                continue
+            run = 10 ** (d % 4) - (1 if d % 2 else 0) or 1
+            st.append(v)
+            ln.append(run)
+            pos = v + run + 1
+    st, ln = np.asarray(st, np.int32), np.asarray(ln, np.int32)
+    R = len(st)
+    bounds = np.asarray([0, 0, 3, 3, 3, R - 1, R, R], np.int64)      # empty: 0, 2, 3, 6
+    n = len(bounds) - 1
+    cap = R + 100
+    d_st = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    d_en = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    d_st[:R] = t(st)
+    d_en[:R] = t(st + ln)
+    d_b = t(bounds)
+    tcap = int(lib.sg_rle_format_device_text_bytes(cap, length))
+    text = torch.empty(tcap, dtype=torch.uint8, device=DEV)
+    text_off = torch.empty(n + 1, dtype=torch.int64, device=DEV)
+    ws = L.workspace(lib.sg_rle_format_device_workspace_bytes(cap), DEV)
+    L.check(lib.sg_rle_format_device(L.ptr(d_st), L.ptr(d_en), L.ptr(d_b), n, cap, length, L.ptr(text),
+                                     tcap, L.ptr(text_off), L.ptr(ws), ws.numel(), L.stream()),
+            'sg_rle_format_device')
+    got = rle_text_to_dicts(length, text, text_off.cpu().tolist())
+    for g in range(n):
+        lo, hi = bounds[g], bounds[g + 1]
+        assert got[g] == rle_encode_runs(length, st[lo:hi], ln[lo:hi]), g
+    # no runs at all
+    d_b0 = torch.zeros(3, dtype=torch.int64, device=DEV)
+    L.check(lib.sg_rle_format_device(L.ptr(d_st), L.ptr(d_en), L.ptr(d_b0), 2, cap, length, L.ptr(text),
+                                     tcap, L.ptr(text_off), L.ptr(ws), ws.numel(), L.stream()),
+            'sg_rle_format_device')
+    assert rle_text_to_dicts(length, text, text_off[:3].cpu().tolist()) == \
+        [dict(length=length, counts='')] * 2
+    # a text buffer below the bound is refused
+    assert lib.sg_rle_format_device(L.ptr(d_st), L.ptr(d_en), L.ptr(d_b), n, cap, length, L.ptr(text),
+                                    tcap - 1, L.ptr(text_off), L.ptr(ws), ws.numel(), L.stream()) != 0
