@@ -317,12 +317,36 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
 int sg_spconv_profile(int enable);
 int sg_spconv_profile_read(double *total_ms, int *launches);
 
-/* Weight gradient of the same operator (training; spconv's backward reached through autograd,
- * tools/train.py:58): dw_kio[k][ci][co] += sum_j in[nbr[j,k]][ci] * g_out[j][co].  dw_kio is
- * [K][Cin][Cout], zero-filled by the caller.  The input gradient needs no extra entry point: it is
- * sg_spconv_gather_conv_f32 on the transposed gather table with transposed weights. */
-int sg_spconv_wgrad_f32(const float *in, const float *g_out, const int32_t *nbr, int num_out_rows,
-                        int kvol, int cin, int cout, float *dw_kio, sg_stream_t stream);
+/* ---- training side of the sparse convolution (csrc/spconv_train.hip; spconv's autograd reached from
+ * tools/train.py:47-58 under autocast) ---------------------------------------------------------
+ * bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16), bf16 result rounded to nearest even:
+ *   out[j,:] = bf16( sum_k in[nbr[j,k],:] . W[k] )
+ * Weights are packed from the fp32 master copy by sg_spconv_pack_weight_bf16 (layout
+ * [K][ceil16(Cin)/8][Cout][8] bf16, zero padded); order / tile_mask / nbr_tiles are the plan of
+ * sg_spconv_plan (all three, or none of them and `nbr` [M_out][K] instead).  ws: deep levels split the
+ * offsets and need sg_spconv_conv_bf16_workspace_bytes (may be NULL: no split).  The input gradient
+ * is the same entry point on the transposed gather table with transposed weights. */
+size_t sg_spconv_packed_weight_elems_bf16(int kvol, int cin, int cout);
+int sg_spconv_pack_weight_bf16(const float *w, int cout, int kvol, int cin, int src_is_kio,
+                               uint16_t *w_k8_bf16, sg_stream_t stream);
+size_t sg_spconv_conv_bf16_workspace_bytes(int num_out_rows, int cout);
+int sg_spconv_gather_conv_bf16(const uint16_t *in, int num_in_rows, const int32_t *nbr, int num_out_rows,
+                               int kvol, int cin, int cout, const uint16_t *w_k8_bf16,
+                               const int32_t *order, const uint32_t *tile_mask, const int32_t *nbr_tiles,
+                               uint16_t *out, void *ws, size_t ws_bytes, sg_stream_t stream);
+
+/* Weight gradient: dw_kio[k][ci][co] = sum_j in[nbr[j,k]][ci] * g_out[j][co]  ([K][Cin][Cout] fp32,
+ * overwritten).  in / g_out are fp32, or bf16 when the matching flag is set (widened on load; products
+ * and sums are fp32).  Row chunks are accumulated separately and added in chunk order: the result is
+ * bit-identical from run to run.  ws: sg_spconv_wgrad_workspace_bytes. */
+/* nbr_t is the gather table transposed to [K][M_out] (sg_spconv_transpose_table; one per rulebook,
+ * shared by all convs that use it): the kernel reads one offset's column at a time. */
+int sg_spconv_transpose_table(const int32_t *nbr, int num_out_rows, int kvol, int32_t *nbr_t,
+                              sg_stream_t stream);
+size_t sg_spconv_wgrad_workspace_bytes(int num_out_rows, int kvol, int cin, int cout);
+int sg_spconv_wgrad(const void *in, int in_is_bf16, const void *g_out, int g_is_bf16, const int32_t *nbr_t,
+                    int num_out_rows, int kvol, int cin, int cout, float *dw_kio, void *ws,
+                    size_t ws_bytes, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Native executor of the sparse U-Net (inference): the whole of

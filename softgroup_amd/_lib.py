@@ -66,7 +66,14 @@ SIGNATURES = {
     'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),
     'sg_spconv_gather_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'sg_spconv_wgrad_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'sg_spconv_packed_weight_elems_bf16': (_sz, [_i, _i, _i]),
+    'sg_spconv_pack_weight_bf16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'sg_spconv_conv_bf16_workspace_bytes': (_sz, [_i, _i]),
+    'sg_spconv_gather_conv_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _vp]),
+    'sg_spconv_transpose_table': (_i, [_vp, _i, _i, _vp, _vp]),
+    'sg_spconv_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'sg_spconv_wgrad': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sg_instance_npoint': (_i, [_vp, _vp, _i64, _i, _i, _f, _i, _vp, _vp]),
     'sg_instance_runs_workspace_bytes': (_sz, [_i, _i]),
     'sg_instance_runs': (_i, [_vp, _vp, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),

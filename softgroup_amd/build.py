@@ -22,6 +22,7 @@ SOURCES = [
     ('bfs.hip', ['-ffp-contract=off']),
     ('spconv_rulebook.hip', ['-ffp-contract=off']),
     ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
+    ('spconv_train.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
     ('eval_ops.hip', ['-ffp-contract=off']),

@@ -576,59 +576,6 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight gradient: dW[k][ci][co] += sum_j act_in[nbr[j,k]][ci] * g_out[j][co]   (training path;
-// reference: spconv's backward, called through autograd from tools/train.py:58).
-// grid = (row chunks, K).  A workgroup walks its rows two at a time: the MFMA A operand is the
-// transposed input row pair (lane (h,ci) <- in[row 2s+h][ci]), B the gradient row pair, so both
-// are 128-B coalesced row reads.  Each wave owns (ci-block, co-block) pairs round-robin and
-// accumulates 32x32 fp32 in registers; chunk partials are added with fp32 atomics (the sum over
-// chunks is the only non-deterministic step; chunks are large, ~1k rows).
-// ---------------------------------------------------------------------------------------------
-constexpr int kWgradRows = 1024;
-
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const float *__restrict__ in,
-                                                        const float *__restrict__ g_out,
-                                                        const int32_t *__restrict__ nbr, int M_out,
-                                                        int K, int Cin, int Cout,
-                                                        float *__restrict__ dw_kio) {
-  __shared__ int32_t src_lds[kWgradRows];
-  const int k = blockIdx.y;
-  const int r0 = blockIdx.x * kWgradRows;
-  const int nrows = min(kWgradRows, M_out - r0);
-  int any = 0;
-  for (int r = threadIdx.x; r < kWgradRows; r += 256) {
-    const int s = r < nrows ? nbr[static_cast<long long>(r0 + r) * K + k] : -1;
-    src_lds[r] = s;
-    any |= (s >= 0);
-  }
-  if (!__syncthreads_or(any)) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int col = lane & 31, half = lane >> 5;
-  const int nbi = (Cin + 31) / 32, nbo = (Cout + 31) / 32;
-  for (int pair = wave; pair < nbi * nbo; pair += 4) {
-    const int cib = pair / nbo, cob = pair % nbo;
-    const int ci = cib * 32 + col, co = cob * 32 + col;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int r = 0; r < nrows; r += 2) {
-      const int rr = r + half;
-      const int s = rr < nrows ? src_lds[rr] : -1;
-      const float a = (s >= 0 && ci < Cin) ? in[static_cast<long long>(s) * Cin + ci] : 0.f;
-      const float b = (s >= 0 && co < Cout) ? g_out[static_cast<long long>(r0 + rr) * Cout + co] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    // acc[reg] = dW[ci = cib*32 + (reg&3)+8*(reg>>2)+4*half][co = cob*32 + col]
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int cir = cib * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-      if (cir < Cin && co < Cout && acc[reg] != 0.f)
-        atomicAdd(&dw_kio[(static_cast<long long>(k) * Cin + cir) * Cout + co], acc[reg]);
-    }
-  }
-}
-
 // fixed-order reduction of the offset-split partial sums (+ residual, post)
 __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restrict__ partial,
                                                          const float4 *__restrict__ residual,
@@ -958,18 +905,6 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
         reinterpret_cast<float4 *>(out));
   }
   return check_launch("sg_spconv_gather_conv_f32");
-}
-
-// dw_kio [K][Cin][Cout] must be zero-filled by the caller; `in` is the (already activated) input
-// the forward conv gathered from.
-int sg_spconv_wgrad_f32(const float *in, const float *g_out, const int32_t *nbr, int M_out, int K,
-                        int Cin, int Cout, float *dw_kio, sg_stream_t stream_) {
-  SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
-             "sg_spconv_wgrad_f32: bad arguments");
-  if (M_out == 0) return SG_OK;
-  dim3 grid((M_out + kWgradRows - 1) / kWgradRows, K);
-  conv_wgrad_kernel<<<grid, 256, 0, as_stream(stream_)>>>(in, g_out, nbr, M_out, K, Cin, Cout, dw_kio);
-  return check_launch("sg_spconv_wgrad_f32");
 }
 
 }  // extern "C"

@@ -1,0 +1,653 @@
+// spconv_train.hip -- the training side of the sparse convolution (BASELINE config 3: bf16
+// autocast, tools/train.py:47 + spconv's autograd): a bf16 forward / input-gradient kernel on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, and a deterministic weight gradient.
+//
+//   forward / dgrad   out[j,:] = bf16( sum_k in[nbr[j,k],:] . W[k] )          in, W, out: bf16
+//   wgrad             dW[k][ci][co] = sum_j in[nbr[j,k]][ci] * g[j][co]       in, g: fp32 | bf16
+//
+// Where the fp32 inference kernel (spconv_conv.hip) is bound by the matrix pipe, the bf16 MFMA
+// retires a 16-channel slice of a 32x32 tile in 32 cycles -- 16x faster per byte of operand -- so
+// this kernel is bound by operand delivery (gather + weights through the CU's vector memory
+// path), not by MFMA.  The design follows from that:
+//   * one wave = one (32-row tile, up to 4 x 32 output columns, offset range) unit: the gathered
+//     A fragment (one 16-B load per lane and slice) is reused for all of the unit's column blocks;
+//   * the tile's gather block sits in LDS (wave-private), absent neighbours are buffer loads past
+//     the end (return 0), a 3-deep operand ring keeps two slices of loads in flight;
+//   * weights are packed [K][ceil16(Cin)/8][Cout][8] bf16 (zero padded): a lane's 8 reduction steps
+//     for its column are one 16-B read, a wave reads 1 KB fully coalesced per (slice, column block);
+//   * deep U-Net levels (few tiles) split the kernel offsets over several units; fp32 partial sums
+//     are reduced in a fixed order.
+// Weight gradient: grid = (row chunks, K); a workgroup walks its chunk two rows per fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: the products are exact, accumulation fp32 -- bf16 operands are widened
+// on load); every lane loads VI consecutive input channels and VO consecutive gradient channels
+// with one vector load each and feeds VI x VO MFMAs from them.  Chunk partials go to a workspace
+// and are added in chunk order by a second kernel: bit-identical from run to run (no atomics).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kTRows = 32;
+constexpr int kTMaxK = 27;
+constexpr unsigned kPast = 0x80000000u;   // byte offset past every (< 2 GB) buffer: loads return 0
+constexpr int kRing = 3;
+
+// round to nearest even, NaN kept quiet (the conversion torch's .to(torch.bfloat16) performs)
+__device__ __forceinline__ uint16_t to_bf16(float x) {
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+__device__ __forceinline__ float from_bf16(uint16_t h) {
+  return __builtin_bit_cast(float, static_cast<uint32_t>(h) << 16);
+}
+
+struct Bf16Args {
+  const uint16_t *in;
+  const int32_t *nbr;          // [M_out][K] (used when the plan arrays are absent)
+  const uint16_t *w;           // packed bf16
+  const int32_t *order;        // plan (all three or none)
+  const uint32_t *tile_mask;
+  const int32_t *nbr_tiles;
+  uint16_t *out;               // [M_out][Cout] bf16 (ksplit == 1)
+  float *partial;              // [ksplit][M_out][Cout] fp32 (ksplit > 1)
+  int M_out, K, Cin, Cout;
+  int col_units, blocks_per_unit, ksplit, k_per_split;
+  unsigned in_bytes, w_bytes;
+};
+
+template <int NBW, bool VEC>
+__global__ void __launch_bounds__(256) gather_conv_bf16_kernel(Bf16Args p) {
+  extern __shared__ __attribute__((aligned(16))) int32_t nbr_all[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int32_t *nbr_lds = nbr_all + wave * kTRows * kTMaxK;
+  const int arow = lane & 31, ahalf = lane >> 5;
+  const int c8p = (p.Cin + 15) / 16 * 2;     // 8-channel blocks of the padded reduction range
+  const int n_slices = c8p / 2;
+
+  const int num_tiles = (p.M_out + kTRows - 1) / kTRows;
+  const int units_per_tile = p.col_units * p.ksplit;
+  const long long unit = static_cast<long long>(blockIdx.x) * 4 + wave;
+  const bool valid = unit < static_cast<long long>(num_tiles) * units_per_tile;
+  const int tile = valid ? static_cast<int>(unit / units_per_tile) : 0;
+  const int sub = valid ? static_cast<int>(unit % units_per_tile) : 0;
+  const int cu = sub % p.col_units, ks = sub / p.col_units;
+  const int nb0 = cu * p.blocks_per_unit;
+  const int nbw = min(p.blocks_per_unit, (p.Cout + 31) / 32 - nb0);
+  const int k_lo = ks * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
+
+  int my_row = -1;
+  if (valid) {
+    const int pos = tile * kTRows + arow;
+    if (p.order) my_row = p.order[pos];         // plan order, padded with -1 to whole tiles
+    else if (pos < p.M_out) my_row = pos;
+    if (p.nbr_tiles) {
+      const int32_t *blk = p.nbr_tiles + static_cast<long long>(tile) * kTRows * p.K;
+      for (int e = lane; e < kTRows * p.K; e += 64) {
+        const int r = e / p.K;
+        nbr_lds[r * kTMaxK + (e - r * p.K)] = blk[e];
+      }
+    } else {
+      for (int e = lane; e < kTRows * p.K; e += 64) {
+        const int r = e / p.K, k = e - r * p.K;
+        const int row = __shfl(my_row, r, 64);
+        nbr_lds[r * kTMaxK + k] = row >= 0 ? p.nbr[static_cast<long long>(row) * p.K + k] : -1;
+      }
+    }
+  }
+  __syncthreads();          // the only barrier: gather blocks visible
+  if (!valid) return;
+
+  uint32_t mask = p.tile_mask ? p.tile_mask[tile] : 0xffffffffu;
+  mask &= ((k_hi >= 32 ? 0u : (1u << k_hi)) - 1u) & ~((1u << k_lo) - 1u);
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w), 0, p.w_bytes, 0x00020000);
+
+  const int col = nb0 * 32 + arow;
+  // surplus column blocks (n >= nbw) re-read the last real one: every load is unconditional
+  unsigned v_w[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) {
+    const int c = min(col + min(n, nbw - 1) * 32, p.Cout - 1);
+    v_w[n] = static_cast<unsigned>(ahalf * p.Cout + c) * 16u;
+  }
+
+  struct Slice { f4 a; f4 b[NBW]; };
+  auto load = [&](int k, int s, Slice &x) {
+    const int src = nbr_lds[arow * kTMaxK + k];
+    if (VEC) {
+      const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + ahalf * 8) * 2u : kPast;
+      x.a = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 32, 0));
+    } else {             // any Cin: element loads, channels past Cin are zeros
+      uint32_t w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = s * 16 + ahalf * 8 + 2 * j;
+        const uint32_t lo = (src >= 0 && c < p.Cin) ? p.in[static_cast<long long>(src) * p.Cin + c] : 0u;
+        const uint32_t hi = (src >= 0 && c + 1 < p.Cin) ? p.in[static_cast<long long>(src) * p.Cin + c + 1] : 0u;
+        w4[j] = lo | (hi << 16);
+      }
+      x.a = __builtin_bit_cast(f4, w4);
+    }
+    const int s_w = (k * c8p + s * 2) * p.Cout * 16;
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+      x.b[n] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, v_w[n], s_w, 0));
+  };
+  auto advance = [&](int &k, int &s) {
+    if (++s == n_slices) {
+      s = 0;
+      const uint32_t rest = mask & ~((2u << k) - 1u);
+      k = rest ? __builtin_ctz(rest) : k;
+    }
+  };
+
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  auto compute = [&](Slice &x) {
+    const bf16x8 a = __builtin_bit_cast(bf16x8, x.a);
+#pragma unroll
+    for (int n = 0; n < NBW; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, x.b[n]), acc[n], 0, 0, 0);
+  };
+
+  // items = (offset in mask) x slice; the ring holds items i .. i+kRing-2 while item i multiplies.
+  // Past the end the last item is re-read and dropped, so loads stay unconditional.
+  const int rem = __builtin_popcount(mask) * n_slices;
+  if (rem > 0) {
+    Slice S[kRing];
+    int kp = __builtin_ctz(mask), sp = 0, issued = 1;
+    load(kp, sp, S[0]);
+#pragma unroll
+    for (int i = 1; i < kRing - 1; ++i) {
+      if (issued < rem) advance(kp, sp);
+      ++issued;
+      load(kp, sp, S[i]);
+    }
+    for (int g = rem / kRing; g > 0; --g) {
+#pragma unroll
+      for (int i = 0; i < kRing; ++i) {
+        if (issued < rem) advance(kp, sp);
+        ++issued;
+        load(kp, sp, S[(i + kRing - 1) % kRing]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int tail = rem % kRing;
+#pragma unroll
+    for (int i = 0; i < kRing - 1; ++i)
+      if (i < tail) compute(S[i]);
+  }
+
+  // acc[n][reg] -> tile row (reg&3) + 8*(reg>>2) + 4*half, column col + 32 n
+  const bool final_out = p.ksplit == 1;
+  float *part = final_out ? nullptr : p.partial + static_cast<long long>(ks) * p.M_out * p.Cout;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * ahalf;
+    const int row = __shfl(my_row, r, 64);
+    if (row < 0) continue;
+    const long long off = static_cast<long long>(row) * p.Cout + col;
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      if (n < nbw && col + n * 32 < p.Cout) {
+        if (final_out) p.out[off + n * 32] = to_bf16(acc[n][reg]);
+        else part[off + n * 32] = acc[n][reg];
+      }
+    }
+  }
+}
+
+// fixed-order sum of the offset-split partials -> bf16
+__global__ void __launch_bounds__(256) conv_reduce_bf16_kernel(const float *__restrict__ partial, int ksplit,
+                                                              long long n, uint16_t *__restrict__ out) {
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < n; t += gridDim.x * 256LL) {
+    float a = partial[t];
+    for (int s = 1; s < ksplit; ++s) a += partial[s * n + t];
+    out[t] = to_bf16(a);
+  }
+}
+
+// src fp32 [Cout][K][Cin] (src_kio == 0) or [K][Cin][Cout] (1) -> bf16 [K][ceil16(Cin)/8][Cout][8]
+__global__ void __launch_bounds__(256) pack_weight_bf16_kernel(const float *__restrict__ w, int cout, int K,
+                                                              int cin, int src_kio,
+                                                              uint16_t *__restrict__ out) {
+  const int c8p = (cin + 15) / 16 * 2;
+  const int64_t total = static_cast<int64_t>(K) * c8p * cout * 8;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int j = static_cast<int>(t & 7);
+    int64_t r = t >> 3;
+    const int co = static_cast<int>(r % cout);
+    r /= cout;
+    const int blk = static_cast<int>(r % c8p), k = static_cast<int>(r / c8p);
+    const int ci = blk * 8 + j;
+    float v = 0.f;
+    if (ci < cin)
+      v = src_kio ? w[(static_cast<int64_t>(k) * cin + ci) * cout + co]
+                  : w[(static_cast<int64_t>(co) * K + k) * cin + ci];
+    out[t] = to_bf16(v);
+  }
+}
+
+template <int NBW>
+static void launch_bf16(const Bf16Args &a, int grid, size_t lds, bool vec, hipStream_t stream) {
+  if (vec) gather_conv_bf16_kernel<NBW, true><<<grid, 256, lds, stream>>>(a);
+  else gather_conv_bf16_kernel<NBW, false><<<grid, 256, lds, stream>>>(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V>
+struct RowVec;
+template <>
+struct RowVec<float, 1> {
+  static __device__ __forceinline__ void load(const float *p, bool ok, float (&v)[1]) { v[0] = ok ? *p : 0.f; }
+};
+template <>
+struct RowVec<float, 2> {
+  static __device__ __forceinline__ void load(const float *p, bool ok, float (&v)[2]) {
+    const float2 t = ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
+    v[0] = t.x;
+    v[1] = t.y;
+  }
+};
+template <>
+struct RowVec<uint16_t, 1> {
+  // the aligned 32-bit word that holds the element (a 16-bit load merges into its destination
+  // register and serialises behind it); the neighbour half is inside the same row or, for the very
+  // last element of an odd-sized tensor, inside the allocation's alignment padding
+  static __device__ __forceinline__ void load(const uint16_t *p, bool ok, float (&v)[1]) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t t = ok ? *reinterpret_cast<const uint32_t *>(addr & ~static_cast<uintptr_t>(3)) : 0u;
+    v[0] = __builtin_bit_cast(float, (addr & 2) ? (t & 0xffff0000u) : (t << 16));
+  }
+};
+template <>
+struct RowVec<uint16_t, 2> {
+  static __device__ __forceinline__ void load(const uint16_t *p, bool ok, float (&v)[2]) {
+    const uint32_t t = ok ? *reinterpret_cast<const uint32_t *>(p) : 0u;
+    v[0] = __builtin_bit_cast(float, t << 16);
+    v[1] = __builtin_bit_cast(float, t & 0xffff0000u);
+  }
+};
+
+// partial [chunks][K][Cin][Cout]; every (chunk, k) block is written (zeros when the chunk has no
+// pair for offset k), so the reduction needs no flags.
+//   1. the chunk's rows that HAVE a neighbour at offset k (one coalesced read of the transposed
+//      gather table nbr_t[K][M]) are compacted, in ascending row order, into LDS (at 2 cm voxels only 14 % of the (row, offset) pairs of the finest level exist:
+//      the matrix loop runs over existing pairs only);
+//   2. the (ci, co) range is cut into supertiles of 32 VI x 32 VO channels.  With >= 3 supertiles
+//      each wave owns whole supertiles (round-robin over the 4 waves x gridDim.z workgroups); with 1
+//      or 2 the compacted rows are split over 4 or 2 waves whose accumulators meet in LDS in a
+//      fixed order ((w0 + w1) + (w2 + w3)).
+template <typename TA, typename TG, int VI, int VO>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ in, const TG *__restrict__ g_out,
+                                                        const int32_t *__restrict__ nbr_t, int M_out, int K,
+                                                        int Cin, int Cout, int chunk_rows,
+                                                        float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) int32_t wg_lds[];
+  int32_t *row_c = wg_lds, *src_c = wg_lds + chunk_rows;
+  float *red = reinterpret_cast<float *>(wg_lds + 2 * chunk_rows);    // [2][VI*VO*16][64]
+  __shared__ int wcount[4];
+  const int k = blockIdx.y;
+  const int r0 = blockIdx.x * chunk_rows;
+  const int nrows = min(chunk_rows, M_out - r0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // every thread's (<= 8) gather-table words are requested before the first one is used
+  constexpr int kMaxPer = 8;           // chunk_rows <= 2048
+  int sv[kMaxPer];
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    const int r = u * 256 + threadIdx.x;
+    sv[u] = r < nrows ? nbr_t[static_cast<long long>(k) * M_out + r0 + r] : -1;
+  }
+  int total = 0;
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    if (u * 256 >= nrows) break;       // uniform
+    const int s = sv[u];
+    const uint64_t bal = __ballot(s >= 0);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = wcount[w];
+      before += w < wave ? c : 0;
+      all += c;
+    }
+    if (s >= 0) {
+      const int pos = total + before + mask_prefix(bal);
+      row_c[pos] = u * 256 + threadIdx.x;
+      src_c[pos] = s;
+    }
+    total += all;
+    __syncthreads();
+  }
+  float *dst = partial + (static_cast<long long>(blockIdx.x) * K + k) * Cin * Cout;
+  if (total == 0) {
+    for (int t = threadIdx.x; t < Cin * Cout; t += 256) dst[t] = 0.f;
+    return;
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int nsi = (Cin + 32 * VI - 1) / (32 * VI), nso = (Cout + 32 * VO - 1) / (32 * VO);
+  const int nst = nsi * nso;
+  const int RS = nst >= 3 ? 1 : (nst == 2 ? 2 : 4);     // row split; 4 / RS waves share the supertiles
+  const int ST = 4 / RS;
+  const int sw = wave % ST, rs = wave / ST;
+  int per = (total + RS - 1) / RS;
+  per = (per + 1) & ~1;
+  const int begin = min(total, rs * per), end = min(total, begin + per);
+  const int st_step = RS == 1 ? 4 * gridDim.z : ST;
+  for (int st = RS == 1 ? blockIdx.z * 4 + wave : sw; st < nst; st += st_step) {
+    const int sib = st / nso, sob = st % nso;
+    const int ci0 = sib * 32 * VI + VI * col, co0 = sob * 32 * VO + VO * col;
+    const bool ci_ok = ci0 + VI <= Cin, co_ok = co0 + VO <= Cout;
+    f32x16 acc[VI][VO];
+#pragma unroll
+    for (int c = 0; c < VI; ++c)
+#pragma unroll
+      for (int d = 0; d < VO; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
+    // 4 pairs of existing rows per trip (8 vector loads, 4 VI VO MFMAs); the loads of trip t+1 are
+    // in flight while trip t multiplies
+    auto ld = [&](int t, float (&a)[4][VI], float (&b)[4][VO]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = t + 2 * u + half;
+        const bool ok = it < end;
+        const int s = ok ? src_c[it] : 0, r = ok ? row_c[it] : 0;
+        RowVec<TA, VI>::load(in + static_cast<long long>(s) * Cin + ci0, ok && ci_ok, a[u]);
+        RowVec<TG, VO>::load(g_out + static_cast<long long>(r0 + r) * Cout + co0, ok && co_ok, b[u]);
+      }
+    };
+    auto mm = [&](float (&a)[4][VI], float (&b)[4][VO]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < VI; ++c)
+#pragma unroll
+          for (int d = 0; d < VO; ++d)
+            acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][c], b[u][d], acc[c][d], 0, 0, 0);
+    };
+    {
+      float a0[4][VI], b0[4][VO], a1[4][VI], b1[4][VO];
+      int t = begin;
+      if (t < end) ld(t, a0, b0);
+      while (t < end) {
+        ld(t + 8, a1, b1);               // past the end: no access, zeros
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        t += 8;
+        if (t >= end) break;
+        ld(t + 8, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        t += 8;
+      }
+    }
+    if (RS > 1) {            // uniform per workgroup: every wave runs exactly one supertile
+      constexpr int kBuf = VI * VO * 16 * 64;
+      auto put = [&](float *buf) {
+#pragma unroll
+        for (int c = 0; c < VI; ++c)
+#pragma unroll
+          for (int d = 0; d < VO; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[((c * VO + d) * 16 + r) * 64 + lane] = acc[c][d][r];
+      };
+      auto add = [&](const float *buf) {
+#pragma unroll
+        for (int c = 0; c < VI; ++c)
+#pragma unroll
+          for (int d = 0; d < VO; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][d][r] += buf[((c * VO + d) * 16 + r) * 64 + lane];
+      };
+      if (RS == 2) {         // waves (rs, sw): sw = wave & 1
+        if (rs == 1) put(red + sw * kBuf);
+        __syncthreads();
+        if (rs == 0) add(red + sw * kBuf);
+      } else {               // RS == 4: (w0 + w1) + (w2 + w3)
+        if (wave & 1) put(red + (wave >> 1) * kBuf);
+        __syncthreads();
+        if (!(wave & 1)) add(red + (wave >> 1) * kBuf);
+        __syncthreads();
+        if (wave == 2) put(red);
+        __syncthreads();
+        if (wave == 0) add(red);
+      }
+      if (rs != 0) continue;           // (no further barrier follows)
+    }
+    // acc[c][d][reg] = dW[ci = sib*32*VI + VI*((reg&3) + 8*(reg>>2) + 4*half) + c][co0 + d]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+#pragma unroll
+      for (int c = 0; c < VI; ++c) {
+        const int ci = sib * 32 * VI + VI * i + c;
+        if (ci < Cin && co_ok) {
+#pragma unroll
+          for (int d = 0; d < VO; ++d) dst[static_cast<long long>(ci) * Cout + co0 + d] = acc[c][d][reg];
+        }
+      }
+    }
+  }
+}
+
+// dw[o] = sum over chunks, in a fixed order: thread (o, q) adds the chunks c = q mod 4 in ascending
+// order (4 loads in flight), the four partial sums meet in LDS as (s0 + s1) + (s2 + s3)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, int chunks,
+                                                          long long n, float *__restrict__ dw) {
+  __shared__ float sh[4][64];
+  const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const long long o = blockIdx.x * 64LL + l;
+  float a = 0.f;
+  if (o < n) {
+    int c = q;
+    for (; c + 12 < chunks; c += 16) {
+      const float v0 = partial[c * n + o], v1 = partial[(c + 4) * n + o];
+      const float v2 = partial[(c + 8) * n + o], v3 = partial[(c + 12) * n + o];
+      a += v0;
+      a += v1;
+      a += v2;
+      a += v3;
+    }
+    for (; c < chunks; c += 4) a += partial[c * n + o];
+  }
+  sh[q][l] = a;
+  __syncthreads();
+  if (q == 0 && o < n) dw[o] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+}
+
+// gather table [M][K] -> [K][M]: the weight gradient walks one offset's column at a time, and a
+// column of the row-major table costs a 128-B line per 4 useful bytes
+__global__ void __launch_bounds__(256) transpose_table_kernel(const int32_t *__restrict__ nbr, int M, int K,
+                                                             int32_t *__restrict__ nbr_t) {
+  __shared__ int32_t tile[64 * kTMaxK];
+  const int r0 = blockIdx.x * 64;
+  const int rows = min(64, M - r0);
+  for (int e = threadIdx.x; e < rows * K; e += 256) tile[e] = nbr[static_cast<long long>(r0) * K + e];
+  __syncthreads();
+  const int r = threadIdx.x & 63;
+  for (int k = threadIdx.x >> 6; k < K; k += 4)
+    if (r < rows) nbr_t[static_cast<long long>(k) * M + r0 + r] = tile[r * K + k];
+}
+
+struct WgradShape {
+  int vi, vo, nst, zs, rows, chunks;
+};
+// one decomposition for the workspace query and the launch: ~1024 workgroups
+static WgradShape wgrad_shape(int M_out, int K, int Cin, int Cout) {
+  WgradShape w;
+  // two channels per lane from 64 channels up: one vector load feeds two MFMAs.  (For odd multiples
+  // of 32 the last 64-channel supertile is half empty; one channel per lane tiles exactly but
+  // doubles the loads per MFMA and measured slower: the loop is bound by load issue / latency.)
+  w.vi = (Cin % 2 == 0 && Cin >= 64) ? 2 : 1;
+  w.vo = (Cout % 2 == 0 && Cout >= 64) ? 2 : 1;
+  w.nst = ((Cin + 32 * w.vi - 1) / (32 * w.vi)) * ((Cout + 32 * w.vo - 1) / (32 * w.vo));
+  w.zs = w.nst >= 3 ? (w.nst + 3) / 4 : 1;
+  const int chunks_want = (1024 + K * w.zs - 1) / (K * w.zs);
+  int r = (M_out + chunks_want - 1) / chunks_want;
+  r = (r + 1) & ~1;
+  if (r < 128) r = 128;
+  if (r > 2048) r = 2048;
+  w.rows = r;
+  w.chunks = (M_out + r - 1) / r;
+  return w;
+}
+
+template <typename TA, typename TG>
+static void launch_wgrad(const void *in, const void *g, const int32_t *nbr, int M_out, int K, int Cin,
+                         int Cout, const WgradShape &w, float *partial, hipStream_t stream) {
+  const dim3 grid(w.chunks, K, w.zs);
+  const size_t lds = static_cast<size_t>(w.rows) * 8 + (w.nst < 3 ? 2u * w.vi * w.vo * 16 * 64 * 4 : 0u);
+  const TA *a = static_cast<const TA *>(in);
+  const TG *b = static_cast<const TG *>(g);
+  const int rows = w.rows;
+  if (w.vi == 2 && w.vo == 2) conv_wgrad_kernel<TA, TG, 2, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
+  else if (w.vi == 2) conv_wgrad_kernel<TA, TG, 2, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
+  else if (w.vo == 2) conv_wgrad_kernel<TA, TG, 1, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
+  else conv_wgrad_kernel<TA, TG, 1, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+size_t sg_spconv_packed_weight_elems_bf16(int kvol, int cin, int cout) {
+  return static_cast<size_t>(kvol) * ((cin + 15) / 16 * 2) * cout * 8;
+}
+
+int sg_spconv_pack_weight_bf16(const float *w, int cout, int kvol, int cin, int src_is_kio, uint16_t *w_k8,
+                               sg_stream_t stream) {
+  SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0 && w && w_k8, "sg_spconv_pack_weight_bf16: bad arguments");
+  const int64_t total = static_cast<int64_t>(sg_spconv_packed_weight_elems_bf16(kvol, cin, cout));
+  pack_weight_bf16_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>(w, cout, kvol, cin,
+                                                                              src_is_kio, w_k8);
+  return check_launch("sg_spconv_pack_weight_bf16");
+}
+
+// workspace of the offset-split path (deep levels only): K * M_out * Cout floats
+size_t sg_spconv_conv_bf16_workspace_bytes(int M_out, int Cout) {
+  const int num_tiles = (M_out + kTRows - 1) / kTRows;
+  if (num_tiles >= 1024) return 256;
+  return static_cast<size_t>(kTMaxK) * M_out * Cout * sizeof(float) + 256;
+}
+
+int sg_spconv_gather_conv_bf16(const uint16_t *in, int num_in_rows, const int32_t *nbr, int M_out, int K,
+                               int Cin, int Cout, const uint16_t *w_k8, const int32_t *order,
+                               const uint32_t *tile_mask, const int32_t *nbr_tiles, uint16_t *out,
+                               void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kTMaxK && Cin >= 1 && Cout >= 1 && num_in_rows >= 0,
+             "sg_spconv_gather_conv_bf16: bad arguments (M_out=%d K=%d Cin=%d Cout=%d)", M_out, K, Cin, Cout);
+  SG_REQUIRE((order == nullptr) == (tile_mask == nullptr) && (order == nullptr) == (nbr_tiles == nullptr),
+             "sg_spconv_gather_conv_bf16: order, tile_mask and nbr_tiles come together (sg_spconv_plan)");
+  SG_REQUIRE(order != nullptr || nbr != nullptr, "sg_spconv_gather_conv_bf16: no gather table");
+  if (M_out == 0) return SG_OK;
+  const long long in_bytes = static_cast<long long>(num_in_rows) * Cin * 2;
+  const long long w_bytes = static_cast<long long>(sg_spconv_packed_weight_elems_bf16(K, Cin, Cout)) * 2;
+  SG_REQUIRE(in_bytes < (1LL << 31) && w_bytes < (1LL << 31),
+             "sg_spconv_gather_conv_bf16: input (%lld B) or weights (%lld B) exceed the 2 GiB buffer range",
+             in_bytes, w_bytes);
+  hipStream_t stream = as_stream(stream_);
+  const int NB = (Cout + 31) / 32;
+  const int num_tiles = (M_out + kTRows - 1) / kTRows;
+  // column blocks per unit: as even as possible, at most 4 (64 accumulator registers)
+  const int col_units = (NB + 3) / 4;
+  const int bpu = (NB + col_units - 1) / col_units;
+  int ksplit = 1;
+  const long long waves = static_cast<long long>(num_tiles) * col_units;
+  if (waves < 1024) {
+    const long long want = (1024 + waves - 1) / waves;
+    ksplit = static_cast<int>(want < K ? want : K);
+    const size_t need = static_cast<size_t>(ksplit) * M_out * Cout * sizeof(float);
+    if (ksplit > 1 && (ws == nullptr || ws_bytes < need)) ksplit = 1;
+  }
+  const int k_per_split = (K + ksplit - 1) / ksplit;
+  ksplit = (K + k_per_split - 1) / k_per_split;
+
+  Bf16Args a;
+  a.in = in; a.nbr = nbr; a.w = w_k8; a.order = order; a.tile_mask = tile_mask; a.nbr_tiles = nbr_tiles;
+  a.out = out; a.partial = static_cast<float *>(ws);
+  a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
+  a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
+  a.in_bytes = static_cast<unsigned>(in_bytes);
+  a.w_bytes = static_cast<unsigned>(w_bytes);
+  const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
+  const int grid = static_cast<int>((units + 3) / 4);
+  const size_t lds = 4 * kTRows * kTMaxK * sizeof(int32_t);
+  const bool vec = Cin % 16 == 0;
+  switch (bpu) {
+    case 1: launch_bf16<1>(a, grid, lds, vec, stream); break;
+    case 2: launch_bf16<2>(a, grid, lds, vec, stream); break;
+    case 3: launch_bf16<3>(a, grid, lds, vec, stream); break;
+    default: launch_bf16<4>(a, grid, lds, vec, stream); break;
+  }
+  if (ksplit > 1) {
+    const long long n = static_cast<long long>(M_out) * Cout;
+    conv_reduce_bf16_kernel<<<grid_for(n, 256), 256, 0, stream>>>(static_cast<const float *>(ws), ksplit, n, out);
+  }
+  return check_launch("sg_spconv_gather_conv_bf16");
+}
+
+int sg_spconv_transpose_table(const int32_t *nbr, int M, int K, int32_t *nbr_t, sg_stream_t stream) {
+  SG_REQUIRE(M >= 0 && K >= 1 && K <= kTMaxK, "sg_spconv_transpose_table: bad arguments");
+  if (M == 0) return SG_OK;
+  transpose_table_kernel<<<(M + 63) / 64, 256, 0, as_stream(stream)>>>(nbr, M, K, nbr_t);
+  return check_launch("sg_spconv_transpose_table");
+}
+
+size_t sg_spconv_wgrad_workspace_bytes(int M_out, int K, int Cin, int Cout) {
+  if (M_out <= 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 256;
+  const WgradShape w = wgrad_shape(M_out, K, Cin, Cout);
+  return static_cast<size_t>(w.chunks) * K * Cin * Cout * sizeof(float) + 256;
+}
+
+// dw_kio [K][Cin][Cout] fp32 is overwritten.  `in` is the input the forward conv gathered from
+// (fp32, or bf16 when in_bf16), g_out the gradient of its output (fp32 | bf16).
+int sg_spconv_wgrad(const void *in, int in_bf16, const void *g_out, int g_bf16, const int32_t *nbr_t,
+                    int M_out, int K, int Cin, int Cout, float *dw_kio, void *ws, size_t ws_bytes,
+                    sg_stream_t stream_) {
+  SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kTMaxK && Cin >= 1 && Cout >= 1 && dw_kio,
+             "sg_spconv_wgrad: bad arguments");
+  hipStream_t stream = as_stream(stream_);
+  const long long n = static_cast<long long>(K) * Cin * Cout;
+  if (M_out == 0) {
+    hipMemsetAsync(dw_kio, 0, static_cast<size_t>(n) * 4, stream);
+    return check_launch("sg_spconv_wgrad");
+  }
+  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_spconv_wgrad_workspace_bytes(M_out, K, Cin, Cout),
+             "sg_spconv_wgrad: workspace too small (sg_spconv_wgrad_workspace_bytes)");
+  const WgradShape w = wgrad_shape(M_out, K, Cin, Cout);
+  float *partial = static_cast<float *>(ws);
+  if (in_bf16 && g_bf16) launch_wgrad<uint16_t, uint16_t>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
+  else if (in_bf16) launch_wgrad<uint16_t, float>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
+  else if (g_bf16) launch_wgrad<float, uint16_t>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
+  else launch_wgrad<float, float>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
+  wgrad_reduce_kernel<<<static_cast<int>((n + 63) / 64), 256, 0, stream>>>(partial, w.chunks, n, dw_kio);
+  return check_launch("sg_spconv_wgrad");
+}
+
+}  // extern "C"

@@ -67,13 +67,14 @@ class SparseConvTensor:
 # ------------------------------------------------------------------------------------------------
 class _Plan:
     """gather table + mask-sorted tile plan for the implicit-GEMM kernel"""
-    __slots__ = ('nbr', 'order', 'tile_mask', 'nbr_tiles', 'num_out', 'kvol', '_pairs')
+    __slots__ = ('nbr', 'order', 'tile_mask', 'nbr_tiles', 'num_out', 'kvol', '_pairs', '_nbr_t')
 
     def __init__(self, nbr, num_out, kvol):
         lib = L.lib()
         dev = nbr.device
         self.nbr, self.num_out, self.kvol = nbr, num_out, kvol
         self._pairs = None
+        self._nbr_t = None
         nt = (num_out + 31) // 32
         self.order = torch.empty(nt * 32, dtype=torch.int32, device=dev)
         self.tile_mask = torch.empty(nt, dtype=torch.int32, device=dev)
@@ -85,6 +86,17 @@ class _Plan:
                                        L.ptr(self.tile_mask), L.ptr(self.nbr_tiles), L.ptr(ws), nb,
                                        L.stream()),
                     'sg_spconv_plan')
+
+
+    @property
+    def nbr_t(self):
+        """gather table transposed to [K, M] (weight gradient only; built on first use)"""
+        if self._nbr_t is None:
+            t = torch.empty((self.kvol, self.num_out), dtype=torch.int32, device=self.nbr.device)
+            L.check(L.lib().sg_spconv_transpose_table(L.ptr(self.nbr), self.num_out, self.kvol,
+                                                      L.ptr(t), L.stream()), 'sg_spconv_transpose_table')
+            self._nbr_t = t
+        return self._nbr_t
 
 
 class SubMRule:
@@ -223,37 +235,80 @@ def gather_conv(features, plan, w_k8, cout, post_scale=None, post_shift=None, re
     return out
 
 
+def pack_weight_bf16(w, cout, kvol, cin, src_is_kio):
+    """fp32 master weight -> the bf16 kernel's packed layout (rounded to nearest even)"""
+    lib = L.lib()
+    src = w.detach().float().contiguous()
+    out = torch.empty(lib.sg_spconv_packed_weight_elems_bf16(kvol, cin, cout), dtype=torch.bfloat16,
+                      device=w.device)
+    L.check(lib.sg_spconv_pack_weight_bf16(L.ptr(src), cout, kvol, cin, 1 if src_is_kio else 0,
+                                           L.ptr(out), L.stream()), 'sg_spconv_pack_weight_bf16')
+    return out
+
+
+def gather_conv_bf16(features, plan, w_k8, cout):
+    """out[j] = bf16(sum_k features[nbr[j,k]] @ W[k]): bf16 operands, fp32 accumulation (HIP, MFMA
+    bf16); the autocast path of training (BASELINE config 3)."""
+    lib = L.lib()
+    assert features.is_cuda and features.dtype == torch.bfloat16 and features.is_contiguous()
+    cin = features.shape[1]
+    out = torch.empty((plan.num_out, cout), dtype=torch.bfloat16, device=features.device)
+    nb = lib.sg_spconv_conv_bf16_workspace_bytes(plan.num_out, cout)
+    ws = L.workspace(nb, features.device) if nb > 256 else None
+    L.check(lib.sg_spconv_gather_conv_bf16(
+        L.ptr(features), features.shape[0], L.ptr(plan.nbr), plan.num_out, plan.kvol, cin, cout,
+        L.ptr(w_k8), L.ptr(plan.order), L.ptr(plan.tile_mask), L.ptr(plan.nbr_tiles), L.ptr(out),
+        L.ptr(ws), nb if ws is not None else 0, L.stream()), 'sg_spconv_gather_conv_bf16')
+    return out
+
+
+def conv_wgrad(feats, g, plan, cin, cout):
+    """dW [K, Cin, Cout] fp32 = sum_j feats[nbr[j,k]]^T g[j]; feats / g fp32 or bf16.
+    Deterministic (fixed-order chunk sums)."""
+    lib = L.lib()
+    assert feats.is_contiguous() and g.is_contiguous()
+    assert feats.dtype in (torch.float32, torch.bfloat16) and g.dtype in (torch.float32, torch.bfloat16)
+    kvol = plan.kvol
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=g.device)
+    nb = lib.sg_spconv_wgrad_workspace_bytes(plan.num_out, kvol, cin, cout)
+    ws = L.workspace(nb, g.device)
+    L.check(lib.sg_spconv_wgrad(L.ptr(feats), int(feats.dtype == torch.bfloat16), L.ptr(g),
+                                int(g.dtype == torch.bfloat16), L.ptr(plan.nbr_t), plan.num_out, kvol,
+                                cin, cout, L.ptr(dw), L.ptr(ws), nb, L.stream()), 'sg_spconv_wgrad')
+    return dw
+
+
 class _GatherConvFn(torch.autograd.Function):
-    """Differentiable sparse conv: forward = gather_conv; input gradient = the same kernel on the
-    transposed gather table with transposed weights; weight gradient = sg_spconv_wgrad_f32."""
+    """Differentiable sparse conv.  forward = gather_conv (fp32) or gather_conv_bf16 (features in
+    bf16: the autocast path); input gradient = the same kernel on the transposed gather table with
+    the transposed weights (packed once per weight version, ``packed(transposed, bf16)``); weight
+    gradient = sg_spconv_wgrad (fp32 sums, deterministic)."""
 
     @staticmethod
-    def forward(ctx, feats, weight, w_k8, plan, bwd_plan, flip_k):
+    def forward(ctx, feats, weight, packed, plan, bwd_plan):
         ctx.save_for_backward(feats, weight)
-        ctx.plan, ctx.bwd_plan, ctx.flip_k = plan, bwd_plan, flip_k
-        return gather_conv(feats, plan, w_k8, weight.shape[0])
+        ctx.plan, ctx.bwd_plan, ctx.packed = plan, bwd_plan, packed
+        if feats.dtype == torch.bfloat16:
+            return gather_conv_bf16(feats, plan, packed(False, True), weight.shape[0])
+        return gather_conv(feats, plan, packed(False, False), weight.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         feats, weight = ctx.saved_tensors
         plan, bwd_plan = ctx.plan, ctx.bwd_plan
         cout, cin = weight.shape[0], weight.shape[-1]
-        kvol = plan.kvol
-        g = g.contiguous().float()
+        low = feats.dtype == torch.bfloat16
+        g = g.contiguous().to(feats.dtype)
         g_feats = g_weight = None
         if ctx.needs_input_grad[0]:
-            # w_t[k'][co][ci] = W[co][k][ci] with k' = K-1-k for SubM (mirrored offset), k otherwise
-            w_t = weight.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
-            if ctx.flip_k:
-                w_t = w_t.flip(0)
-            g_feats = gather_conv(g, bwd_plan, pack_weight(w_t, cin, kvol, cout, True), cin)
+            if low:
+                g_feats = gather_conv_bf16(g, bwd_plan, ctx.packed(True, True), cin)
+            else:
+                g_feats = gather_conv(g, bwd_plan, ctx.packed(True, False), cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((kvol, cin, cout), dtype=torch.float32, device=g.device)
-            L.check(L.lib().sg_spconv_wgrad_f32(L.ptr(feats), L.ptr(g), L.ptr(plan.nbr), plan.num_out,
-                                                kvol, cin, cout, L.ptr(dw), L.stream()),
-                    'sg_spconv_wgrad_f32')
+            dw = conv_wgrad(feats, g, plan, cin, cout)
             g_weight = dw.permute(2, 0, 1).reshape(weight.shape).to(weight.dtype)
-        return g_feats, g_weight, None, None, None, None
+        return g_feats, g_weight, None, None, None
 
 
 # ---- derived-tensor caches (packed conv weights, eval-mode BatchNorm affines, executor
@@ -347,14 +402,28 @@ class SparseConvolution(SparseModule):
         state['_kio_cache'] = None
         return state
 
-    # [Cout, K, Cin] -> packed kernel layout, cached until the weight changes
-    def weight_packed(self):
+    # [Cout, K, Cin] -> packed kernel layouts, cached until the weight changes: the forward layout and
+    # (training) the transposed one of the input gradient, in fp32 and in bf16
+    def weight_packed(self, transposed=False, bf16=False, flip_k=False):
         w = self.weight
         key = (_CACHE_EPOCH[0], w._version, w.data_ptr(), w.device, w.dtype)
         if self._kio_cache is None or self._kio_cache[0] != key:
+            self._kio_cache = (key, {})
+        slot = self._kio_cache[1]
+        which = (transposed, bf16, flip_k)
+        if which not in slot:
             kvol = int(torch.tensor(self.kernel_size).prod())
-            self._kio_cache = (key, pack_weight(w, self.out_channels, kvol, self.in_channels, False))
-        return self._kio_cache[1]
+            cout, cin = self.out_channels, self.in_channels
+            pack = pack_weight_bf16 if bf16 else pack_weight
+            if not transposed:
+                slot[which] = pack(w, cout, kvol, cin, False)
+            else:
+                # w_t[k'][co][ci] = W[co][k][ci], k' = K-1-k for SubM (mirrored offset), k otherwise
+                w_t = w.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
+                if flip_k:
+                    w_t = w_t.flip(0)
+                slot[which] = pack(w_t.contiguous(), cin, kvol, cout, True)
+        return slot[which]
 
     def _rule_and_plan(self, input):
         """-> (plan, out_indices, out_spatial_shape, backward-plan getter, mirrored offsets?)"""
@@ -393,18 +462,26 @@ class SparseConvolution(SparseModule):
                 out = out + self.bias
             return input.replace_feature(out)
         plan, out_indices, out_shape, bwd_plan, flip_k = self._rule_and_plan(input)
-        x = (feats if feats.dtype == torch.float32 else feats.float()).contiguous()
+        # bf16 autocast (training, BASELINE config 3) or bf16 features: bf16 operands, fp32 sums;
+        # everything else computes in fp32
+        low = feats.is_cuda and (feats.dtype == torch.bfloat16 or (
+            torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16))
+        x = feats.to(torch.bfloat16 if low else torch.float32).contiguous()
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
             assert post_scale is None and residual is None, 'fused epilogue is inference-only'
-            out = _GatherConvFn.apply(x, self.weight, self.weight_packed(), plan,
-                                      bwd_plan() if x.requires_grad else None, flip_k)
+            packed = lambda t, b: self.weight_packed(t, b, flip_k and t)  # noqa: E731
+            out = _GatherConvFn.apply(x, self.weight, packed, plan,
+                                      bwd_plan() if x.requires_grad else None)
+        elif low:
+            assert post_scale is None and residual is None, 'fused epilogue is fp32-only'
+            out = gather_conv_bf16(x, plan, self.weight_packed(False, True), self.out_channels)
         else:
             assert post_scale is None or self.bias is None
             out = gather_conv(x, plan, self.weight_packed(), self.out_channels, post_scale,
                               post_shift, residual)
         if self.bias is not None:
-            out = out + self.bias.float()
-        if out.dtype != feats.dtype:
+            out = out + self.bias.to(out.dtype)
+        if not low and out.dtype != feats.dtype:
             out = out.to(feats.dtype)
         return SparseConvTensor(out, out_indices, out_shape, input.batch_size, input.grid,
                                 input.voxel_num, input.indice_dict, input.benchmark)

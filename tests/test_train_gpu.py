@@ -70,6 +70,127 @@ def test_conv_gradients_match_dense_autograd():
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-3, rtol=1e-3, err_msg=name)
 
 
+def _bf16_ulp_close(got, ref, what):
+    """bf16 result vs the same sum in fp32: half a bf16 ulp of rounding plus the fp32 summation-order
+    noise of a few hundred terms -> 2^-7 relative on the row scale"""
+    got, ref = got.float().cpu().numpy(), ref.float().cpu().numpy()
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-6
+    err = np.abs(got - ref) / scale
+    assert err.max() <= 2.0 ** -7, (what, float(err.max()))
+
+
+@pytest.mark.parametrize('cin,cout,D,B', [(32, 32, 10, 2), (64, 96, 10, 2), (6, 32, 10, 2), (160, 224, 7, 1),
+                                          (48, 40, 9, 1), (32, 64, 48, 1)])
+def test_bf16_conv_matches_fp32_math_on_rounded_operands(cin, cout, D, B):
+    """sg_spconv_gather_conv_bf16 (MFMA bf16, fp32 accumulation) against the fp32 kernel fed with the
+    same bf16-rounded features and weights: SubM k3, strided k2 and its inverse; small grids take
+    the offset-split path, the 48^3 grid (~39 k rows, 1.2 k tiles) the direct one; Cin = 6 / 48 the
+    unaligned gather."""
+    rng = np.random.default_rng(cin * 1000 + cout)
+    idx = _grid(rng, D, B, p=0.35)
+    ti = torch.from_numpy(idx).to(DEV)
+    M = len(idx)
+    torch.manual_seed(cin + cout)
+    feats = torch.randn(M, cin, device=DEV).bfloat16()
+    subm = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key='s').to(DEV)
+    down = spconv.SparseConv3d(cout, cout, kernel_size=2, stride=2, bias=False, indice_key='d').to(DEV)
+    inv = spconv.SparseInverseConv3d(cout, cin, kernel_size=2, bias=False, indice_key='d').to(DEV)
+    ref_mods = [copy.deepcopy(m) for m in (subm, down, inv)]
+    for m in ref_mods:
+        with torch.no_grad():
+            m.weight.copy_(m.weight.bfloat16().float())
+    with torch.no_grad():
+        x = spconv.SparseConvTensor(feats, ti, [D] * 3, B)
+        y = subm(x)
+        d = down(y)
+        u = inv(d)
+        assert y.features.dtype == d.features.dtype == u.features.dtype == torch.bfloat16
+        xr = spconv.SparseConvTensor(feats.float(), ti, [D] * 3, B)
+        yr = ref_mods[0](xr)
+        # the next layer sees the bf16-rounded output of the previous one in both paths
+        dr = ref_mods[1](yr.replace_feature(y.features.float()))
+        ur = ref_mods[2](dr.replace_feature(d.features.float()))
+    _bf16_ulp_close(y.features, yr.features, 'subm')
+    _bf16_ulp_close(d.features, dr.features, 'down')
+    _bf16_ulp_close(u.features, ur.features, 'inverse')
+    assert torch.equal(d.indices, dr.indices)
+
+
+def test_bf16_autocast_gradients_and_deterministic_wgrad():
+    """Under bf16 autocast the convs run forward, dgrad and wgrad on the bf16 kernels: gradients
+    against fp32 dense autograd at bf16 tolerance; two backward passes give bit-identical weight
+    gradients (fixed-order chunk sums, no atomics)."""
+    rng = np.random.default_rng(9)
+    D, B, Cin, Cmid = 11, 2, 32, 64
+    idx = _grid(rng, D, B, p=0.4)
+    ti = torch.from_numpy(idx).to(DEV)
+    li = ti.long()
+    M = len(idx)
+    torch.manual_seed(3)
+    feats = torch.randn(M, Cin, device=DEV, requires_grad=True)
+    subm = spconv.SubMConv3d(Cin, Cmid, 3, padding=1, bias=False, indice_key='subm1').to(DEV)
+    subm2 = spconv.SubMConv3d(Cmid, Cmid, 3, padding=1, bias=False, indice_key='subm1').to(DEV)
+    r = torch.randn(M, Cmid, device=DEV)
+
+    def run():
+        for t in (feats, subm.weight, subm2.weight):
+            t.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = subm2(subm(spconv.SparseConvTensor(feats, ti, [D] * 3, B)))
+        assert y.features.dtype == torch.bfloat16
+        (y.features.float() * r).sum().backward()
+        return [feats.grad.clone(), subm.weight.grad.clone(), subm2.weight.grad.clone()]
+
+    got = run()
+    again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    assert got[1].dtype == torch.float32 and got[0].dtype == torch.float32
+
+    f2 = feats.detach().clone().requires_grad_(True)
+    ws = [w.detach().clone().requires_grad_(True) for w in (subm.weight, subm2.weight)]
+    dense = torch.zeros(B, D, D, D, Cin, device=DEV)
+    dense = dense.index_put((li[:, 0], li[:, 1], li[:, 2], li[:, 3]), f2).permute(0, 4, 1, 2, 3)
+    active = torch.zeros(B, 1, D, D, D, device=DEV)
+    active[li[:, 0], 0, li[:, 1], li[:, 2], li[:, 3]] = 1
+    y1 = F.conv3d(dense, ws[0].permute(0, 4, 1, 2, 3), padding=1) * active
+    y2 = F.conv3d(y1, ws[1].permute(0, 4, 1, 2, 3), padding=1) * active
+    (y2[li[:, 0], :, li[:, 1], li[:, 2], li[:, 3]] * r).sum().backward()
+    for a, b, name in zip(got, [f2.grad, ws[0].grad, ws[1].grad], ['d_feats', 'd_W1', 'd_W2']):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        rel = np.abs(a - b).max() / np.abs(b).max()
+        assert rel < 3e-2, (name, rel)
+        # and no systematic loss: the gradients correlate almost perfectly
+        assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.9995, name
+
+
+def test_wgrad_bf16_and_fp32_operands_agree_and_channel_shapes():
+    """sg_spconv_wgrad over the channel shapes of the model (vector widths 1 and 2, Cin = 6, odd
+    multiples of 32, concatenated 2C inputs) against a dense gather + matmul in fp64."""
+    from softgroup_amd.spconv import core
+    rng = np.random.default_rng(13)
+    idx = _grid(rng, 12, 2, p=0.3)
+    ti = torch.from_numpy(idx).to(DEV)
+    M = len(idx)
+    rule = core.SubMRule(ti, [12] * 3)
+    nbr = rule.plan.nbr.long()
+    for cin, cout in [(6, 32), (32, 32), (64, 32), (96, 96), (192, 96), (160, 224), (40, 72)]:
+        torch.manual_seed(cin)
+        x = torch.randn(M, cin, device=DEV)
+        g = torch.randn(M, cout, device=DEV)
+        xz = torch.cat([x, torch.zeros(1, cin, device=DEV)]).double()
+        ref = torch.stack([xz[nbr[:, k]].T @ g.double() for k in range(27)])          # [K, Cin, Cout]
+        dw = core.conv_wgrad(x, g, rule.plan, cin, cout)
+        np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), atol=2e-3, rtol=1e-4)
+        assert torch.equal(dw, core.conv_wgrad(x, g, rule.plan, cin, cout))
+        xb, gb = x.bfloat16(), g.bfloat16()
+        refb = torch.stack([torch.cat([xb.double(), torch.zeros(1, cin, device=DEV).double()])[nbr[:, k]].T
+                            @ gb.double() for k in range(27)])
+        for a, b in ((xb, gb), (xb, gb.float()), (xb.float(), gb)):
+            dwb = core.conv_wgrad(a.contiguous(), b.contiguous(), rule.plan, cin, cout)
+            np.testing.assert_allclose(dwb.cpu().numpy(), refb.cpu().numpy(), atol=2e-3, rtol=1e-4)
+
+
 def _train_batch(n=30000):
     xyz, rgb, inst = synthetic.scene_s2(seed=21, n=n, room_scale=0.45)
     return synthetic.make_batch(xyz, rgb, instance_labels=inst)
