@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kMetaInts = kTileRows * kMaxK + kTileRows + 4;   // gather block, rows, mask
 
-template <int CK, int DEPTH, int TRACE, int WPE>
+template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1>
 __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
                                                                          unsigned w_bytes) {
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
@@ -256,8 +256,8 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   // buffer-load scalar offsets stay in SGPRs (no waterfall loops)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int arow = lane & 31, ahalf = lane >> 5;
-  float *red = reinterpret_cast<float *>(smem_raw);                  // [4 waves][16][64]
-  int32_t *meta_lds = reinterpret_cast<int32_t *>(red + kWavesPerWg * 16 * 64);   // [2][kMetaInts]
+  float *red = reinterpret_cast<float *>(smem_raw);                  // [4 waves][NBW][16][64]
+  int32_t *meta_lds = reinterpret_cast<int32_t *>(red + kWavesPerWg * NBW * 16 * 64);   // [2][kMetaInts]
 
   const int G = gridDim.x;
   const int units_per_tile = p.col_units * p.ksplit;
@@ -341,19 +341,19 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     if (threadIdx.x == 0) dst[kMaskAt] = m.mask;
   };
 
-  struct Slice { f4 a[NQ]; f4 b[NQ]; };
+  struct Slice { f4 a[NQ]; f4 b[NBW][NQ]; };
   // per-unit context (wave-uniform scalars + the lane's column)
   struct Ctx {
     const int32_t *meta;   // LDS block of the unit
     uint32_t wg_mask;
     int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
     int v_w;
-    float ps, pb, as, ab;
+    float ps[NBW], pb[NBW], as[NBW], ab[NBW];
     bool col_ok;
   };
 
   Slice S[DEPTH];   // operand ring: DEPTH-1 slices of loads in flight behind the one multiplied
-  float resv[4];
+  float resv[NBW][4];
 
   // lane (h, i) owns channels s*CK + h*HC .. + HC-1 of gathered row i: HC*4 contiguous bytes of the
   // row (CK = 32: the half-wave pair reads the row's whole 128-B line in one slice) and the
@@ -366,10 +366,14 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     for (int q = 0; q < NQ; ++q)
       S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, 0));
     const int s_w = (k * c8 + s * (CK / 8)) * p.Cout * 32;
+    // column block n of the unit: the same packed block 32 columns (1 KB) further on
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      S.b[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                          rs_w, c.v_w + (q & 1) * 16, s_w + (q >> 1) * (p.Cout * 32), 0));
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        S.b[n][q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rs_w, c.v_w + n * 1024 + (q & 1) * 16,
+                                               s_w + (q >> 1) * (p.Cout * 32), 0));
   };
 
   auto advance = [&](const Ctx &c, int &k, int &s) {
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     }
     m = __builtin_amdgcn_readfirstlane(m);
     c.wg_mask = m;
-    c.col = d.cu * 32 + arow;
+    c.col = d.cu * (32 * NBW) + arow;
     c.col_ok = c.col < p.Cout;
     const int colc = min(c.col, p.Cout - 1);
     c.v_w = (ahalf * (HC / 8) * p.Cout + colc) * 32;
@@ -419,31 +423,42 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     for (int rr = 0; rr < 4; ++rr) {
       const unsigned off = (row4[rr] >= 0 && c.col_ok)
                                ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
-      resv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, 0, 0));
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        resv[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, n * 128, 0));
     }
-    c.ps = c.pb = c.as = c.ab = 0.f;
-    if (post) {            // uniform
-      c.ps = p.post_scale[colc];
-      c.pb = p.post_shift[colc];
-    }
-    if (act) {
-      c.as = p.act_scale[colc];
-      c.ab = p.act_shift[colc];
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      c.ps[n] = c.pb[n] = c.as[n] = c.ab[n] = 0.f;
+      if (post) {            // uniform
+        c.ps[n] = p.post_scale[colc + 32 * n];
+        c.pb[n] = p.post_shift[colc + 32 * n];
+      }
+      if (act) {
+        c.as[n] = p.act_scale[colc + 32 * n];
+        c.ab[n] = p.act_shift[colc + 32 * n];
+      }
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[NBW];
   auto compute = [&](Slice &S) {
     // every operand of the slice is in registers before the matrix block starts: one wait, then
-    // back-to-back MFMAs with nothing in between
+    // back-to-back MFMAs with nothing in between (the column blocks alternate: independent chains)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(S.a[q]), "+v"(S.b[q]));
+    for (int q = 0; q < NQ; ++q) {
+      asm volatile("" : "+v"(S.a[q]));
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) asm volatile("" : "+v"(S.b[n][q]));
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S.a[q][j], S.b[q][j], acc, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.a[q][j], S.b[n][q][j], acc[n], 0, 0, 0);
   };
 
   unsigned long long stamp[8];
@@ -478,7 +493,9 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     const Unit dn = decode(has_next ? un : u);
     fetch(dn, m);                       // lands during the matrix loop
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     // ---- matrix loop over this wave's items.  S[0..DEPTH-2] already hold items 0..DEPTH-2
     //      (setup).  Past the end the last item is re-read and dropped, so every load is
@@ -507,14 +524,16 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       for (int i = 0; i < DEPTH - 1; ++i)
         if (i < tail) compute(S[i]);
     }
-    if constexpr (TRACE) { asm volatile("" : "+v"(acc[0])); }
+    if constexpr (TRACE) { asm volatile("" : "+v"(acc[0][0])); }
     mark(1);
 
     // ---- partial sums + residual rows + next unit's metadata meet in LDS
     __syncthreads();                     // the previous unit's epilogue has read `red`
     mark(2);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
+    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) red[((wave * NBW + n) * 16 + reg) * 64 + lane] = acc[n][reg];
     publish(m, buf ^ 1);
     __syncthreads();
     mark(3);
@@ -522,25 +541,30 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     // ---- epilogue operands first (all LDS reads in flight together), then the next unit's first
     //      operand loads, then the stores: fixed-order sum w0+w1+w2+w3 (+ residual, post); each
     //      wave stores 4 row groups, padding rows go past the end of the buffer (dropped)
-    float v[4], va[4];
+    float v[NBW][4], va[NBW][4];
     unsigned o_off[4];
     {
       const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
       const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
-      float part[4][4];
+      float part[NBW][4][4];
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int reg = wave * 4 + rr;
+#pragma unroll
+          for (int w = 0; w < kWavesPerWg; ++w) part[n][rr][w] = red[((w * NBW + n) * 16 + reg) * 64 + lane];
+        }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int reg = wave * 4 + rr;
 #pragma unroll
-        for (int w = 0; w < kWavesPerWg; ++w) part[rr][w] = red[(w * 16 + reg) * 64 + lane];
-      }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float t = ((part[rr][0] + part[rr][1]) + part[rr][2]) + part[rr][3];
-        t += resv[rr];       // residual rows of THIS unit (requested by its setup, one unit ago)
-        if (post) t = fmaxf(fmaf(t, c.ps, c.pb), 0.f);
-        v[rr] = t;
-        va[rr] = fmaxf(fmaf(t, c.as, c.ab), 0.f);
+        for (int n = 0; n < NBW; ++n) {
+          float t = ((part[n][rr][0] + part[n][rr][1]) + part[n][rr][2]) + part[n][rr][3];
+          t += resv[n][rr];    // residual rows of THIS unit (requested by its setup, one unit ago)
+          if (post) t = fmaxf(fmaf(t, c.ps[n], c.pb[n]), 0.f);
+          v[n][rr] = t;
+          va[n][rr] = fmaxf(fmaf(t, c.as[n], c.ab[n]), 0.f);
+        }
         o_off[rr] = (row4[rr] >= 0 && c.col_ok)
                         ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
       }
@@ -551,11 +575,17 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     mark(4);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), rs_out, o_off[rr], o_base, 0);
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
+                                              o_base + n * 128, 0);
     if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[rr]), rs_act, o_off[rr], 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[n][rr]), rs_act, o_off[rr],
+                                                n * 128, 0);
     }
     mark(5);
     if constexpr (TRACE) {
@@ -786,6 +816,12 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     bpu = NB < 4 ? NB : 4;
     while (bpu > 1 && static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) < target) --bpu;
   }
+  // persistent kernel, large layers with an even number of column blocks: 2 blocks per unit (the
+  // gathered rows are read once for both, half as many unit boundaries).  SG_CONV_NBW=1 disables it.
+  static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;   // developer knob
+  const bool wide = persistent && nbw_env >= 2 && NB % 2 == 0 &&
+                    static_cast<long long>(num_tiles) * (NB / 2) >= 2048;
+  if (wide) bpu = 2;
   const int col_units = (NB + bpu - 1) / bpu;
   int ksplit = 1;
   const long long waves = static_cast<long long>(num_tiles) * col_units * waves_per_unit;
@@ -816,7 +852,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   if (persistent) {
     // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
     // XCD u % 8)
-    const size_t lds = static_cast<size_t>(kWavesPerWg) * 16 * 64 * sizeof(float) +
+    const size_t lds = static_cast<size_t>(kWavesPerWg) * (wide ? 2 : 1) * 16 * 64 * sizeof(float) +
                        2 * kMetaInts * sizeof(int32_t);
     static int num_cu = 0;
     if (num_cu == 0) {
@@ -835,26 +871,28 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // held to 80 VGPRs, 6 workgroups per CU (developer knob for the occupancy A/B)
     static const int wpe_env = getenv("SG_CONV_WPE") ? atoi(getenv("SG_CONV_WPE")) : 5;
     const bool wpe6 = wpe_env >= 6;
-    static int occ_tab[4] = {0, 0, 0, 0};     // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves
+    static int occ_tab[5] = {0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide
     auto occupancy = [&](int which) {
       if (occ_tab[which] == 0) {
         int o = 0;
         if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 5>, 256, lds);
         else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0, 4>, 256, lds);
         else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0, 2>, 256, lds);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
+        else if (which == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
         if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
         occ_tab[which] = o < 1 ? 1 : o;
       }
       return occ_tab[which];
     };
-    int which = wpe6 ? 3 : 0;
-    if (units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
+    int which = wide ? 4 : wpe6 ? 3 : 0;
+    if (!wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
       which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : which;
     const int occ = occupancy(which);
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 3) gather_conv_persistent_kernel<kSliceCh, 2, 0, 6><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 1) gather_conv_persistent_kernel<kSliceCh, 4, 0, 4><<<g_, 256, lds, stream>>>(a, ib_, wb_);
