@@ -570,15 +570,21 @@ class SoftGroup(nn.Module):
             npoint = torch.empty((n_inst, nc), dtype=torch.int32, device=dev)
             L.check(lib.sg_instance_npoint(L.ptr(pairs), L.ptr(ms), S, ms.size(1), nc, mthr, n_inst,
                                            L.ptr(npoint), L.stream()), 'sg_instance_npoint')
-            keep = (cls_prob[:, :nc] > _cfg(tcfg, 'cls_score_thr')) & \
-                (npoint >= _cfg(tcfg, 'min_npoint'))                                # [n_inst, nc]
-            kept = keep.t().nonzero()                       # (class, proposal), class-major order
-            n_kept = kept.size(0)
+            # one read-back of the three small [n_inst, nc] tables; which (class, proposal) pairs are
+            # kept, their order (class-major, the reference's) and the run capacity are host work
+            probs = cls_prob[:, :nc].contiguous()
+            score = probs * iou_scores[:, :nc].clamp(0, 1)
+            host = torch.stack([npoint.view(torch.float32), probs, score]).cpu().numpy()
+            npoint_h = host[0].view(np.int32)
+            keep = (host[1] > _cfg(tcfg, 'cls_score_thr')) & (npoint_h >= _cfg(tcfg, 'min_npoint'))
+            kept = np.argwhere(keep.T)                      # rows (class, proposal), class-major
+            n_kept = kept.shape[0]
             if n_kept == 0:
                 return []
-            inst_of = torch.full((nc, n_inst), -1, dtype=torch.int32, device=dev)
-            inst_of[kept[:, 0], kept[:, 1]] = torch.arange(n_kept, dtype=torch.int32, device=dev)
-            cap = int((npoint * keep).sum().item())         # every kept point is at most one run
+            inst_of_h = np.full((nc, n_inst), -1, dtype=np.int32)
+            inst_of_h[kept[:, 0], kept[:, 1]] = np.arange(n_kept, dtype=np.int32)
+            inst_of = torch.from_numpy(inst_of_h).to(dev, non_blocking=True)
+            cap = int(npoint_h[keep].sum())                 # every kept point is at most one run
             starts = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
             ends = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
             bounds = torch.empty(n_kept + 1, dtype=torch.int64, device=dev)
@@ -596,9 +602,8 @@ class SoftGroup(nn.Module):
             L.check(lib.sg_rle_format_device(L.ptr(starts), L.ptr(ends), L.ptr(bounds), n_kept, cap,
                                              n_out, L.ptr(text), tcap, L.ptr(text_off), L.ptr(ws),
                                              ws.numel(), L.stream()), 'sg_rle_format_device')
-            score = (cls_prob[:, :nc] * iou_scores[:, :nc].clamp(0, 1))[kept[:, 1], kept[:, 0]]
-            cls_pred = (kept[:, 0] + 1).cpu().numpy()
-            score_pred = score.cpu().numpy()
+            cls_pred = kept[:, 0] + 1
+            score_pred = host[2][kept[:, 1], kept[:, 0]]
             o = text_off.cpu().tolist()
             masks = rle_text_to_dicts(n_out, text, o)
             return [dict(scan_id=scan_id, label_id=cls_pred[k], conf=score_pred[k],
