@@ -1,0 +1,53 @@
+"""Developer tool: which Python lines issue copies / fills / casts in one forward (TorchDispatchMode
++ the Python stack)."""
+import collections
+import os
+import sys
+import traceback
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from softgroup_amd import synthetic  # noqa: E402
+
+WATCH = ('copy_', '_to_copy', 'fill_', 'zero_', 'zeros', 'full', 'item', '_local_scalar_dense', 'nonzero',
+         'clone', 'contiguous', 'cat', 'index_put_', 'empty_like', 'ones', 'arange')
+
+
+class Spy(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.cnt = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split('.')[0]
+        if name in WATCH:
+            where = '?'
+            for f in reversed(traceback.extract_stack()):
+                if 'softgroup_amd/' in f.filename and 'tools/' not in f.filename:
+                    where = f'{f.filename.split("softgroup_amd/")[-1]}:{f.lineno}'
+                    break
+            self.cnt[(where, name)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+def main():
+    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=150000)
+    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    model = synthetic.build_model(seed=0)
+    with torch.no_grad():
+        for _ in range(3):
+            model(batch)
+        torch.cuda.synchronize()
+        spy = Spy()
+        with spy:
+            model(batch)
+            torch.cuda.synchronize()
+    for (where, n), c in sorted(spy.cnt.items()):
+        print(f'{c:3d} {n:22s} {where}')
+
+
+if __name__ == '__main__':
+    main()

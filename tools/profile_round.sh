@@ -2,8 +2,9 @@
 # Collects the round's measurement set on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh r02
 # -> gpurun_out/<tag>_bench.json, _bench_under_rocprof.json, _kernel_stats.csv, _conv_by_grid.txt,
-#    _conv_pmc.{txt,json} (separate --pmc passes, --kernel-trace only), _calib.txt (FETCH/WRITE_SIZE
-#    on known byte counts).  Copy what should be judged into profiles/.
+#    _conv_pmc.{txt,json} (separate --pmc passes, --kernel-trace only), _train_* (training kernels),
+#    with CALIB=1 also _calib.txt (FETCH/WRITE_SIZE on known byte counts).  Copy what should be
+#    judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02}
 OUT=$R/gpurun_out
@@ -29,12 +30,20 @@ for S in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
   echo "== $S" >> $OUT/${TAG}_conv_pmc.txt
   python $R/tools/pmc_summary.py /tmp/pmc gather_conv_persistent_kernel --json $OUT/${TAG}_conv_pmc.json --scans 8 >> $OUT/${TAG}_conv_pmc.txt 2>&1
 done
-rm -f $OUT/${TAG}_calib.txt
-for S in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/cal
-  rocprofv3 --pmc $S --kernel-trace --output-format csv -d /tmp/cal -- $R/tools/micro/fetch_calib >> $OUT/${TAG}_calib.txt 2>/dev/null
-  echo "== $S" >> $OUT/${TAG}_calib.txt
-  python $R/tools/pmc_summary.py /tmp/cal _kernel >> $OUT/${TAG}_calib.txt 2>&1
-done
-rocprofv3 -L 2>/dev/null | grep -o "TA_[A-Z_a-z]*\|TCP_[A-Z_a-z]*" | sort -u | head -80 > $OUT/${TAG}_counters_ta_tcp.txt
+# training-side kernels (bf16 forward / deterministic wgrad): per-level table + kernel stats
+python $R/tools/train_conv_bench.py > $OUT/${TAG}_train_conv.txt 2>/dev/null < /dev/null
+rm -rf /tmp/proft
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft -o r -- python $R/tools/train_conv_bench.py > /dev/null 2> /tmp/proft.err < /dev/null
+F=$(find /tmp/proft -name "*kernel_stats.csv" | head -1)
+if [ -n "$F" ]; then cp "$F" $OUT/${TAG}_train_kernel_stats.csv; fi
+python $R/tools/train_step_bench.py 2>/dev/null < /dev/null | grep "ms/step" > $OUT/${TAG}_train_step.txt
+if [ -n "$CALIB" ]; then
+  rm -f $OUT/${TAG}_calib.txt
+  for S in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/cal
+    rocprofv3 --pmc $S --kernel-trace --output-format csv -d /tmp/cal -- $R/tools/micro/fetch_calib >> $OUT/${TAG}_calib.txt 2>/dev/null
+    echo "== $S" >> $OUT/${TAG}_calib.txt
+    python $R/tools/pmc_summary.py /tmp/cal _kernel >> $OUT/${TAG}_calib.txt 2>&1
+  done
+fi
 echo done
