@@ -47,7 +47,7 @@ REF_MS_PER_SCAN = 288.0       # reference README.md:22, 1x Titan X,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--steps', type=int, default=160)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--points', type=int, default=150000)
     ap.add_argument('--contexts', type=int, default=4, help='scans in flight in the timed region')
