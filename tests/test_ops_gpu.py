@@ -435,3 +435,29 @@ def test_rle_text_on_device_digit_boundaries_and_empty_instances():
     # a text buffer below the bound is refused
     assert lib.sg_rle_format_device(L.ptr(d_st), L.ptr(d_en), L.ptr(d_b), n, cap, length, L.ptr(text),
                                     tcap - 1, L.ptr(text_off), L.ptr(ws), ws.numel(), L.stream()) != 0
+
+
+@pytest.mark.parametrize('C', [3, 32, 33, 128])
+def test_row_gather_and_bn_relu_glue(C):
+    """sg_gather_rows_* (devoxelize, softgroup.py:374,677) and sg_bn_relu_f32 (output_layer,
+    softgroup.py:65) against torch indexing / the same affine + ReLU: copies are bit-exact, int32
+    and int64 indices, repeated and empty index lists, channel counts off the float4 path."""
+    from softgroup_amd import _lib as L
+    from softgroup_amd.model.softgroup import _take_rows
+    lib = L.lib()
+    torch.manual_seed(C)
+    M, N = 1237, 4001
+    feats = torch.randn(M, C, device=DEV)
+    for dt in (torch.int32, torch.int64):
+        index = torch.randint(0, M, (N, ), device=DEV).to(dt)
+        assert torch.equal(_take_rows(feats, index), feats[index.long()])
+        assert _take_rows(feats, index[:0]).shape == (0, C)
+    scale = torch.rand(C, device=DEV) + 0.5
+    shift = torch.randn(C, device=DEV)
+    for relu in (1, 0):
+        out = torch.empty_like(feats)
+        L.check(lib.sg_bn_relu_f32(L.ptr(feats), L.ptr(scale), L.ptr(shift), M, C, relu, L.ptr(out),
+                                   L.stream()), 'sg_bn_relu_f32')
+        ref = torch.addcmul(shift, feats, scale)          # one fma per element, like the kernel
+        ref = ref.clamp_min(0) if relu else ref
+        np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=1e-6)
