@@ -422,6 +422,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist_on:
+        dist.barrier()          # leave together: rank 0 was still measuring its extras
         dist.destroy_process_group()
 
 
