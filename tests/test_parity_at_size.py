@@ -19,8 +19,9 @@ from softgroup_amd import ops, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def test_s2_150k_full_model_parity():
-    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=150000)
+@pytest.mark.parametrize('seed', [1, 7])      # 1 = the bench scene of rank 0, 7 = rank 6's scene at N=8
+def test_s2_150k_full_model_parity(seed):
+    xyz, rgb, inst = synthetic.scene_s2(seed=seed, n=150000)
     batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
     model = synthetic.build_model(seed=0)
     rep = parity.parity_report(model, batch, synthetic.SCANNET_MODEL_CFG)
