@@ -54,7 +54,40 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-legs', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' + --stub: the launch / sharding / timing plumbing on CPU (tests)")
+    ap.add_argument('--stub', action='store_true',
+                    help='replace the scan by a fixed host-side delay (plumbing test, no GPU)')
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: launch N ranks of this script, one process per
+    GPU, the way the reference's tools/dist_test.sh:7 does (torchrun, OMP_NUM_THREADS=1), and hand
+    its exit code back.  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS='1', MASTER_ADDR='127.0.0.1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def device_identity(stub, rank):
+    """something that differs between two physical GPUs: uuid, else PCI address, else the index"""
+    if stub:
+        return f'cpu:{rank}'
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    for attr in ('uuid', 'pci_bus_id'):
+        v = getattr(p, attr, None)
+        if v not in (None, ''):
+            extra = f':{getattr(p, "pci_domain_id", 0)}:{getattr(p, "pci_device_id", 0)}' if attr == 'pci_bus_id' else ''
+            return f'{attr}={v}{extra}'
+    return f'index={torch.cuda.current_device()}'
 
 
 def stage_times(model, batch, reps=5):
@@ -229,17 +262,87 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
     return legs
 
 
+def timed_steps(step, resolve, steps, sync_all):
+    """the contract's timed region: EXACTLY `steps` steps between two barrier+synchronize brackets.
+    Also returns the ms/step of each third of the region (host time stamps taken as results of
+    the window's last step are resolved) -- the rate of a run with several scans in flight wanders
+    between windows, the median says how representative the whole-region figure is."""
+    sync_all()
+    t0 = time.perf_counter()
+    rets = [step() for _ in range(steps)]
+    marks, cuts = [], [steps * (i + 1) // 3 for i in range(3)]
+    for i, r in enumerate(rets):
+        resolve(r)
+        if i + 1 in cuts:
+            marks.append(time.perf_counter())
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    windows, prev_t, prev_n = [], t0, 0
+    for m, c in zip(marks, cuts):
+        if c > prev_n:
+            windows.append((m - prev_t) / (c - prev_n) * 1e3)
+        prev_t, prev_n = m, c
+    return elapsed, rets, windows
+
+
+def stub_main(args, rank, world, devices):
+    """plumbing only (tests/test_bench_launch.py): same launch, barrier, MAX-over-ranks and JSON
+    code as the real run, the scan replaced by a 2 ms host delay"""
+    import torch.distributed as dist
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    elapsed, _, windows = timed_steps(lambda: time.sleep(0.002), lambda r: None, args.steps, sync_all)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'stub steps/s (plumbing test)', 'value': round(world * args.steps / elapsed, 3),
+                          'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub',
+                          'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == max(args.gpus, 1), f'--gpus {args.gpus} but the launcher started {world} ranks'
     dist_on = world > 1
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank if torch.cuda.device_count() > local_rank else 0)
+    if dist_on:
+        # one process per GPU next to N-1 others on the same host: no intra-op thread pools
+        # (a single torch CPU op otherwise wakes one thread per host core, DESIGN.md section 7)
+        torch.set_num_threads(1)
+    if not args.stub:
+        n_dev = torch.cuda.device_count()
+        assert n_dev > local_rank, (f'rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible -- '
+                                    f'refusing to share a device between ranks')
+        torch.cuda.set_device(local_rank)
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')       # RCCL on ROCm
+        dist.init_process_group(args.backend)       # 'nccl' is RCCL on ROCm
+    # every rank's device: all distinct, or the figure would be N ranks time-sharing one GPU
+    ident = device_identity(args.stub, rank)
+    devices = [ident]
+    if dist_on:
+        devices = [None] * world
+        dist.all_gather_object(devices, ident)
+        assert len(set(devices)) == world, f'ranks share a device: {devices}'
+    if args.stub:
+        return stub_main(args, rank, world, devices)
     from softgroup_amd import _lib, synthetic
     from softgroup_amd.spconv import core as spcore
     assert os.path.exists(_lib.LIB_PATH), 'libsoftgroup_hip.so missing: run __graft_entry__.build()'
@@ -263,13 +366,8 @@ def main():
     with torch.no_grad():
         for r in [model(batch) for _ in range(max(args.warmup, 1))]:
             r.resolve()
-        sync_all()
-        t0 = time.perf_counter()
-        rets = [model(batch) for _ in range(args.steps)]
-        for r in rets:
-            r.resolve()
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        elapsed, rets, windows = timed_steps(lambda: model(batch), lambda r: r.resolve(), args.steps,
+                                             sync_all)
     assert all('pred_instances' in r and 'semantic_preds' in r for r in rets)
     del rets
     if dist_on:
@@ -283,18 +381,25 @@ def main():
         'metric': 'scans/sec ScanNet-v2-like inference (softgroup_scannet.yaml, full forward_test)',
         'value': round(value, 3), 'unit': 'scans/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': round(value / world / (1000.0 / REF_MS_PER_SCAN), 3),
+        'scaling': 'weak', 'vs_baseline': None,      # filled below from the single-scan latency
+        'vs_baseline_throughput': round(value / world / (1000.0 / REF_MS_PER_SCAN), 3),
         'dtype': 'f32', 'data': 'synthetic',
         'config': {
             'workload': f'S2 synthetic room scene, {args.points} pts/scene, 0.02 m voxels, one scene '
                         f'per GPU; softgroup_scannet.yaml model section; random-init weights '
                         f'(30.84 M params), BN running stats randomised, semantic head last layer '
                         f're-drawn with std 20 so grouping/refinement run on a realistic load',
-            'baseline_note': 'vs_baseline = per-GPU scans/s / (1000/288): 288 ms/scan is the '
-                             'reference README number on 1x Titan X with real ScanNet v2 data',
+            'baseline_note': 'vs_baseline = 288 / latency_ms (one scan at a time, like the reference '
+                             'figure); vs_baseline_throughput = per-GPU scans/s / (1000/288) with '
+                             'scans_in_flight scans overlapping; 288 ms/scan is the reference README '
+                             'number on 1x Titan X with real ScanNet v2 data',
             'parallelism': f'scenes sharded one per GPU x{world}, no data-path collective',
             'scans_in_flight': model.scan_contexts,
         },
+        'ranks_seen': world, 'devices': devices,
+        # ms/scan of each third of the timed region on rank 0, and their median
+        'ms_per_step_windows': [round(w, 3) for w in windows],
+        'ms_per_step_window_median': round(sorted(windows)[len(windows) // 2], 3) if windows else None,
     }
     model.scan_contexts = 1
 
@@ -318,6 +423,8 @@ def main():
                 model(batch)
             torch.cuda.synchronize()
             out['ms_per_step_unpipelined'] = round((time.perf_counter() - t1) / min(args.steps, 10) * 1e3, 3)
+        out['latency_ms'] = out['ms_per_step_unpipelined']        # one scan, everything in line
+        out['vs_baseline'] = round(REF_MS_PER_SCAN / out['latency_ms'], 3)
         model.async_results = True
         stages, info = stage_times(model, batch)
         out['stages_ms'] = stages
@@ -357,14 +464,15 @@ def main():
         tflops = s['flops'] / (s['ms'] * 1e-3) / 1e12
         launches = max(s['launches'], 1)
         # HBM traffic of the same kernel from rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in KiB, separate
-        # passes, collected by the recipe in profiles/README.md on this workload and committed as
-        # profiles/r01_conv_pmc.json).  FETCH_SIZE x2 is the guide's gfx950 correction for 16-B/lane
-        # reads (MI355X_MICROARCH.md "HBM"); null when the file is not there.
+        # passes, collected by tools/profile_round.sh on this workload and committed as
+        # profiles/rNN_conv_pmc.json, newest round first).  The FETCH_SIZE factor is the one stored
+        # in the file: calibrated on this kernel's access pattern (profiles/r02_calib.txt, x1.97;
+        # the guide's gfx950 correction is x2); null when no file is there.
         # NOT measured in this run (PMC needs rocprofv3 around the process): `traffic_source` says
         # which committed counter file the figure comes from and which FETCH_SIZE factor was applied.
         traffic, traffic_source = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for fn in ('r02_conv_pmc.json', 'r01_conv_pmc.json'):
+        for fn in ('r03_conv_pmc.json', 'r02_conv_pmc.json', 'r01_conv_pmc.json'):
             try:
                 rec = json.load(open(os.path.join(here, 'profiles', fn)))
                 pmc = rec['counters']

@@ -9,8 +9,16 @@
                                  cuda*->hip* shim (oracle/ref_shims_gpu), C entry points in
                                  oracle/ref_gpu_tu.hip, Python front end oracle/ref_gpu.py
 
+  oracle/_ref/pysrc/             the reference's own PYTHON (softgroup/{model,util,evaluation,data}
+                                 and tools/test.py) byte-compiled from the sources where they lie
+                                 into sourceless .pyc files -- a build output like the .so files:
+                                 no reference source text enters the repository.  It lets the GPU
+                                 box (which has no /root/reference) import the reference's SoftGroup
+                                 class, dataset, evaluator and test loop on top of the HIP operators
+                                 (tests/test_dropin_gpu.py); oracle/facade.py falls back to it.
+
 Outputs go only to oracle/_ref/ (git-ignored, but shipped to the GPU box).  Skips silently when
-/root/reference is absent (GPU box: the prebuilt .so files are used)."""
+/root/reference is absent (GPU box: the prebuilt files are used)."""
 import os
 import subprocess
 import sys
@@ -22,6 +30,33 @@ OUT_DIR = os.path.join(HERE, '_ref')
 OUT = os.path.join(OUT_DIR, 'sg_ref_ops.so')
 OUT_GPU = os.path.join(OUT_DIR, 'sg_ref_gpu_ops.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+REF_ROOT = '/root/reference'
+PY_OUT = os.path.join(OUT_DIR, 'pysrc')
+PY_PACKAGES = ('softgroup/model', 'softgroup/util', 'softgroup/evaluation', 'softgroup/data')
+PY_FILES = ('tools/test.py', 'tools/train.py')
+
+
+def build_py(force=False):
+    """byte-compile the reference's Python packages (sourceless import layout: <pkg>/<mod>.pyc).
+    The .pyc magic number is the interpreter's; the GPU box runs the same image."""
+    import py_compile
+    if not os.path.isdir(os.path.join(REF_ROOT, 'softgroup')):
+        return PY_OUT if os.path.isdir(PY_OUT) else None
+    jobs = []
+    for pkg in PY_PACKAGES:
+        d = os.path.join(REF_ROOT, pkg)
+        jobs += [(os.path.join(d, f), os.path.join(PY_OUT, pkg, f + 'c'))
+                 for f in sorted(os.listdir(d)) if f.endswith('.py')]
+    jobs += [(os.path.join(REF_ROOT, f), os.path.join(PY_OUT, f + 'c')) for f in PY_FILES]
+    for src, dst in jobs:
+        if not force and os.path.exists(dst) and os.path.getmtime(dst) > os.path.getmtime(src):
+            continue
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        py_compile.compile(src, cfile=dst, dfile=os.path.relpath(src, REF_ROOT), doraise=True)
+    with open(os.path.join(PY_OUT, 'MAGIC'), 'wb') as f:
+        import importlib.util
+        f.write(importlib.util.MAGIC_NUMBER)
+    return PY_OUT
 
 
 def build_gpu(force=False):
@@ -49,6 +84,7 @@ def build_gpu(force=False):
 
 def build(force=False):
     build_gpu(force)
+    build_py(force)
     if not os.path.isdir(REF_SRC):
         return OUT if os.path.exists(OUT) else None
     src = os.path.join(HERE, 'ref_tu.cpp')

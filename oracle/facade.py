@@ -18,9 +18,15 @@ masks and rle_encode) is executed AS WRITTEN, so its outputs can be stored as go
 ``.cuda()`` / ``device='cuda'`` in a few places; ``reference_model()`` neutralises exactly those
 (Tensor.cuda -> identity, torch.zeros/tensor/ones(device='cuda') -> CPU) while the model runs.
 
-Only tests/ and tests/golden/*.py import this module; needs /root/reference (authoring container)."""
+Only tests/ and tests/golden/*.py import this module.  The reference's Python is imported from
+/root/reference where that exists (authoring container) and otherwise from oracle/_ref/pysrc --
+the same files byte-compiled by oracle/build_ref.py (sourceless .pyc; a git-ignored build output
+that travels to the GPU box like the .so files)."""
 import contextlib
 import importlib
+import importlib.machinery
+import importlib.util
+import os
 import sys
 import types
 from collections import OrderedDict
@@ -31,7 +37,20 @@ from torch import nn
 
 import oracle as O
 
-REF_ROOT = '/root/reference'
+REF_ROOT = os.environ.get('SG_REF_ROOT', '/root/reference')   # (override: exercise the .pyc path here)
+PYC_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'pysrc')
+
+
+def ref_root():
+    """directory holding the reference's `softgroup/` and `tools/` Python: the reference tree itself,
+    or its byte-compiled image under oracle/_ref/pysrc (None if neither exists)"""
+    if os.path.isdir(os.path.join(REF_ROOT, 'softgroup', 'model')):
+        return REF_ROOT
+    if os.path.isdir(os.path.join(PYC_ROOT, 'softgroup', 'model')):
+        magic = open(os.path.join(PYC_ROOT, 'MAGIC'), 'rb').read()
+        assert magic == importlib.util.MAGIC_NUMBER, 'oracle/_ref/pysrc was compiled by another Python'
+        return PYC_ROOT
+    return None
 
 
 def _t(a, dtype=None):
@@ -232,19 +251,60 @@ def import_reference(ops_module=None, spconv_modules=None):
     """Import /root/reference/softgroup/model with the given stand-ins for `softgroup.ops` and
     `spconv.pytorch` (default: the oracle-backed CPU ones of this file).  Returns the module
     `softgroup.model.softgroup`."""
-    import os
-    assert os.path.isdir(REF_ROOT), 'needs /root/reference'
+    root = ref_root()
+    assert root is not None, 'needs /root/reference or oracle/_ref/pysrc (oracle/build_ref.py)'
     for k in [k for k in sys.modules if k == 'softgroup' or k.startswith('softgroup.')]:
         del sys.modules[k]
     sys.modules.update(spconv_modules or _spconv_modules())
     tb = types.ModuleType('tensorboardX')
     tb.SummaryWriter = object
     sys.modules.setdefault('tensorboardX', tb)
+    ply = types.ModuleType('plyfile')          # instance_eval_util imports it for file export only
+    ply.PlyData = ply.PlyElement = object
+    sys.modules.setdefault('plyfile', ply)
     pkg = types.ModuleType('softgroup')
-    pkg.__path__ = [os.path.join(REF_ROOT, 'softgroup')]
+    pkg.__path__ = [os.path.join(root, 'softgroup')]
     sys.modules['softgroup'] = pkg
     sys.modules['softgroup.ops'] = ops_module or _ops_module()
     return importlib.import_module('softgroup.model.softgroup')
+
+
+class Munch(dict):
+    """stand-in for munch.Munch (not installed): dict with attribute access, as tools/test.py and
+    tools/train.py use it (`Munch.fromDict(yaml)`, `cfg.model`, `getattr(cfg, key, default)`)"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    __setattr__ = dict.__setitem__
+
+    @classmethod
+    def fromDict(cls, d):
+        if isinstance(d, dict):
+            return cls((k, cls.fromDict(v)) for k, v in d.items())
+        if isinstance(d, (list, tuple)):
+            return type(d)(cls.fromDict(v) for v in d)
+        return d
+
+
+def import_reference_tool(name):
+    """the reference's tools/<name>.py as a module (call after import_reference, which installs the
+    `softgroup` package the tool imports)"""
+    root = ref_root()
+    m = types.ModuleType('munch')
+    m.Munch = Munch
+    sys.modules.setdefault('munch', m)
+    src = os.path.join(root, 'tools', name + '.py')
+    path = src if os.path.exists(src) else src + 'c'
+    loader = (importlib.machinery.SourceFileLoader if path.endswith('.py')
+              else importlib.machinery.SourcelessFileLoader)(f'ref_tools_{name}', path)
+    spec = importlib.util.spec_from_loader(loader.name, loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
 
 
 @contextlib.contextmanager

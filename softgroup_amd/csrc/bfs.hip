@@ -224,6 +224,19 @@ __global__ void __launch_bounds__(256) bfs_zero_size_kernel(int n, int32_t *size
   if (i < n) size[i] = 0;
 }
 
+// Recovery path of the multi-workgroup replay (bfs_emit_big_kernel): if its bounded grid barrier
+// ever gave up (workgroups not co-resident: `fail` set), the claim words of the giant clusters are
+// put back to "unvisited" and the per-cluster kernel replays those clusters alone.  Gated on the
+// device: without a failure both launches return at once, the host never waits.
+__global__ void __launch_bounds__(256) bfs_owner_reset_kernel(int n, const int4 *__restrict__ label,
+                                                             const int32_t *__restrict__ size,
+                                                             int min_size, const int32_t *gate,
+                                                             int32_t *__restrict__ owner) {
+  if (SG_LD(gate) == 0) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (size[label[i].x] > min_size) owner[i] = 0x7fffffff;
+}
+
 // emit: cluster_offsets[cid+1] and the seed list
 __global__ void __launch_bounds__(256) bfs_seed_kernel(int n, const int4 *__restrict__ label,
                                                       const int32_t *__restrict__ size,
@@ -311,7 +324,9 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ idx, const int32_t *__restrict__ start_len,
     const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
-    int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats, int skip_above) {
+    int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats, int skip_above, int only_above,
+    const int32_t *gate /* null, or a word that must be non-zero for the launch to do anything */) {
+  if (gate != nullptr && SG_LD(gate) == 0) return;
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
   __shared__ int f_st[2][kFrontChunk], f_ln[2][kFrontChunk];
@@ -324,7 +339,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int seed = seeds[c];
     const int off = cluster_offsets[c];
     const int size = cluster_offsets[c + 1] - off;
-    if (size > skip_above) continue;        // giant clusters: bfs_emit_big_kernel (all workgroups)
+    if (size > skip_above || size <= only_above) continue;   // giant clusters: bfs_emit_big_kernel
     const bool own_in_lds = size <= kOwnCap;
     int32_t *Q = cluster_idxs + 2LL * off;  // pairs (cluster id, point); queue = column 1
     if (own_in_lds)
@@ -856,16 +871,25 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
-      stats, big_on ? kBigMin : 0x7fffffff);
+      stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr);
   if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
     static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 32;   // developer knob
     const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
     int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 2 * kBigWgsMax ints
     if (static_cast<size_t>(n) >= 64 + 2 * kBigWgsMax) {
       hipMemsetAsync(sync, 0, (64 + 2 * kBigWgsMax) * 4, stream);
+      if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))      // test hook: pretend the barrier gave up
+        if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
       bfs_emit_big_kernel<<<big_wgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
                                                               cluster_offsets, n_cluster, w.owner,
                                                               w.wcnt, cluster_idxs, sync);
+      // sync[1] != 0: the replay gave up somewhere (see big_barrier) -- redo the giant clusters on
+      // the per-cluster kernel (same output, slower); both launches are no-ops otherwise
+      bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin,
+                                                                        sync + 1, w.owner);
+      bfs_emit_kernel<<<min(n_cluster, 256), kEmitThreads, 0, stream>>>(
+          bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner,
+          cluster_idxs, nullptr, 0x7fffffff, kBigMin, sync + 1);
     }
   }
   if (want_stats) {

@@ -819,7 +819,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   // persistent kernel, large layers with an even number of column blocks: 2 blocks per unit (the
   // gathered rows are read once for both, half as many unit boundaries).  SG_CONV_NBW=1 disables it.
   static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;   // developer knob
-  const bool wide = persistent && nbw_env >= 2 && NB % 2 == 0 &&
+  // (Cout % 64 == 0: the second column block of a unit is addressed without its own bounds check)
+  const bool wide = persistent && nbw_env >= 2 && Cout % 64 == 0 &&
                     static_cast<long long>(num_tiles) * (NB / 2) >= 2048;
   if (wide) bpu = 2;
   const int col_units = (NB + bpu - 1) / bpu;

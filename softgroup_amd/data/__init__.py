@@ -15,19 +15,23 @@ dict (keys, dtypes, values), but
 
 Every tensor of the result is already resident: ``forward_test``'s ``cuda_cast`` is a no-op.
 """
+import threading
+
 import numpy as np
 import torch
 
 from .. import ops
 
-_staging = {}     # (key, dtype) -> [pinned tensor (grow-only), event of the last copy out of it]
+_local = threading.local()   # per thread: {(key, dtype) -> [pinned tensor (grow-only), event of the
+#                              last copy out of it]} -- loader threads never share a staging buffer
 
 
 def _pinned(key, shape, dtype):
     n = int(np.prod(shape)) if len(shape) else 1
-    slot = _staging.get((key, dtype))
+    staging = _local.__dict__.setdefault('staging', {})
+    slot = staging.get((key, dtype))
     if slot is None or slot[0].numel() < n:
-        slot = _staging[(key, dtype)] = [torch.empty(max(n, 1), dtype=dtype).pin_memory(), None]
+        slot = staging[(key, dtype)] = [torch.empty(max(n, 1), dtype=dtype).pin_memory(), None]
     if slot[1] is not None:
         slot[1].synchronize()        # the previous batch's async copy has left the buffer
     return slot, slot[0][:n].view(*shape)

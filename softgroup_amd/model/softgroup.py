@@ -488,9 +488,11 @@ class SoftGroup(nn.Module):
         hi = hi * cscale[:, None]
         coords = coords * cscale[cluster_of][:, None]
         if rand_quantize:
+            # two draws from the CPU generator, like the reference (`torch.rand(3).cuda()`,
+            # softgroup.py:692-693): the same torch.manual_seed gives the same crops
             span = hi - lo
-            lo -= torch.clamp(spatial_shape - span - 0.001, min=0) * torch.rand(3, device=dev)
-            lo -= torch.clamp(spatial_shape - span + 0.001, max=0) * torch.rand(3, device=dev)
+            lo -= torch.clamp(spatial_shape - span - 0.001, min=0) * torch.rand(3).to(dev)
+            lo -= torch.clamp(spatial_shape - span + 0.001, max=0) * torch.rand(3).to(dev)
         coords -= lo[cluster_of]
         assert coords.shape.numel() == ((coords >= 0) * (coords < spatial_shape)).sum()
         vox = torch.cat([cluster_of.view(-1, 1), coords.long()], 1).contiguous()

@@ -91,8 +91,11 @@ def scene_s1(seed=0, n=20000):
     return xyz, rgb
 
 
-def scene_s2(seed=1, n=150000, room_scale=1.0):
+def scene_s2(seed=1, n=150000, room_scale=1.0, class_colour=False):
     """room shell + 12 box-shaped objects; returns xyz, rgb and a synthetic instance labelling.
+    ``class_colour``: instead of noise, points carry the colour of their semantic class
+    (2 + instance % 18; room = class 0) plus noise, so that a head fitted by
+    ``fit_point_heads`` can read the class off the backbone features.
     ``room_scale`` shrinks the room so that smaller test scenes keep the ScanNet-like surface
     density (~900 pts/m^2 at n=150k, scale 1) that makes the 4 cm neighbour graph connected."""
     rng = np.random.default_rng(seed)
@@ -110,7 +113,12 @@ def scene_s2(seed=1, n=150000, room_scale=1.0):
     xyz = np.concatenate(parts)
     xyz = (xyz + rng.normal(0, 0.003, xyz.shape)).astype(np.float32)
     rgb = rng.uniform(-1, 1, xyz.shape).astype(np.float32)
-    return xyz, rgb, np.concatenate(inst)
+    inst = np.concatenate(inst)
+    if class_colour:
+        palette = np.random.default_rng(12345).uniform(-1, 1, (20, 3))
+        cls = np.where(inst >= 0, 2 + inst % 18, 0)
+        rgb = (palette[cls] + 0.15 * rgb).astype(np.float32)
+    return xyz, rgb, inst
 
 
 def scene_g1(seed=2, blobs=40, per_blob=1000, noise=10000, sigma=0.03):
@@ -191,3 +199,135 @@ def build_model(cfg=None, seed=0, device='cuda', head_std=20.0):
             w = model.semantic_linear[-1].weight
             w.copy_(torch.randn(w.shape, generator=g) * head_std)
     return model.to(device).eval()
+
+
+def _lstsq_head(linear, a, target, ridge=1e-4):
+    """linear.weight / bias := ridge least-squares solution of [a, 1] w = target"""
+    a1 = torch.cat([a, torch.ones_like(a[:, :1])], 1).double()
+    g = a1.t() @ a1
+    g += ridge * g.diagonal().mean() * torch.eye(g.shape[0], dtype=g.dtype, device=g.device)
+    w = torch.linalg.solve(g, a1.t() @ target.double()).float()
+    linear.weight.copy_(w[:-1].t())
+    linear.bias.copy_(w[-1])
+
+
+def fit_model_to_scenes(model, batches, logit_scale=8.0):
+    """Stand-in for a trained checkpoint (none is available offline), GPU only.  Over the given
+    labelled scenes (batch dicts of ``make_batch`` / ``collate_device``):
+
+      1. every BatchNorm's running statistics := the statistics of its input (cumulative average in
+         train mode) -- as in a trained network, so the activations stay standardised and the input
+         signal survives the random backbone;
+      2. the last layers of ``semantic_linear`` / ``offset_linear`` are least-squares fitted to the
+         semantic labels (+-``logit_scale`` one-hot logits) and the offset labels;
+      3. the tiny U-Net's BatchNorms are calibrated on the resulting proposals, ``cls_linear`` is
+         fitted to the majority class of each proposal (background when < 50 % of its points carry
+         an instance label) and ``iou_score_linear`` predicts 1.
+
+    Returns dict(sem_acc=..., proposals=..., cls_acc=...)."""
+    from torch import nn
+    from . import ops as _ops
+    from .spconv import pytorch as spconv
+
+    def bns(mods):
+        return [m for mod in mods for m in mod.modules() if isinstance(m, nn.BatchNorm1d)]
+
+    def calibrate(mods, run):
+        layers = bns(mods)
+        for m in layers:
+            m.reset_running_stats()
+            m.momentum = None
+            m.train()
+        for b in batches:
+            run(b)
+        for m in layers:
+            m.momentum = 0.1
+            m.eval()
+
+    def cuda(b):
+        return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+
+    def backbone(b):
+        feats = torch.cat((b['feats'], b['coords_float']), 1) if model.with_coords else b['feats']
+        x = spconv.SparseConvTensor(_ops.voxelization(feats, b['p2v_map']), b['voxel_coords'].int(),
+                                    b['spatial_shape'], b['batch_size'])
+        return model.forward_backbone(x, b['v2p_map'])
+
+    batches = [cuda(b) for b in batches]
+    info = {}
+    with torch.no_grad():
+        model.eval()
+        point_mods = [model.input_conv, model.unet, model.output_layer]
+        calibrate(point_mods, backbone)
+        # hidden layer of the heads: calibrate its BatchNorm too, then solve the last layer
+        feats = torch.cat([backbone(b)[2] for b in batches])
+        for head in (model.semantic_linear, model.offset_linear):
+            for m in bns([head]):
+                m.reset_running_stats()
+                m.momentum = None
+                m.train()
+            head(feats)
+            for m in bns([head]):
+                m.momentum = 0.1
+                m.eval()
+        sem = torch.cat([b['semantic_labels'] for b in batches]).long()
+        ins = torch.cat([b['instance_labels'] for b in batches])
+        off = torch.cat([b['pt_offset_labels'] for b in batches]).float()
+
+        def hidden(head):
+            h = feats
+            for layer in list(head)[:-1]:
+                h = layer(h)
+            return h
+
+        valid = sem >= 0
+        n_cls = model.semantic_linear[-1].out_features
+        target = torch.full((feats.shape[0], n_cls), -logit_scale, device=feats.device)
+        target[valid, sem[valid]] = logit_scale
+        _lstsq_head(model.semantic_linear[-1], hidden(model.semantic_linear)[valid], target[valid])
+        pos = ins >= 0
+        _lstsq_head(model.offset_linear[-1], hidden(model.offset_linear)[pos], off[pos])
+        info['sem_acc'] = (model.semantic_linear(feats).argmax(1)[valid] == sem[valid]).float().mean().item()
+        model.invalidate_caches()
+        if model.semantic_only:
+            return info
+
+        # ---- refinement stage
+        pooled_all, label_all = [], []
+
+        def refine(b, collect=False):
+            s, o, f = backbone(b)
+            pidx, poff = model.forward_grouping(s, o, b['batch_idxs'], b['coords_float'])
+            if pidx.shape[0] == 0:
+                return
+            t, inp_map = model.clusters_voxelization(pidx, poff, f, b['coords_float'],
+                                                     **model.instance_voxel_cfg)
+            y = model.tiny_unet_outputlayer(model.tiny_unet(t))
+            if collect:
+                pooled_all.append(model.global_pool(y))
+                # majority class of each proposal
+                prop, pt = pidx[:, 0].long(), pidx[:, 1].long()
+                cls = torch.where(b['instance_labels'][pt] >= 0,
+                                  b['semantic_labels'][pt] - (model.semantic_classes - model.instance_classes),
+                                  torch.full_like(prop, model.instance_classes))
+                votes = torch.zeros((poff.numel() - 1, model.instance_classes + 1), device=prop.device)
+                votes.index_put_((prop, cls.clamp(min=0)), torch.ones_like(prop, dtype=votes.dtype),
+                                 accumulate=True)
+                label_all.append(votes.argmax(1))
+
+        calibrate([model.tiny_unet, model.tiny_unet_outputlayer], refine)
+        model.invalidate_caches()
+        for b in batches:
+            refine(b, collect=True)
+        info['proposals'] = int(sum(p.shape[0] for p in pooled_all))
+        if pooled_all:
+            pooled, labels = torch.cat(pooled_all), torch.cat(label_all)
+            target = torch.full((pooled.shape[0], model.instance_classes + 1), -logit_scale / 2,
+                                device=pooled.device)
+            target[torch.arange(pooled.shape[0]), labels] = logit_scale / 2
+            _lstsq_head(model.cls_linear, pooled, target, ridge=1e-3)
+            info['cls_acc'] = (model.cls_linear(pooled).argmax(1) == labels).float().mean().item()
+        model.iou_score_linear.weight.zero_()
+        model.iou_score_linear.bias.fill_(1.0)
+        model.invalidate_caches()
+    return info

@@ -1,0 +1,124 @@
+"""Generates golden vectors of the REFERENCE'S OWN ``forward_train`` (authoring container only:
+needs /root/reference).
+
+The reference's ``SoftGroup`` class (softgroup/model/softgroup.py, imported from where it lies) is
+built from the ``model:`` section of its own YAML, loaded with our seeded synthetic weights, put in
+training mode by its own ``train()`` override (:98-104: frozen modules keep BatchNorm in eval, the
+rest uses batch statistics) and ``model(batch, return_loss=True)`` (:113-155 ``forward_train``,
+:157-175 ``point_wise_loss``, :177-262 ``instance_loss``, :264-298 ``parse_losses``) is executed AS
+WRITTEN -- on the CPU, over the C-oracle-backed stand-ins of oracle/facade.py for spconv and
+softgroup.ops.  ``torch.manual_seed(SEED)`` right before the call fixes the two ``torch.rand(3)``
+draws of ``clusters_voxelization(rand_quantize=True)`` (:690-694; CPU generator in the reference,
+hence also in softgroup_amd).
+
+Ground truth of a case: the instances are the model's own eval-mode proposals (first the grouping
+runs through the oracle restatement, then every proposal becomes a GT instance of class
+``id % instance_classes``), so that every loss term is live -- positives, negatives, mask labels,
+IoU regression.  The GT arrays are stored next to the losses; tests only read the file.
+
+Output (committed): tests/golden/ref_train_<case>.npz -- GT arrays + every entry of ``log_vars``.
+tests/test_train_gpu.py::test_forward_train_losses_match_reference compares softgroup_amd's
+``forward_train`` on the GPU with it (<= 1e-4 relative per term, counts exact).
+
+Usage:  python tests/golden/make_ref_train.py
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_ref_forward as G  # noqa: E402
+from oracle import facade  # noqa: E402
+from oracle.model import OracleSoftGroup  # noqa: E402
+from softgroup_amd import synthetic  # noqa: E402
+
+SEED = 1234
+
+# case -> forward case (scene + yaml) and overrides of the model section
+CASES = {
+    'scannet_frozen': dict(forward='scannet'),                         # fine-tune stage: frozen backbone
+    'scannet_full': dict(forward='scannet', fixed_modules=[]),         # every BatchNorm on batch statistics
+    'stpls3d_pp': dict(forward='stpls3d_pp'),                          # semantic_weight, match_low_quality,
+    #                                                                    octree + pyramid grouping in training
+}
+
+
+def case_cfg(case):
+    configs = json.load(open(os.path.join(HERE, 'ref_configs.json')))
+    c = CASES[case]
+    cfg = copy.deepcopy(configs[G.CASES[c['forward']]['yaml']])
+    if 'fixed_modules' in c:
+        cfg['fixed_modules'] = c['fixed_modules']
+    return cfg
+
+
+def gt_from_proposals(pidx, n, n_inst_cls, sem_shift, xyz):
+    """every proposal becomes a GT instance (a point listed by several proposals goes to the last)"""
+    inst = np.full(n, -100, np.int64)
+    inst[pidx[:, 1]] = pidx[:, 0]
+    ids = np.unique(inst[inst >= 0])
+    remap = np.full(int(ids.max()) + 1, -100, np.int64)
+    remap[ids] = np.arange(len(ids))
+    inst = np.where(inst >= 0, remap[np.clip(inst, 0, None)], inst)
+    cls = np.arange(len(ids)) % n_inst_cls
+    sem = np.where(inst >= 0, sem_shift + cls[np.clip(inst, 0, None)], 0).astype(np.int64)
+    pointnum = np.bincount(inst[inst >= 0], minlength=len(ids)).astype(np.int32)
+    off = np.zeros((n, 3), np.float32)
+    for i in range(len(ids)):
+        m = inst == i
+        off[m] = xyz[m].mean(0) - xyz[m]
+    return dict(instance_labels=inst, semantic_labels=sem, instance_pointnum=pointnum,
+                instance_cls=cls.astype(np.int64), pt_offset_labels=off)
+
+
+def apply_gt(batch, gt):
+    for k, v in gt.items():
+        batch[k] = torch.from_numpy(np.asarray(v))
+    return batch
+
+
+def main():
+    for case, c in CASES.items():
+        fc = G.CASES[c['forward']]
+        cfg = case_cfg(case)
+        batch, xyz = G.make_case_batch(c['forward'])
+        sd = synthetic.build_model(cfg, seed=0, device='cpu').state_dict()
+        ora = OracleSoftGroup(sd, cfg)
+        if fc.get('force_lvl2'):
+            ora.get_level = G.lvl2
+        sem, off, _ = ora.point_wise(batch)
+        pidx, poff = ora.grouping(sem, off, batch['batch_idxs'], batch['coords_float'])
+        assert len(poff) - 1 > 3, 'too few proposals for a meaningful GT'
+        gt = gt_from_proposals(pidx, xyz.shape[0], cfg['instance_classes'],
+                               cfg['semantic_classes'] - cfg['instance_classes'], xyz)
+        apply_gt(batch, gt)
+
+        ref, mod = facade.reference_model(cfg, sd)
+        if fc.get('force_lvl2'):
+            ref.get_level = G.lvl2
+        ref.train()                                    # the reference's override (softgroup.py:98-104)
+        torch.manual_seed(SEED)
+        with facade.cpu_only(mod), torch.no_grad():    # loss VALUES only: the stand-in convs have no autograd
+            loss, log_vars = ref(batch, return_loss=True)
+        rec = dict(gt, yaml=np.array(fc['yaml']), seed=np.int64(SEED), n_points=np.int64(xyz.shape[0]),
+                   xyz_checksum=np.float64(np.abs(xyz.astype(np.float64)).sum()),
+                   fixed_modules=np.array(json.dumps(cfg['fixed_modules'])),
+                   n_proposals_eval=np.int64(len(poff) - 1),
+                   log_keys=np.array(list(log_vars.keys())),
+                   log_vals=np.array([float(v) for v in log_vars.values()], np.float64))
+        path = os.path.join(HERE, f'ref_train_{case}.npz')
+        np.savez_compressed(path, **rec)
+        print(case, 'points', xyz.shape[0], 'GT instances', len(gt['instance_pointnum']),
+              {k: round(float(v), 6) for k, v in log_vars.items()}, os.path.getsize(path) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()

@@ -219,6 +219,16 @@ def test_bfs_cluster_bigger_than_the_lds_claim_array():
     rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 50.0, 0)
     assert np.diff(rco).max() == 22500 and len(rco) - 1 == 5
     assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
+    # the multi-workgroup replay's grid barrier is bounded; if it ever gives up (workgroups not
+    # co-resident) the giant clusters are replayed by the per-cluster kernel, gated on the device.
+    # SG_BFS_FORCE_FALLBACK sets the failure word up front: the result must be the same.
+    import os
+    os.environ['SG_BFS_FORCE_FALLBACK'] = '1'
+    try:
+        ci2, co2 = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
+    finally:
+        del os.environ['SG_BFS_FORCE_FALLBACK']
+    assert np.array_equal(co2.cpu().numpy(), rco) and np.array_equal(ci2.cpu().numpy(), rci)
 
 
 def test_bfs_cluster_empty_and_all_dropped():

@@ -318,6 +318,31 @@ def test_large_scene_linearity_and_determinism():
     np.testing.assert_allclose(cxy.cpu().numpy(), (2 * cx - 3 * cy).cpu().numpy(), atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('cin,cout', [(48, 48), (16, 112), (64, 96)])
+def test_large_layer_with_a_partial_last_column_block(cin, cout):
+    """>= 70 k output rows with Cout % 64 != 0 (the STPLS3D channels = 16 pyramid has 48 and 112):
+    sizes where the persistent kernel's 64-column units are eligible by launch count.  They may
+    only be used when every column block of a unit is whole; otherwise lanes of the second block
+    past Cout would write into the next row.  Checked against plain torch on the gather table."""
+    rng = np.random.default_rng(cin + cout)
+    shape = [320, 270, 150]
+    idx = _scene(rng, 200000, shape)
+    M = len(idx)
+    assert M >= 70000
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key='k').to(DEV)
+    x = torch.randn(M, cin, device=DEV)
+    with torch.no_grad():
+        st = spconv.SparseConvTensor(x, t(idx), shape, 1)
+        got = conv(st).features
+        nbr = core.SubMRule(t(idx), shape).plan.nbr.long()                  # [M, 27]
+        w = conv.weight.detach().reshape(cout, 27, cin)
+        xp = torch.cat([x, x.new_zeros(1, cin)])                           # row M = absent neighbour
+        ref = torch.zeros(M, cout, device=DEV, dtype=torch.float64)
+        for k in range(27):
+            ref += xp[torch.where(nbr[:, k] >= 0, nbr[:, k], M)].double() @ w[:, k].t().double()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize('cin,cout,n,kernel', [
     (64, 64, 9000, 'persistent'),      # several rounds of units
     (128, 96, 300, 'persistent+split'),  # tiny layer: offsets split over units, reduce kernel
