@@ -290,6 +290,26 @@ class Munch(dict):
         return d
 
 
+def torch2_compat(ref_module):
+    """The reference was written for torch 1.11 (docs/installation.md:14-19).  One construct of its
+    `get_instances` no longer runs on torch >= 2: `proposals_idx[mask_inds]` indexes the CPU tensor
+    that `bfs_cluster` returns with a CUDA boolean mask (softgroup.py:568-569); torch 2 raises
+    "indices should be either on cpu or on the same device as the indexed tensor".  This moves that
+    one argument to the scores' device before the reference's own method body runs -- no logic of
+    the reference is replaced.  (INTEGRATION.md section 3 lists it as the one-line change a
+    maintainer on torch 2 needs regardless of the operator library underneath.)"""
+    cls = ref_module.SoftGroup
+    if getattr(cls, '_sg_torch2_compat', False):
+        return
+    orig = cls.get_instances
+
+    def get_instances(self, scan_id, proposals_idx, semantic_scores, *a, **k):
+        return orig(self, scan_id, proposals_idx.to(semantic_scores.device), semantic_scores, *a, **k)
+
+    cls.get_instances = get_instances
+    cls._sg_torch2_compat = True
+
+
 def import_reference_tool(name):
     """the reference's tools/<name>.py as a module (call after import_reference, which installs the
     `softgroup` package the tool imports)"""

@@ -131,6 +131,53 @@ def scene_g1(seed=2, blobs=40, per_blob=1000, noise=10000, sigma=0.03):
     return xyz[rng.permutation(len(xyz))]
 
 
+def scene_lidar(seed=3, n=120000, beams=64, n_boxes=24):
+    """BASELINE config 5 proxy: one LiDAR-like sweep -- `beams` rings (elevation -24.8
+    .. +2 degrees, HDL-64 like) x n/beams azimuth steps, rays cast against a ground plane 1.73 m
+    below the sensor and `n_boxes` car-sized boxes 4-18 m away; range noise 1 cm.  Returns xyz
+    (sensor frame), a 1-channel intensity feature and instance labels (box id, -100 = ground)."""
+    if n > 0:        # rays that hit nothing are dropped: cast n / hit-rate rays (hit rate of a first pass)
+        got = scene_lidar(seed, -n, beams, n_boxes)[0].shape[0]
+        n = -int(n * n / got)
+    rng = np.random.default_rng(seed)
+    per = -n // beams
+    el = np.deg2rad(np.linspace(-24.8, 2.0, beams))[:, None]
+    az = (np.arange(per) / per * 2 * np.pi)[None, :] + rng.uniform(0, 2 * np.pi / per, (beams, 1))
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.broadcast_to(np.sin(el), az.shape)], -1)
+    d = d.reshape(-1, 3)
+    n = len(d)
+    t_hit = np.full(n, 60.0)
+    inst = np.full(n, -100, np.int64)
+    down = d[:, 2] < -1e-3
+    t_ground = np.where(down, -1.73 / np.where(down, d[:, 2], -1.0), np.inf)
+    t_hit = np.minimum(t_hit, t_ground)
+    ang = rng.uniform(0, 2 * np.pi, n_boxes)
+    rad = rng.uniform(4.0, 18.0, n_boxes)
+    for b in range(n_boxes):
+        size = np.array([rng.uniform(3.5, 4.8), rng.uniform(1.6, 2.0), rng.uniform(1.4, 1.9)])
+        if rng.random() < 0.5:
+            size[[0, 1]] = size[[1, 0]]
+        lo = np.array([rad[b] * np.cos(ang[b]), rad[b] * np.sin(ang[b]), -1.73]) - size * [0.5, 0.5, 0]
+        hi = lo + size
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t1, t2 = (lo - 0.0) / d, (hi - 0.0) / d
+        tn = np.nanmax(np.minimum(t1, t2), 1)
+        tf = np.nanmin(np.maximum(t1, t2), 1)
+        hit = (tn <= tf) & (tn > 0.5) & (tn < t_hit)
+        t_hit = np.where(hit, tn, t_hit)
+        inst = np.where(hit, b, inst)
+    keep = t_hit < 59.0
+    r = t_hit[keep] + rng.normal(0, 0.01, int(keep.sum()))
+    xyz = (d[keep] * r[:, None]).astype(np.float32)
+    inst = inst[keep]
+    ids = np.unique(inst[inst >= 0])                 # dense ids (a box may be fully occluded)
+    remap = np.full(n_boxes, -100, np.int64)
+    remap[ids] = np.arange(len(ids))
+    inst = np.where(inst >= 0, remap[np.clip(inst, 0, None)], -100)
+    intensity = rng.uniform(0, 1, (len(xyz), 1)).astype(np.float32)
+    return xyz, intensity, inst
+
+
 def make_batch(xyz, rgb, scale=50, min_spatial=128, instance_labels=None, semantic_labels=None,
                scan_id='synthetic_0000', x4_split=False):
     """One-scene batch dict with the keys/dtypes of collate_fn (data/custom.py:240-256).

@@ -51,3 +51,53 @@ def test_g1_grouping_input_bit_exact():
     rci, rco = oracle.bfs_cluster(mean.numpy(), ridx, rsl, 100.0, 0)
     assert len(rco) - 1 >= 38                          # 40 components >= 100 pts
     assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(ci.cpu().numpy(), rci)
+
+
+def _assert_report(rep, min_props):
+    print(rep)
+    assert rep['proposals'] >= min_props and rep['instances'] > 0
+    assert rep['float_stages_within_tol'], rep
+    assert rep['proposals_equal'] and rep['proposal_voxel_index_equal'] and rep['instances_equal'], rep
+    assert rep['e2e_instances_oracle'] > 0
+    assert abs(rep['e2e_instances_gpu'] - rep['e2e_instances_oracle']) <= max(2, rep['e2e_instances_oracle'] // 50), rep
+    assert rep['e2e_mean_best_mask_iou'] >= 0.98, rep
+
+
+def test_config4_stpls3d_pp_at_size():
+    """BASELINE config 4 at SURVEY 8(d)'s size: softgroup++_stpls3d.yaml (channels 16, 0.33 m voxels,
+    octree ball query, pyramid levels with the model's own get_level -- the 149 k-point class takes
+    level 2 naturally) on the S2 coordinates x 40 (a ~240 m tile, 150 000 points).  Same stage-wise
+    bar as the S2 test: floats <= 1e-4, proposals / proposal voxel index / instances + RLE
+    identical."""
+    import copy
+    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=150000)
+    xyz = (xyz * np.float32(40)).astype(np.float32)
+    batch = synthetic.make_batch(xyz, rgb, scale=3, instance_labels=inst)
+    cfg = copy.deepcopy(synthetic.STPLS3D_PP_MODEL_CFG)
+    model = synthetic.build_model(cfg, seed=0)
+    rep = parity.parity_report(model, batch, cfg)
+    assert rep['points'] == 150000
+    _assert_report(rep, min_props=1000)
+
+
+def test_config5_kitti_sweep_at_size():
+    """BASELINE config 5 at SURVEY 8(d)'s size: softgroup_kitti.yaml (1 input channel, no coords,
+    5 cm voxels, radius 0.1, npoint_thr 5 absolute, panoptic) on one ~120 k-point LiDAR-like sweep
+    (64 rings against a ground plane and car-sized boxes).  Stage-wise bar as above, plus the
+    panoptic fusion of the GPU's instances == the oracle's fusion of the same instances."""
+    import copy
+    from oracle.model import OracleSoftGroup
+    xyz, intensity, inst = synthetic.scene_lidar(seed=3, n=120000)
+    assert 119000 <= xyz.shape[0] <= 121000
+    batch = synthetic.make_batch(xyz, intensity, scale=20, instance_labels=inst)
+    cfg = copy.deepcopy(synthetic.KITTI_MODEL_CFG)
+    model = synthetic.build_model(cfg, seed=0)
+    rep = parity.parity_report(model, batch, cfg)
+    _assert_report(rep, min_props=100)
+    with torch.no_grad():
+        full = model(batch)
+    assert full['panoptic_preds'].dtype == np.uint32 and full['panoptic_preds'].shape[0] == xyz.shape[0]
+    g = parity.gpu_stages(model, batch)
+    sem_pred = g['sem'].argmax(1).cpu().numpy()
+    ora = OracleSoftGroup(model.state_dict(), cfg)
+    assert np.array_equal(model.panoptic_fusion(sem_pred, g['preds']), ora.panoptic_fusion(sem_pred, g['preds']))
