@@ -21,7 +21,8 @@ SOURCES = [
     ('octree.hip', ['-ffp-contract=off']),
     ('bfs.hip', ['-ffp-contract=off']),
     ('spconv_rulebook.hip', ['-ffp-contract=off']),
-    ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
+    # (atomic optimizer off: it would wait for the unit-ticket atomic right where it is issued)
+    ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None']),
     ('spconv_train.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),

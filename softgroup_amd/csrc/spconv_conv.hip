@@ -31,6 +31,9 @@
 #include <stdlib.h>
 
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -45,6 +48,26 @@ constexpr int kWavesPerWg = 4;
 constexpr int kCk = 16;        // channels per pipeline slice (8 per half-wave)
 constexpr int kMaxK = 27;
 constexpr unsigned kOob = 0x80000000u;   // byte offset past every (< 2 GB) buffer: loads return 0
+
+// LDS-DMA piece: every active lane moves `16` / `4` bytes from its own global address to
+// LDS[lds_dst + lane * size].  Written as asm on purpose: while a compiler-visible global_load_lds
+// is (possibly) in flight hipcc turns every partial s_waitcnt vmcnt(N) of ordinary loads into
+// vmcnt(0), which would serialise the operand ring of the matrix loop; an asm statement is outside
+// its bookkeeping, and an untracked OLDER operation only ever makes a counted wait longer, never
+// wrong.  The issuing wave waits for the data itself (s_waitcnt vmcnt(0), then the barrier).
+// M0 = LDS base of the transfer; saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma_b128(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma_b32(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 struct ConvArgs {
   const float *in;
@@ -67,6 +90,7 @@ struct ConvArgs {
   int k_per_split;
   int num_units;
   unsigned magic_upt, magic_cu, magic_nsl;   // reciprocals of units_per_tile, col_units, n_slices
+  unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per XCD)
   unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
 };
 
@@ -244,7 +268,10 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 //   * units whose column blocks share a tile run on the same XCD (unit u -> XCD u % 8), so the
 //     second column block finds the gathered rows in that XCD's L2.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMetaInts = kTileRows * kMaxK + kTileRows + 4;   // gather block, rows, mask
+// LDS block of a unit, filled by LDS-DMA (lane-linear images): the tile's gather block as it lies
+// in memory (row-major, stride K), the 32 row ids, the tile mask
+constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
+constexpr int kMetaInts = kMaskAt + 4;
 
 template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1>
 __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
@@ -283,8 +310,6 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       p.out, 0, out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
       act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_nbr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int32_t *>(p.nbr_tiles), 0, static_cast<unsigned>(num_tiles) * tileK * 4u, 0x00020000);
 
   // x / d for the few small wave-uniform divisors of the unit arithmetic: one s_mul_hi with a
   // host-made reciprocal (exact for x * d < 2^32; magic 0 means d == 1)
@@ -312,34 +337,24 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     return d;
   };
 
-  // ---- metadata of a unit: 4 gather-table words per thread, one row id, the tile mask.
-  //      Branch-free (out-of-range lanes read past the buffer) so that the loads stay in flight
-  //      across the matrix loop.
-  struct Meta { int nbr[4]; int row; int mask; };
-  auto fetch = [&](const Unit &d, Meta &m) {
+  // ---- metadata of a unit goes from memory straight into LDS (global_load_lds: no registers, no
+  //      publish pass), issued by wave 0 alone; lanes past the tile's block sit the DMA out (the
+  //      destination of a lane is base + lane * size, so the image stays dense).
+  int32_t *ctl = meta_lds + 2 * kMetaInts;           // [2] unit id held by each metadata buffer
+  const unsigned meta_lds_addr = __builtin_amdgcn_readfirstlane(
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>(meta_lds)));       // LDS byte offset
+  auto dma_meta = [&](int tile, int buf) {
+    const unsigned dst = meta_lds_addr + static_cast<unsigned>(buf * kMetaInts) * 4u;
+    const int32_t *blk = p.nbr_tiles + static_cast<long long>(tile) * tileK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int e = threadIdx.x + q * 256;
-      const unsigned off = e < tileK ? static_cast<unsigned>(d.tile * tileK + e) * 4u : kOob;
-      m.nbr[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_nbr, off, 0, 0);
+      const int e = q * 256 + lane * 4;
+      if (e < tileK) lds_dma_b128(blk + e, dst + q * 1024);
     }
-    // row ids and the mask through plain loads: epilogue-only / per-unit data does not need buffer
-    // descriptors (every descriptor is 4 SGPRs of a kernel that was spilling SGPRs)
-    m.row = threadIdx.x < kTileRows ? p.order[d.tile * kTileRows + threadIdx.x] : 0;
-    m.mask = static_cast<int>(p.tile_mask[d.tile]);
+    if (lane < kTileRows) lds_dma_b32(p.order + tile * kTileRows + lane, dst + kRowsAt * 4);
+    if (lane == 0) lds_dma_b32(p.tile_mask + tile, dst + kMaskAt * 4);
   };
-  // LDS block of a unit: [0, 32*K) gather block as fetched (stride K), then 32 rows, then the mask
-  constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
-  auto publish = [&](const Meta &m, int buf) {
-    int32_t *dst = meta_lds + buf * kMetaInts;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = threadIdx.x + q * 256;
-      if (q < 3 || e < kRowsAt) dst[e] = m.nbr[q];     // words past 32*K are zeros nobody reads
-    }
-    if (threadIdx.x < kTileRows) dst[kRowsAt + threadIdx.x] = m.row;
-    if (threadIdx.x == 0) dst[kMaskAt] = m.mask;
-  };
+  (void)num_tiles;
 
   struct Slice { f4 a[NQ]; f4 b[NBW][NQ]; };
   // per-unit context (wave-uniform scalars + the lane's column)
@@ -349,6 +364,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
     int v_w;
     float ps[NBW], pb[NBW], as[NBW], ab[NBW];
+    unsigned o_off[4];     // byte offsets of the 4 output rows this lane stores (kOob: padding row)
     bool col_ok;
   };
 
@@ -423,6 +439,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     for (int rr = 0; rr < 4; ++rr) {
       const unsigned off = (row4[rr] >= 0 && c.col_ok)
                                ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
+      c.o_off[rr] = off;   // kept for the epilogue: the unit's LDS block is not read after its loop
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
         resv[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, n * 128, 0));
@@ -466,32 +483,57 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter();
   };
 
-  // ---- work distribution: static snake over the descending unit list.  (A dynamic tail fed by
-  //      per-XCD atomic counters was measured slower: a returning atomic sits in the same in-order
-  //      return queue as the wave's operand loads and stalls its matrix loop for microseconds.)
-  // round r runs forward or reversed after the Thue-Morse word (F R R F R F F R ...): for a convex
-  // descending weight list that evens the per-workgroup totals better than plain alternation
-  auto static_unit = [&](int r) {
-    return r * G + ((__builtin_popcount(r) & 1) ? G - 1 - static_cast<int>(blockIdx.x)
-                                                : static_cast<int>(blockIdx.x));
+  // ---- work distribution.  The unit list is heaviest-first.  Rounds 0 and 1 are static (round 0
+  //      forward, round 1 reversed: one heavy + one light unit each); from round 2 on the units are
+  //      HANDED OUT: one ticket counter per XCD (unit u always runs on XCD u % 8, so the column
+  //      blocks of a tile share that XCD's L2), drawn by lane 0 of wave 0 right after its matrix
+  //      loop -- two units ahead, so the ticket's round trip (and the LDS-DMA of the next unit's
+  //      metadata, which needs the ticket) hides behind a whole unit; nothing ever waits for it.
+  //      (An earlier attempt drew tickets inside the matrix loop: the returning atomic sat in the
+  //      same in-order return queue as the operand loads and stalled them for microseconds.)
+  //      With ~3 units per workgroup the late finishers used to define the kernel's span (workgroup
+  //      end times spread 109-146 k ticks on the 64->64 x 77 k-row layer); now whoever is ahead
+  //      takes the remaining (lightest) units.  Results do not depend on who computes a unit.
+  const int xcd = blockIdx.x & 7;
+  const int dyn0 = 2 * G;                      // first handed-out unit (G is a multiple of 8 when > 8)
+  auto barrier = [] {                          // LDS-only rendezvous: must not drain the ticket atomic
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
   // ---- prologue of the workgroup: metadata of its first unit
   int round = 0, u = blockIdx.x, buf = 0;
   Unit du = decode(u);
-  Meta m;
-  fetch(du, m);
-  publish(m, 0);
-  __syncthreads();
+  unsigned ticket = 0;                         // wave 0, lane 0: the last ticket drawn
+  bool drawing = true;                         // wave 0: no out-of-range ticket seen yet
+  if (wave == 0) {
+    dma_meta(du.tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  barrier();
   Ctx c;
   setup(du, 0, c);
 
   while (true) {
     mark(0);
-    const int un = static_unit(round + 1);
-    const bool has_next = un < num_units;
-    const Unit dn = decode(has_next ? un : u);
-    fetch(dn, m);                       // lands during the matrix loop
+    // wave 0: which unit comes after this one, and its metadata on the way into the other buffer
+    int un_w0 = -1;
+    if (wave == 0) {
+      if (round == 0 || p.queue == nullptr) {      // (no queue: the static snake all the way, A/B knob)
+        const int r = round + 1;
+        un_w0 = r * G + ((__builtin_popcount(r) & 1) ? G - 1 - static_cast<int>(blockIdx.x)
+                                                     : static_cast<int>(blockIdx.x));
+      } else if (drawing) {
+        const unsigned t = __builtin_amdgcn_readfirstlane(ticket);     // drawn one unit ago
+        un_w0 = dyn0 + static_cast<int>(t) * 8 + xcd;
+      }
+      if (un_w0 >= num_units || un_w0 < 0) {
+        un_w0 = -1;
+        drawing = false;
+      }
+      if (un_w0 >= 0) dma_meta(decode(un_w0).tile, buf ^ 1);
+      // (this slot and that buffer were last read two barriers ago; next read: after barrier B)
+      if (lane == 0) ctl[buf ^ 1] = un_w0;
+    }
 #pragma unroll
     for (int n = 0; n < NBW; ++n)
 #pragma unroll
@@ -527,16 +569,28 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     if constexpr (TRACE) { asm volatile("" : "+v"(acc[0][0])); }
     mark(1);
 
-    // ---- partial sums + residual rows + next unit's metadata meet in LDS
-    __syncthreads();                     // the previous unit's epilogue has read `red`
+    // wave 0: the metadata DMA (issued a whole matrix loop ago) has landed; draw the ticket for
+    // the unit after next.  Its answer is first looked at one unit from now.
+    if (wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (drawn every unit, also after the queue has run dry: a draw nobody looks at is cheaper
+      // than a data-dependent branch around it; the counters are this launch's own)
+      if (lane == 0 && p.queue != nullptr)
+        ticket = __hip_atomic_fetch_add(p.queue + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- partial sums meet in LDS (the next unit's identity and metadata are there already)
+    barrier();                           // the previous unit's epilogue has read `red`
     mark(2);
 #pragma unroll
     for (int n = 0; n < NBW; ++n)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) red[((wave * NBW + n) * 16 + reg) * 64 + lane] = acc[n][reg];
-    publish(m, buf ^ 1);
-    __syncthreads();
+    barrier();
     mark(3);
+    const int un = __builtin_amdgcn_readfirstlane(ctl[buf ^ 1]);
+    const bool has_next = un >= 0;
+    const Unit dn = decode(has_next ? un : u);
 
     // ---- epilogue operands first (all LDS reads in flight together), then the next unit's first
     //      operand loads, then the stores: fixed-order sum w0+w1+w2+w3 (+ residual, post); each
@@ -544,8 +598,6 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     float v[NBW][4], va[NBW][4];
     unsigned o_off[4];
     {
-      const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
-      const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
       float part[NBW][4][4];
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
@@ -565,8 +617,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
           v[n][rr] = t;
           va[n][rr] = fmaxf(fmaf(t, c.as[n], c.ab[n]), 0.f);
         }
-        o_off[rr] = (row4[rr] >= 0 && c.col_ok)
-                        ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
+        o_off[rr] = c.o_off[rr];
       }
     }
     const unsigned o_base = final_out ? 0u : static_cast<unsigned>(c.ks) * out_bytes;
@@ -719,6 +770,34 @@ struct ConvProf {
 };
 static ConvProf g_conv_prof;
 
+// Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
+// of 8 counters (one per XCD) out of a per-(device, stream) pool; the pool is cleared again, in
+// stream order, when it has been used up.  Launches on one stream run in order, so a block is
+// never shared by two kernels.
+struct TicketPool {
+  unsigned *dev = nullptr;
+  size_t next = 0;
+};
+constexpr size_t kTicketBlocks = 1 << 15;     // x 32 B = 1 MB per stream
+static std::mutex g_ticket_mu;
+static std::map<std::pair<int, hipStream_t>, TicketPool> g_ticket_pools;
+
+static unsigned *take_tickets(hipStream_t stream) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_ticket_mu);
+  TicketPool &tp = g_ticket_pools[{dev, stream}];
+  if (tp.dev == nullptr) {
+    if (hipMalloc(&tp.dev, kTicketBlocks * 32) != hipSuccess) return nullptr;
+    tp.next = kTicketBlocks;
+  }
+  if (tp.next == kTicketBlocks) {
+    hipMemsetAsync(tp.dev, 0, kTicketBlocks * 32, stream);
+    tp.next = 0;
+  }
+  return tp.dev + 8 * tp.next++;
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -805,7 +884,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   const bool persistent = Cin % 16 == 0 && in_bytes_ll < (1LL << 31) && num_in_rows > 0 &&
                           static_cast<long long>(M_out) * Cout * 4 * kMaxK < (1LL << 32) &&
                           static_cast<long long>(num_tiles) * kTileRows * K * 4 < (1LL << 31) &&
-                          order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr;
+                          order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr &&
+                          reinterpret_cast<uintptr_t>(nbr_tiles) % 16 == 0;      // 16-byte LDS-DMA pieces
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
   static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 2048;   // developer knob
@@ -843,6 +923,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.M_out = M_out; a.K = K; a.Cin = Cin; a.Cout = Cout;
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
   a.trace = nullptr;
+  a.queue = nullptr;
   const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
   a.num_units = static_cast<int>(units);
   auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
@@ -854,7 +935,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
     // XCD u % 8)
     const size_t lds = static_cast<size_t>(kWavesPerWg) * (wide ? 2 : 1) * 16 * 64 * sizeof(float) +
-                       2 * kMetaInts * sizeof(int32_t);
+                       2 * kMetaInts * sizeof(int32_t) + 16;
     static int num_cu = 0;
     if (num_cu == 0) {
       int dev = 0;
@@ -900,6 +981,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
       else gather_conv_persistent_kernel<kSliceCh, 2, 0, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
     };
     a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
+    static const bool static_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC"));   // developer knob
+    a.queue = static_env ? nullptr : take_tickets(stream);       // (null: static hand-out)
     long long g = static_cast<long long>(num_cu) * occ;
     if (g > units) g = units;
     if (g >= 8) g -= g % 8;
