@@ -16,7 +16,10 @@ Besides the headline line the JSON carries
                 host cores of the same box on one scan of the same scene (rank 0, N=1 only)
   stages        per-stage milliseconds of the GPU path (HIP events), for orientation
   parity_at_bench  the oracle's outputs on this very scene compared with the GPU's (not discarded)
-  legs          SURVEY 8(d)'s other measurement legs (rank 0, N=1): G1 grouping-head input with
+  legs          (config_legs) BASELINE configs 3 / 4 / 5 at their own sizes: S3DIS-shaped training
+                step (batch 4, frozen backbone, fp32 and bf16 autocast), SoftGroup++/STPLS3D and
+                SemanticKITTI inference ms/scan with stage split; and
+                SURVEY 8(d)'s other measurement legs (rank 0, N=1): G1 grouping-head input with
                 roofline entries for the ball query and the BFS clustering, a 2x denser 300k-point
                 scene, the S1 config-1 backbone on the CPU (all cores and OMP_NUM_THREADS=1), and
                 the host-to-device inclusive rate of the S2 scan (device-side collate)
@@ -102,9 +105,9 @@ def stage_times(model, batch, reps=5):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         with torch.no_grad():
             ev[0].record()
-            feats = torch.cat((b['feats'], b['coords_float']), 1)
+            feats = torch.cat((b['feats'], b['coords_float']), 1) if model.with_coords else b['feats']
             vf = ops.voxelization(feats, b['p2v_map'])
-            x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], 1)
+            x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], b['batch_size'])
             sem, off, out_feats = model.forward_backbone(x, b['v2p_map'])
             ev[1].record()
             pidx, poff = model.forward_grouping(sem, off, b['batch_idxs'], b['coords_float'])
@@ -138,6 +141,93 @@ def _events_ms(fn, reps=5, warm=2):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+def config_legs(args):
+    """BASELINE configs 3 / 4 / 5 at SURVEY 8(d)'s sizes (they are parity cases in tests/, here their
+    measured cost; bounded to a few seconds each):
+      train_step_s3dis  softgroup_s3dis_fold5.yaml shapes: batch 4 scenes x 150 k points per rank,
+                        frozen backbone, forward_train + backward + Adam, fp32 and bf16 autocast;
+                        gradient bytes = what DDP all-reduces per step
+      stpls3d_pp        softgroup++_stpls3d.yaml inference on the S2 coordinates x 40 tile
+                        (octree ball query, pyramid level 2 on the 149 k-point class)
+      kitti             softgroup_kitti.yaml panoptic inference on one ~120 k-point LiDAR-like sweep
+    """
+    import copy
+    import numpy as np
+    from softgroup_amd import synthetic
+    from softgroup_amd.data import collate_device, make_item
+    from softgroup_amd.model import SoftGroup
+    legs = {}
+
+    def cuda(b):
+        return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+
+    def infer_leg(cfg, batch):
+        model = synthetic.build_model(cfg, seed=0)
+        model.async_results = False
+        with torch.no_grad():
+            for _ in range(2):
+                model(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                model(batch)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            stages, info = stage_times(model, batch, reps=2)
+        return {'ms_per_scan_unpipelined': round(ms, 3), 'stages_ms': stages, 'scene': info}
+
+    # ---- config 4
+    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=args.points)
+    xyz = (xyz * np.float32(40)).astype(np.float32)
+    legs['stpls3d_pp'] = infer_leg(copy.deepcopy(synthetic.STPLS3D_PP_MODEL_CFG),
+                                   cuda(synthetic.make_batch(xyz, rgb, scale=3, instance_labels=inst)))
+    # ---- config 5
+    xyz, intensity, inst = synthetic.scene_lidar(seed=3, n=120000)
+    legs['kitti'] = infer_leg(copy.deepcopy(synthetic.KITTI_MODEL_CFG),
+                              cuda(synthetic.make_batch(xyz, intensity, scale=20, instance_labels=inst)))
+    # ---- config 3
+    cfg = copy.deepcopy(synthetic.S3DIS_MODEL_CFG)
+    torch.manual_seed(0)
+    model = SoftGroup(**cfg).cuda()
+    with torch.no_grad():
+        model.semantic_linear[-1].weight.normal_(0, 20.0)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    items = []
+    for i in range(4):
+        x, c, ins = synthetic.scene_s2(seed=31 + i, n=args.points)
+        sem = np.where(ins >= 0, 2 + ins % 11, 0).astype(np.int64)          # 13 S3DIS classes
+        items.append(make_item(x, c, 50, sem, ins, f'crop_{i}'))
+    batch = collate_device(items)
+    batch['instance_cls'] = batch['instance_cls'].clamp(min=0)
+    rec = {'scenes_per_step': 4, 'points_per_step': int(batch['coords_float'].shape[0]),
+           'voxels_per_step': int(batch['voxel_coords'].shape[0]),
+           'trainable_params': int(sum(p.numel() for p in params)),
+           'gradient_allreduce_bytes': int(sum(p.numel() * p.element_size() for p in params))}
+    for name, ctx in (('fp32', lambda: torch.autocast('cuda', enabled=False)),
+                      ('bf16_autocast', lambda: torch.autocast('cuda', dtype=torch.bfloat16))):
+        ts, fw = [], []
+        for it in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with ctx():
+                loss, _ = model(batch, return_loss=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            fw.append((t1 - t0) * 1e3)
+        ts, fw = sorted(ts[2:]), sorted(fw[2:])
+        rec[name] = {'ms_per_step': round(ts[len(ts) // 2], 2), 'forward_ms': round(fw[len(fw) // 2], 2),
+                     'loss': round(float(loss), 4)}
+    legs['train_step_s3dis'] = rec
+    return legs
 
 
 def measurement_legs(args, model, batch, xyz, rgb, inst):
@@ -526,6 +616,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_legs:
         out['legs'] = measurement_legs(args, model, batch, xyz, rgb, inst)
+        del model, batch
+        torch.cuda.empty_cache()
+        out['legs'].update(config_legs(args))
 
     if rank == 0:
         print(json.dumps(out))

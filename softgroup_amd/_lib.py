@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsoftgroup_hip.so')
+LIB_PATH = os.path.join(_HERE, 'lib', os.environ.get('SG_LIB_NAME', 'libsoftgroup_hip.so'))   # (developer A/B builds)
 
 _lib = None
 

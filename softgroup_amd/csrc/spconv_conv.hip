@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   //      takes the remaining (lightest) units.  Results do not depend on who computes a unit.
   const int xcd = blockIdx.x & 7;
   const int dyn0 = 2 * G;                      // first handed-out unit (G is a multiple of 8 when > 8)
+  const bool draws = p.queue != nullptr && dyn0 < num_units;     // anything to hand out at all?
   auto barrier = [] {                          // LDS-only rendezvous: must not drain the ticket atomic
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -518,7 +519,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     // wave 0: which unit comes after this one, and its metadata on the way into the other buffer
     int un_w0 = -1;
     if (wave == 0) {
-      if (round == 0 || p.queue == nullptr) {      // (no queue: the static snake all the way, A/B knob)
+      if (round == 0 || !draws) {      // (no queue: the static snake all the way, A/B knob)
         const int r = round + 1;
         un_w0 = r * G + ((__builtin_popcount(r) & 1) ? G - 1 - static_cast<int>(blockIdx.x)
                                                      : static_cast<int>(blockIdx.x));
@@ -573,9 +574,9 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     // the unit after next.  Its answer is first looked at one unit from now.
     if (wave == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // (drawn every unit, also after the queue has run dry: a draw nobody looks at is cheaper
-      // than a data-dependent branch around it; the counters are this launch's own)
-      if (lane == 0 && p.queue != nullptr)
+      // (drawn every unit of a launch that hands units out, also after the queue has run dry: a
+      // draw nobody looks at is cheaper than a data-dependent branch around it)
+      if (lane == 0 && draws)
         ticket = __hip_atomic_fetch_add(p.queue + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 

@@ -248,6 +248,37 @@ def build_model(cfg=None, seed=0, device='cuda', head_std=20.0):
     return model.to(device).eval()
 
 
+def passthrough_init(model, damp=0.2):
+    """Part of the stand-in for a trained checkpoint (`fit_model_to_scenes`): re-shape the random
+    backbone so that the input colour survives to the output features.
+      * `input_conv`: output channels 0..2c-1 carry +-(input channel) of the voxel itself (centre
+        tap), the other channels keep their random taps;
+      * every residual branch and every decoder (deconv) branch is damped by `damp`, the 1x1
+        shortcut of every `blocks_tail.block0` starts as [identity | 0]: the skip path dominates and
+        the deep levels act as a perturbation (they still run, at full cost).
+    A random U-Net with calibrated BatchNorms scrambles the colour (linear R^2 of rgb from the
+    features 0.03-0.16, measured), so no read-out of it finds the synthetic classes."""
+    from .model.blocks import ResidualBlock, UBlock
+    with torch.no_grad():
+        w = model.input_conv[0].weight                     # [Cout, 3, 3, 3, Cin]
+        cin = min(w.shape[-1], 3)
+        w[:2 * cin] = 0
+        for c in range(cin):
+            w[2 * c, 1, 1, 1, c] = 1.0
+            w[2 * c + 1, 1, 1, 1, c] = -1.0
+        for m in model.unet.modules():
+            if isinstance(m, ResidualBlock):
+                m.conv_branch[5].weight.mul_(damp)
+                if not isinstance(m.i_branch[0], torch.nn.Identity):
+                    iw = m.i_branch[0].weight             # [C, 1, 1, 1, 2C]
+                    iw.mul_(damp)
+                    c = iw.shape[0]
+                    iw[torch.arange(c), 0, 0, 0, torch.arange(c)] = 1.0
+            elif isinstance(m, UBlock) and hasattr(m, 'deconv'):
+                m.deconv[2].weight.mul_(damp)
+    return model
+
+
 def _lstsq_head(linear, a, target, ridge=1e-4):
     """linear.weight / bias := ridge least-squares solution of [a, 1] w = target"""
     a1 = torch.cat([a, torch.ones_like(a[:, :1])], 1).double()
@@ -258,6 +289,35 @@ def _lstsq_head(linear, a, target, ridge=1e-4):
     linear.bias.copy_(w[-1])
 
 
+def fit_point_heads(model, feats, semantic_labels, instance_labels, pt_offset_labels, steps=300, lr=0.02):
+    """A few hundred Adam steps on the two point-wise heads (both layers, BatchNorm in eval mode)
+    over fixed backbone features: cross-entropy on the semantic labels, L1 on the offsets of
+    instance points.  Works on any device; returns the final loss."""
+    heads = [model.semantic_linear, model.offset_linear]
+    params = [p for h in heads for p in h.parameters()]
+    was = [p.requires_grad for p in params]
+    for h in heads:
+        h.eval()
+    feats = feats.detach().float()
+    valid = semantic_labels >= 0
+    pos = instance_labels >= 0
+    with torch.enable_grad():
+        for p in params:
+            p.requires_grad_(True)
+        opt = torch.optim.Adam(params, lr=lr)
+        for _ in range(steps):
+            loss = torch.nn.functional.cross_entropy(model.semantic_linear(feats)[valid], semantic_labels[valid])
+            if pos.any():
+                loss = loss + (model.offset_linear(feats)[pos] - pt_offset_labels[pos]).abs().mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        for p, w in zip(params, was):
+            p.requires_grad_(w)
+            p.grad = None
+    return float(loss.detach())
+
+
 def fit_model_to_scenes(model, batches, logit_scale=8.0):
     """Stand-in for a trained checkpoint (none is available offline), GPU only.  Over the given
     labelled scenes (batch dicts of ``make_batch`` / ``collate_device``):
@@ -265,8 +325,9 @@ def fit_model_to_scenes(model, batches, logit_scale=8.0):
       1. every BatchNorm's running statistics := the statistics of its input (cumulative average in
          train mode) -- as in a trained network, so the activations stay standardised and the input
          signal survives the random backbone;
-      2. the last layers of ``semantic_linear`` / ``offset_linear`` are least-squares fitted to the
-         semantic labels (+-``logit_scale`` one-hot logits) and the offset labels;
+      0. ``passthrough_init``: the input colour survives the random backbone;
+      2. ``semantic_linear`` / ``offset_linear`` are fitted to the semantic and offset labels
+         (``fit_point_heads``: a few hundred Adam steps on frozen features);
       3. the tiny U-Net's BatchNorms are calibrated on the resulting proposals, ``cls_linear`` is
          fitted to the majority class of each proposal (background when < 50 % of its points carry
          an instance label) and ``iou_score_linear`` predicts 1.
@@ -302,6 +363,8 @@ def fit_model_to_scenes(model, batches, logit_scale=8.0):
 
     batches = [cuda(b) for b in batches]
     info = {}
+    passthrough_init(model)
+    model.invalidate_caches()
     with torch.no_grad():
         model.eval()
         point_mods = [model.input_conv, model.unet, model.output_layer]
@@ -321,19 +384,8 @@ def fit_model_to_scenes(model, batches, logit_scale=8.0):
         ins = torch.cat([b['instance_labels'] for b in batches])
         off = torch.cat([b['pt_offset_labels'] for b in batches]).float()
 
-        def hidden(head):
-            h = feats
-            for layer in list(head)[:-1]:
-                h = layer(h)
-            return h
-
         valid = sem >= 0
-        n_cls = model.semantic_linear[-1].out_features
-        target = torch.full((feats.shape[0], n_cls), -logit_scale, device=feats.device)
-        target[valid, sem[valid]] = logit_scale
-        _lstsq_head(model.semantic_linear[-1], hidden(model.semantic_linear)[valid], target[valid])
-        pos = ins >= 0
-        _lstsq_head(model.offset_linear[-1], hidden(model.offset_linear)[pos], off[pos])
+        fit_point_heads(model, feats, sem, ins, off)
         info['sem_acc'] = (model.semantic_linear(feats).argmax(1)[valid] == sem[valid]).float().mean().item()
         model.invalidate_caches()
         if model.semantic_only:
