@@ -42,11 +42,43 @@ namespace sg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// ---- fp32 products on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate):
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; the
+// subtractions are exact, the three parts carry 24+ significant bits, |x - (h+m+l)| <= 2^-26 |x|).
+// a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-24 |ab|): six bf16 products, each
+// exact in the MFMA, accumulated in fp32, smallest terms first.  Weights are split once when they
+// are packed; gathered activations are split in registers.
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f2 v = {x[2 * j], x[2 * j + 1]};
+    const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+    const f2 r = v - __builtin_convertvector(hh, f2);
+    const bf16x2 mm = __builtin_convertvector(r, bf16x2);
+    const f2 r2 = r - __builtin_convertvector(mm, f2);
+    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+    h[2 * j] = hh[0]; h[2 * j + 1] = hh[1];
+    m[2 * j] = mm[0]; m[2 * j + 1] = mm[1];
+    l[2 * j] = ll[0]; l[2 * j + 1] = ll[1];
+  }
+}
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return static_cast<uint16_t>((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f32(uint16_t b) {
+  return __builtin_bit_cast(float, static_cast<uint32_t>(b) << 16);
+}
 
 constexpr int kTileRows = 32;
 constexpr int kWavesPerWg = 4;
 constexpr int kCk = 16;        // channels per pipeline slice (8 per half-wave)
 constexpr int kMaxK = 27;
+constexpr int kTicketStride = 32;        // unsigned words between two ticket counters (128 B)
 constexpr unsigned kOob = 0x80000000u;   // byte offset past every (< 2 GB) buffer: loads return 0
 
 // LDS-DMA piece: every active lane moves `16` / `4` bytes from its own global address to
@@ -90,7 +122,8 @@ struct ConvArgs {
   int k_per_split;
   int num_units;
   unsigned magic_upt, magic_cu, magic_nsl;   // reciprocals of units_per_tile, col_units, n_slices
-  unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per XCD)
+  unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per
+                               // XCD, 128 B apart), or null = static hand-out
   unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
 };
 
@@ -273,9 +306,10 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
 constexpr int kMetaInts = kMaskAt + 4;
 
-template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1>
+template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0>
 __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
                                                                          unsigned w_bytes) {
+  static_assert(!SPLIT || CK == 16, "split-precision path: 16-channel slices");
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
   constexpr int NQ = HC / 4;   // dwordx4 loads per lane per operand per slice
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -356,7 +390,11 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   };
   (void)num_tiles;
 
-  struct Slice { f4 a[NQ]; f4 b[NBW][NQ]; };
+  // SPLIT: b[n][pl] = the 8 bf16 weights of plane pl (h, m, l) for this lane's channel block
+  constexpr int NB_ = SPLIT ? 3 : NQ;
+  struct Slice { f4 a[NQ]; f4 b[NBW][NB_]; };
+  const int plane_bytes = p.K * c8 * p.Cout * 16;          // one bf16 plane of the packed weights
+  const int planes_at = 2 * plane_bytes;                   // they follow the fp32 copy
   // per-unit context (wave-uniform scalars + the lane's column)
   struct Ctx {
     const int32_t *meta;   // LDS block of the unit
@@ -381,15 +419,26 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, 0));
-    const int s_w = (k * c8 + s * (CK / 8)) * p.Cout * 32;
-    // column block n of the unit: the same packed block 32 columns (1 KB) further on
+    if constexpr (SPLIT) {
+      // bf16 planes, layout [K][Cin/8][Cout][8]: lane (h, col) reads block (k, 2s + h) of its column
+      const int s_w = planes_at + (k * c8 + s * 2) * p.Cout * 16;
 #pragma unroll
-    for (int n = 0; n < NBW; ++n)
+      for (int n = 0; n < NBW; ++n)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        S.b[n][q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rs_w, c.v_w + n * 1024 + (q & 1) * 16,
-                                               s_w + (q >> 1) * (p.Cout * 32), 0));
+        for (int pl = 0; pl < 3; ++pl)
+          S.b[n][pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rs_w, c.v_w + n * 512, s_w + pl * plane_bytes, 0));
+    } else {
+      const int s_w = (k * c8 + s * (CK / 8)) * p.Cout * 32;
+      // column block n of the unit: the same packed block 32 columns (1 KB) further on
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          S.b[n][q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rs_w, c.v_w + n * 1024 + (q & 1) * 16,
+                                                 s_w + (q >> 1) * (p.Cout * 32), 0));
+    }
   };
 
   auto advance = [&](const Ctx &c, int &k, int &s) {
@@ -415,7 +464,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     c.col = d.cu * (32 * NBW) + arow;
     c.col_ok = c.col < p.Cout;
     const int colc = min(c.col, p.Cout - 1);
-    c.v_w = (ahalf * (HC / 8) * p.Cout + colc) * 32;
+    c.v_w = SPLIT ? (ahalf * p.Cout + colc) * 16 : (ahalf * (HC / 8) * p.Cout + colc) * 32;
     const int items = __builtin_popcount(m) * n_slices;
     const int per = (items + kWavesPerWg - 1) >> 2;
     const int begin = min(items, wave * per);
@@ -460,6 +509,24 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
 
   f32x16 acc[NBW];
   auto compute = [&](Slice &S) {
+    if constexpr (SPLIT) {
+      const float af[8] = {S.a[0][0], S.a[0][1], S.a[0][2], S.a[0][3], S.a[1][0], S.a[1][1], S.a[1][2], S.a[1][3]};
+      bf16x8 ah, am, al;
+      split3(af, ah, am, al);
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, S.b[n][0]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, S.b[n][1]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, S.b[n][2]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+      }
+      return;
+    }
     // every operand of the slice is in registers before the matrix block starts: one wait, then
     // back-to-back MFMAs with nothing in between (the column blocks alternate: independent chains)
 #pragma unroll
@@ -577,7 +644,8 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       // (drawn every unit of a launch that hands units out, also after the queue has run dry: a
       // draw nobody looks at is cheaper than a data-dependent branch around it)
       if (lane == 0 && draws)
-        ticket = __hip_atomic_fetch_add(p.queue + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(p.queue + xcd * kTicketStride, 1u, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ---- partial sums meet in LDS (the next unit's identity and metadata are there already)
@@ -743,6 +811,15 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restric
       v = src_kio ? w[(static_cast<int64_t>(k) * cin + ci) * cout + co]
                   : w[(static_cast<int64_t>(co) * K + k) * cin + ci];
     out[t] = v;
+    // the same element as three bf16 planes behind the fp32 copy (split-precision MFMA path)
+    uint16_t *planes = reinterpret_cast<uint16_t *>(out + total);
+    const uint16_t h = bf16_rne(v);
+    const float rest = v - bf16_f32(h);
+    const uint16_t m = bf16_rne(rest);
+    const uint16_t l = bf16_rne(rest - bf16_f32(m));
+    planes[t] = h;
+    planes[total + t] = m;
+    planes[2 * total + t] = l;
   }
 }
 
@@ -774,12 +851,15 @@ static ConvProf g_conv_prof;
 // Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
 // of 8 counters (one per XCD) out of a per-(device, stream) pool; the pool is cleared again, in
 // stream order, when it has been used up.  Launches on one stream run in order, so a block is
-// never shared by two kernels.
+// never shared by two kernels.  Every counter has a 128-byte line to itself: with the 8 counters
+// of a launch in one line a draw took 13-34 k ticks (the line ping-pongs between the XCDs' L2s),
+// with one line each 1.4 k (tools/micro/atomic_ticket.hip, profiles/r03_atomic_ticket.txt).
 struct TicketPool {
   unsigned *dev = nullptr;
   size_t next = 0;
 };
-constexpr size_t kTicketBlocks = 1 << 15;     // x 32 B = 1 MB per stream
+constexpr size_t kTicketBlockBytes = 8 * kTicketStride * sizeof(unsigned);
+constexpr size_t kTicketBlocks = 1 << 12;     // x 1 KB = 4 MB per stream
 static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, TicketPool> g_ticket_pools;
 
@@ -789,14 +869,14 @@ static unsigned *take_tickets(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_ticket_mu);
   TicketPool &tp = g_ticket_pools[{dev, stream}];
   if (tp.dev == nullptr) {
-    if (hipMalloc(&tp.dev, kTicketBlocks * 32) != hipSuccess) return nullptr;
+    if (hipMalloc(&tp.dev, kTicketBlocks * kTicketBlockBytes) != hipSuccess) return nullptr;
     tp.next = kTicketBlocks;
   }
   if (tp.next == kTicketBlocks) {
-    hipMemsetAsync(tp.dev, 0, kTicketBlocks * 32, stream);
+    hipMemsetAsync(tp.dev, 0, kTicketBlocks * kTicketBlockBytes, stream);
     tp.next = 0;
   }
-  return tp.dev + 8 * tp.next++;
+  return tp.dev + (8 * kTicketStride) * tp.next++;
 }
 
 }  // namespace sg
@@ -827,14 +907,19 @@ int sg_spconv_profile_read(double *total_ms, int *launches) {
   return SG_OK;
 }
 
-size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout) {
+// fp32 "k8" copy followed by its three bf16 split planes (h, m, l), 2 bytes per element each
+static size_t packed_k8_elems(int kvol, int cin, int cout) {
   return static_cast<size_t>(kvol) * ((cin + 7) / 8) * cout * 8;
+}
+size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout) {
+  const size_t n = packed_k8_elems(kvol, cin, cout);
+  return n + 3 * n / 2;
 }
 
 int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
                           sg_stream_t stream) {
   SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0, "sg_spconv_pack_weight: bad arguments");
-  const int64_t total = static_cast<int64_t>(sg_spconv_packed_weight_elems(kvol, cin, cout));
+  const int64_t total = static_cast<int64_t>(packed_k8_elems(kvol, cin, cout));
   pack_weight_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>(w, cout, kvol, cin,
                                                                          src_is_kio, w_k8);
   return check_launch("sg_spconv_pack_weight");
@@ -954,7 +1039,12 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // held to 80 VGPRs, 6 workgroups per CU (developer knob for the occupancy A/B)
     static const int wpe_env = getenv("SG_CONV_WPE") ? atoi(getenv("SG_CONV_WPE")) : 5;
     const bool wpe6 = wpe_env >= 6;
-    static int occ_tab[5] = {0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide
+    // split-precision path (fp32 products as six bf16 MFMAs, see split3): on by default for layers
+    // with Cin >= SG_CONV_SPLIT_MIN_CIN (developer knobs SG_CONV_SPLIT=0 turns it off)
+    static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
+    static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 32;
+    const bool split = split_env != 0 && Cin >= split_min_cin;
+    static int occ_tab[7] = {0, 0, 0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide; split; split wide
     auto occupancy = [&](int which) {
       if (occ_tab[which] == 0) {
         int o = 0;
@@ -962,19 +1052,24 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
         else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0, 4>, 256, lds);
         else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0, 2>, 256, lds);
         else if (which == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
+        else if (which == 4) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
+        else if (which == 5) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 1, 1>, 256, lds);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 3, 2, 1>, 256, lds);
         if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
         occ_tab[which] = o < 1 ? 1 : o;
       }
       return occ_tab[which];
     };
     int which = wide ? 4 : wpe6 ? 3 : 0;
-    if (!wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
+    if (split) which = wide ? 6 : 5;
+    if (!split && !wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
       which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : which;
     const int occ = occupancy(which);
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      if (which == 6) gather_conv_persistent_kernel<kSliceCh, 2, 0, 3, 2, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 5) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 1, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      else if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 3) gather_conv_persistent_kernel<kSliceCh, 2, 0, 6><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Developer A/B of the sparse-conv kernel on one box: the round-2 kernel (libsoftgroup_hip_r02conv.so,
-# built by hand from the previous source), this round's kernel with the static hand-out, and with
-# the ticket hand-out.  Conv time per scan comes from the in-library HIP events (bench.py roofline).
+# Developer A/B of the sparse-conv kernel variants on one box (environment knobs of
+# csrc/spconv_conv.hip).  Conv time per scan comes from the in-library HIP events (bench.py roofline).
+#   bash tools/conv_ab.sh "SG_CONV_SPLIT=0" "SG_CONV_SPLIT=1" ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in 1 2; do
-for v in "SG_LIB_NAME=libsoftgroup_hip_r02conv.so" "SG_CONV_STATIC=1" "SG_CONV_STATIC=0"; do
+for v in "$@"; do
   env $v python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-legs 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
