@@ -306,10 +306,25 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
 constexpr int kMetaInts = kMaskAt + 4;
 
-template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
-                                                                         unsigned w_bytes) {
-  static_assert(!SPLIT || CK == 16, "split-precision path: 16-channel slices");
+//   * WV waves per workgroup (4, 8 or 16) share a unit: the unit's items are split WV ways.  More
+//     waves = shorter units and more rounds of units per workgroup slot, which is what evens out
+//     layers with few units (22 649 rows x 96 columns: 2 124 units for 1 280 four-wave slots = 1.7
+//     rounds, workgroups ended between 42 k and 110 k ticks; the deep levels used to split their
+//     offsets over several workgroups and add the partial sums in a second kernel).
+//   * AT (with SPLIT, CK = 32): the gathered rows are fetched in FULL 128-byte lines -- 8 lanes per
+//     row, 4 coalesced loads for the tile's 32 rows x 32 channels -- and transposed into the MFMA
+//     fragment layout through a wave-private 4 KB LDS block (XOR-swizzled, conflict-free both ways).
+//     The fragment-shaped alternative (every lane 32 B of its own row) touches 32 different lines
+//     per load instruction, and it is the CU's vector-memory path, not the matrix pipe, that this
+//     kernel waits on once the products are bf16 MFMAs.
+template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0, int WV = 4, int AT = 0>
+__global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
+                                                                             unsigned w_bytes) {
+  static_assert(!SPLIT || CK == 16 || AT, "split-precision path: 16-channel slices");
+  static_assert(!AT || (SPLIT && CK == 32), "line-wise gather: split path, 32-channel items");
+  static_assert(WV == 4 || WV == 8 || WV == 16, "4, 8 or 16 waves per workgroup");
+  constexpr int RR = 16 / WV;          // accumulator registers (row groups) each wave finalises
+  constexpr int WV_SHIFT = WV == 4 ? 2 : WV == 8 ? 3 : 4;
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
   constexpr int NQ = HC / 4;   // dwordx4 loads per lane per operand per slice
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int arow = lane & 31, ahalf = lane >> 5;
   float *red = reinterpret_cast<float *>(smem_raw);                  // [4 waves][NBW][16][64]
-  int32_t *meta_lds = reinterpret_cast<int32_t *>(red + kWavesPerWg * NBW * 16 * 64);   // [2][kMetaInts]
+  int32_t *meta_lds = reinterpret_cast<int32_t *>(red + WV * NBW * 16 * 64);   // [2][kMetaInts]
 
   const int G = gridDim.x;
   const int units_per_tile = p.col_units * p.ksplit;
@@ -391,7 +406,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
   (void)num_tiles;
 
   // SPLIT: b[n][pl] = the 8 bf16 weights of plane pl (h, m, l) for this lane's channel block
-  constexpr int NB_ = SPLIT ? 3 : NQ;
+  constexpr int NB_ = AT ? 6 : SPLIT ? 3 : NQ;   // AT: two 16-channel sub-slices x three planes
   struct Slice { f4 a[NQ]; f4 b[NBW][NB_]; };
   const int plane_bytes = p.K * c8 * p.Cout * 16;          // one bf16 plane of the packed weights
   const int planes_at = 2 * plane_bytes;                   // they follow the fp32 copy
@@ -402,17 +417,39 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
     int v_w;
     float ps[NBW], pb[NBW], as[NBW], ab[NBW];
-    unsigned o_off[4];     // byte offsets of the 4 output rows this lane stores (kOob: padding row)
+    unsigned o_off[RR];    // byte offsets of the output rows this lane stores (kOob: padding row)
     bool col_ok;
   };
 
   Slice S[DEPTH];   // operand ring: DEPTH-1 slices of loads in flight behind the one multiplied
-  float resv[NBW][4];
+  float resv[NBW][RR];
 
   // lane (h, i) owns channels s*CK + h*HC .. + HC-1 of gathered row i: HC*4 contiguous bytes of the
   // row (CK = 32: the half-wave pair reads the row's whole 128-B line in one slice) and the
   // matching HC/8 packed weight blocks of its column
+  f4 *tr_lds = reinterpret_cast<f4 *>(ctl + 4) + wave * 256;       // AT: this wave's 32 x 128 B block
   auto load = [&](const Ctx &c, int k, int s, Slice &S) {
+    if constexpr (AT) {
+      // load q: row 8q + lane/8 of the tile, 16-byte chunk lane%8 of the item's 128-byte line
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src = c.meta[(8 * q + (lane >> 3)) * p.K + k];
+        const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + (lane & 7) * 4) * 4u : kOob;
+        S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, 0));
+      }
+      // weights: sub-slice sl = channel blocks 4s + 2sl + h of the three bf16 planes
+      const int s_w = planes_at + (k * c8 + s * 4) * p.Cout * 16;
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            S.b[n][sl * 3 + pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             rs_w, c.v_w + n * 512,
+                                                             s_w + sl * (2 * p.Cout * 16) + pl * plane_bytes, 0));
+      return;
+    }
     const int src = c.meta[nbr_base + k];
     const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + ahalf * HC) * 4u : kOob;
     const int s_a = s * (CK * 4);
@@ -466,7 +503,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     const int colc = min(c.col, p.Cout - 1);
     c.v_w = SPLIT ? (ahalf * p.Cout + colc) * 16 : (ahalf * (HC / 8) * p.Cout + colc) * 32;
     const int items = __builtin_popcount(m) * n_slices;
-    const int per = (items + kWavesPerWg - 1) >> 2;
+    const int per = (items + WV - 1) >> WV_SHIFT;
     const int begin = min(items, wave * per);
     c.rem = min(items, begin + per) - begin;
     int rank = udiv(begin, p.magic_nsl);
@@ -482,10 +519,16 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
       if (i < c.rem) advance(c, c.kp, c.sp);
       load(c, c.kp, c.sp, S[i]);
     }
-    const int4 rows = *reinterpret_cast<const int4 *>(c.meta + kRowsAt + 8 * wave + 4 * ahalf);
-    const int row4[4] = {rows.x, rows.y, rows.z, rows.w};
+    // this wave finalises accumulator registers wave*RR .. wave*RR+RR-1; register r of lane half h
+    // is tile row (r & 3) + 8 * (r >> 2) + 4 * h
+    int row4[RR];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < RR; ++rr) {
+      const int reg = wave * RR + rr;
+      row4[rr] = c.meta[kRowsAt + (reg & 3) + 8 * (reg >> 2) + 4 * ahalf];
+    }
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
       const unsigned off = (row4[rr] >= 0 && c.col_ok)
                                ? static_cast<unsigned>(row4[rr] * p.Cout + c.col) * 4u : kOob;
       c.o_off[rr] = off;   // kept for the epilogue: the unit's LDS block is not read after its loop
@@ -509,6 +552,41 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
 
   f32x16 acc[NBW];
   auto compute = [&](Slice &S) {
+    if constexpr (AT) {
+      // rows as loaded -> LDS (row r at r * 128 B, chunk c at position c ^ ((r >> 1) & 7)), then
+      // lane (h, i) reads the two chunks of its 8 channels of row i for each sub-slice
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + (lane >> 3);
+        tr_lds[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = S.a[q];
+      }
+      f4 fr[2][2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          fr[sl][j] = tr_lds[arow * 8 + ((sl * 4 + ahalf * 2 + j) ^ ((arow >> 1) & 7))];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const float af[8] = {fr[sl][0][0], fr[sl][0][1], fr[sl][0][2], fr[sl][0][3],
+                             fr[sl][1][0], fr[sl][1][1], fr[sl][1][2], fr[sl][1][3]};
+        bf16x8 ah, am, al;
+        split3(af, ah, am, al);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 0]);
+          const bf16x8 bm = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 1]);
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 2]);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+        }
+      }
+      return;
+    }
     if constexpr (SPLIT) {
       const float af[8] = {S.a[0][0], S.a[0][1], S.a[0][2], S.a[0][3], S.a[1][0], S.a[1][1], S.a[1][2], S.a[1][3]};
       bf16x8 ah, am, al;
@@ -664,23 +742,25 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     // ---- epilogue operands first (all LDS reads in flight together), then the next unit's first
     //      operand loads, then the stores: fixed-order sum w0+w1+w2+w3 (+ residual, post); each
     //      wave stores 4 row groups, padding rows go past the end of the buffer (dropped)
-    float v[NBW][4], va[NBW][4];
-    unsigned o_off[4];
+    float v[NBW][RR], va[NBW][RR];
+    unsigned o_off[RR];
     {
-      float part[NBW][4][4];
+      float part[NBW][RR][WV];
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int reg = wave * 4 + rr;
+        for (int rr = 0; rr < RR; ++rr) {
+          const int reg = wave * RR + rr;
 #pragma unroll
-          for (int w = 0; w < kWavesPerWg; ++w) part[n][rr][w] = red[((w * NBW + n) * 16 + reg) * 64 + lane];
+          for (int w = 0; w < WV; ++w) part[n][rr][w] = red[((w * NBW + n) * 16 + reg) * 64 + lane];
         }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < RR; ++rr) {
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
-          float t = ((part[n][rr][0] + part[n][rr][1]) + part[n][rr][2]) + part[n][rr][3];
+          float t = part[n][rr][0];          // fixed order: wave 0 + wave 1 + ... (deterministic)
+#pragma unroll
+          for (int w = 1; w < WV; ++w) t += part[n][rr][w];
           t += resv[n][rr];    // residual rows of THIS unit (requested by its setup, one unit ago)
           if (post) t = fmaxf(fmaf(t, c.ps[n], c.pb[n]), 0.f);
           v[n][rr] = t;
@@ -694,14 +774,14 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     setup(dn, has_next ? (buf ^ 1) : buf, c);
     mark(4);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
                                               o_base + n * 128, 0);
     if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+      for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[n][rr]), rs_act, o_off[rr],
@@ -709,7 +789,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_persistent_kernel(ConvAr
     }
     mark(5);
     if constexpr (TRACE) {
-      if (lane == 0 && p.trace) {
+      if (lane == 0 && p.trace && wave < kWavesPerWg) {       // (the first four waves of a unit)
         unsigned long long *t = p.trace + (static_cast<long long>(u) * kWavesPerWg + wave) * 8;
         for (int i = 0; i < 6; ++i) t[i] = stamp[i];
         unsigned hw, xcc;
@@ -879,6 +959,113 @@ static unsigned *take_tickets(hipStream_t stream) {
   return tp.dev + (8 * kTicketStride) * tp.next++;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Launch of the split-precision persistent kernel.  Decomposition: unit = (32-row tile, one or
+// two 32-column blocks, ALL offsets); the unit's items are split over the WV waves of one
+// workgroup and meet in LDS -- no partial sums through memory, no reduce kernel.  (NBW, WV) is the
+// first of (2,4) (1,4) (1,8) (1,16) that gives every workgroup slot >= 2.5 units on average, else
+// (1,16): large layers keep the gathered rows in registers for two column blocks, small layers
+// put more waves on fewer, shorter units.
+// ---------------------------------------------------------------------------------------------
+typedef void (*PersistentFn)(ConvArgs, unsigned, unsigned);
+struct SplitVariant {
+  PersistentFn fn, fn_trace;
+  int nbw, wv, ck, at;
+  size_t lds;
+  int occ;      // resident workgroups per CU (0 = not asked yet)
+};
+#define SG_SPLIT_VARIANT(CK, WPE, NBW, WV, AT)                                                   \
+  {gather_conv_persistent_kernel<CK, 2, 0, WPE, NBW, 1, WV, AT>,                                  \
+   gather_conv_persistent_kernel<CK, 2, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
+static SplitVariant g_split_variants[7] = {
+    SG_SPLIT_VARIANT(32, 2, 2, 4, 1),  SG_SPLIT_VARIANT(32, 3, 1, 4, 1), SG_SPLIT_VARIANT(32, 1, 1, 8, 1),
+    SG_SPLIT_VARIANT(16, 3, 2, 4, 0),  SG_SPLIT_VARIANT(16, 4, 1, 4, 0), SG_SPLIT_VARIANT(16, 2, 1, 8, 0),
+    SG_SPLIT_VARIANT(16, 1, 1, 16, 0),
+};
+
+static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes, long long w_bytes,
+                                   hipStream_t stream) {
+  static int num_cu = 0;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (num_cu <= 0) num_cu = 256;
+    for (SplitVariant &v : g_split_variants) {
+      v.lds = static_cast<size_t>(v.wv) * v.nbw * 16 * 64 * sizeof(float) + 2 * kMetaInts * sizeof(int32_t) + 16 +
+              (v.at ? static_cast<size_t>(v.wv) * 4096 : 0);
+      int o = 0;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn, 64 * v.wv, v.lds);
+      v.occ = o < 1 ? 1 : o;
+    }
+  });
+  static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;          // developer knobs
+  static const int wv_env = getenv("SG_CONV_WV") ? atoi(getenv("SG_CONV_WV")) : 0;             // force 4 / 8 / 16
+  static const float min_rounds = getenv("SG_CONV_ROUNDS") ? atof(getenv("SG_CONV_ROUNDS")) : 2.5f;
+  static const int at_env = getenv("SG_CONV_AT") ? atoi(getenv("SG_CONV_AT")) : 1;             // line-wise gather
+  const int NB = (a.Cout + 31) / 32;
+  const int use_at = (at_env != 0 && a.Cin % 32 == 0) ? 1 : 0;
+  int pick = -1;
+  // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
+  // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units
+  // (141 rows x 192 columns: 22.6 us against 42.7 us).  They run as 4-wave, one-block units.
+  for (int i = 0; i < 7; ++i) {
+    const SplitVariant &v = g_split_variants[i];
+    if (v.at != use_at) continue;
+    if (a.ksplit > 1) {
+      if (v.nbw == 1 && v.wv == 4) { pick = i; break; }
+      continue;
+    }
+    pick = i;                         // (the last candidate of the group stays if none qualifies)
+    if (v.nbw == 2 && (a.Cout % 64 != 0 || nbw_env < 2)) continue;
+    if (wv_env && v.wv != wv_env) continue;
+    const long long units = static_cast<long long>(num_tiles) * (NB / v.nbw);
+    if (wv_env || units >= static_cast<long long>(min_rounds * num_cu * v.occ)) {
+      pick = i;
+      break;
+    }
+  }
+  const SplitVariant &v = g_split_variants[pick];
+  a.col_units = NB / v.nbw;
+  a.blocks_per_unit = v.nbw;
+  const long long units = static_cast<long long>(num_tiles) * a.col_units * a.ksplit;
+  a.num_units = static_cast<int>(units);
+  auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
+  a.magic_upt = magic(static_cast<unsigned>(a.col_units * a.ksplit));
+  a.magic_cu = magic(static_cast<unsigned>(a.col_units));
+  a.magic_nsl = magic(static_cast<unsigned>(a.Cin / v.ck));
+  static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
+  a.queue = dyn_env ? take_tickets(stream) : nullptr;
+  long long g = static_cast<long long>(num_cu) * v.occ;
+  if (g > units) g = units;
+  if (g >= 8) g -= g % 8;
+  const unsigned ib = static_cast<unsigned>(in_bytes), wb = static_cast<unsigned>(w_bytes);
+  static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
+  if (trace_env) {
+    const size_t nb = static_cast<size_t>(units) * kWavesPerWg * 8 * sizeof(unsigned long long);
+    unsigned long long *dbuf = nullptr;
+    hipMalloc(&dbuf, nb);
+    hipMemsetAsync(dbuf, 0, nb, stream);
+    a.trace = dbuf;
+    v.fn_trace<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
+    hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h(nb / 8);
+    hipMemcpy(h.data(), dbuf, nb, hipMemcpyDeviceToHost);
+    hipFree(dbuf);
+    if (FILE *f = fopen(trace_env, "ab")) {
+      long long hdr[8] = {a.M_out, a.K, a.Cin, a.Cout, units, a.col_units, v.wv, g};
+      fwrite(hdr, 8, 8, f);
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+  } else {
+    v.fn<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
+  }
+  return check_launch("sg_spconv_gather_conv_f32(split)");
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -972,6 +1159,12 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                           static_cast<long long>(num_tiles) * kTileRows * K * 4 < (1LL << 31) &&
                           order != nullptr && tile_mask != nullptr && nbr_tiles != nullptr &&
                           reinterpret_cast<uintptr_t>(nbr_tiles) % 16 == 0;      // 16-byte LDS-DMA pieces
+  // split-precision path (fp32 products as six bf16 MFMAs, see split3): the default for every layer
+  // the persistent kernel takes with Cin >= SG_CONV_SPLIT_MIN_CIN (SG_CONV_SPLIT=0: the fp32-MFMA
+  // kernel, kept for A/B)
+  static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
+  static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 32;
+  const bool split = persistent && split_env != 0 && Cin >= split_min_cin;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
   static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 2048;   // developer knob
@@ -986,7 +1179,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   // gathered rows are read once for both, half as many unit boundaries).  SG_CONV_NBW=1 disables it.
   static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;   // developer knob
   // (Cout % 64 == 0: the second column block of a unit is addressed without its own bounds check)
-  const bool wide = persistent && nbw_env >= 2 && Cout % 64 == 0 &&
+  const bool wide = persistent && !split && nbw_env >= 2 && Cout % 64 == 0 &&
                     static_cast<long long>(num_tiles) * (NB / 2) >= 2048;
   if (wide) bpu = 2;
   const int col_units = (NB + bpu - 1) / bpu;
@@ -1017,7 +1210,10 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.magic_cu = magic(static_cast<unsigned>(col_units));
   a.magic_nsl = 0;
 
-  if (persistent) {
+  if (split) {
+    const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream);
+    if (rc != SG_OK) return rc;
+  } else if (persistent) {
     // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
     // XCD u % 8)
     const size_t lds = static_cast<size_t>(kWavesPerWg) * (wide ? 2 : 1) * 16 * 64 * sizeof(float) +
@@ -1039,12 +1235,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     // held to 80 VGPRs, 6 workgroups per CU (developer knob for the occupancy A/B)
     static const int wpe_env = getenv("SG_CONV_WPE") ? atoi(getenv("SG_CONV_WPE")) : 5;
     const bool wpe6 = wpe_env >= 6;
-    // split-precision path (fp32 products as six bf16 MFMAs, see split3): on by default for layers
-    // with Cin >= SG_CONV_SPLIT_MIN_CIN (developer knobs SG_CONV_SPLIT=0 turns it off)
-    static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
-    static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 32;
-    const bool split = split_env != 0 && Cin >= split_min_cin;
-    static int occ_tab[7] = {0, 0, 0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide; split; split wide
+    static int occ_tab[5] = {0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide
     auto occupancy = [&](int which) {
       if (occ_tab[which] == 0) {
         int o = 0;
@@ -1052,24 +1243,19 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
         else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0, 4>, 256, lds);
         else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0, 2>, 256, lds);
         else if (which == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
-        else if (which == 4) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
-        else if (which == 5) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 1, 1>, 256, lds);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 3, 2, 1>, 256, lds);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
         if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
         occ_tab[which] = o < 1 ? 1 : o;
       }
       return occ_tab[which];
     };
     int which = wide ? 4 : wpe6 ? 3 : 0;
-    if (split) which = wide ? 6 : 5;
-    if (!split && !wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
+    if (!wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
       which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : which;
     const int occ = occupancy(which);
     auto launch = [&](int g_, bool trace) {
       const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (which == 6) gather_conv_persistent_kernel<kSliceCh, 2, 0, 3, 2, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 5) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 1, 1><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
+      if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 3) gather_conv_persistent_kernel<kSliceCh, 2, 0, 6><<<g_, 256, lds, stream>>>(a, ib_, wb_);
       else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);

@@ -18,12 +18,12 @@ def main():
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     model = synthetic.build_model(seed=0)
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(int(os.environ.get('CONV_LAYERS_WARM', '3'))):
             model(batch)
         prof = spcore.ConvProfiler()
         spcore.PROFILER = prof
         model.use_executor = False      # per-launch events are recorded on the module path
-        reps = 5
+        reps = int(os.environ.get('CONV_LAYERS_REPS', '5'))
         for _ in range(reps):
             model(batch)
         torch.cuda.synchronize()
