@@ -485,6 +485,11 @@ def main():
                              'number on 1x Titan X with real ScanNet v2 data',
             'parallelism': f'scenes sharded one per GPU x{world}, no data-path collective',
             'scans_in_flight': model.scan_contexts,
+            'arithmetic': 'fp32 in, fp32 out, fp32 accumulation everywhere; the sparse-conv products run on '
+                          'the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per 16-channel slice over '
+                          '3-way split operands (x = h + m + l, bf16 each: 24+ significant bits; dropped '
+                          'terms <= 2^-24 |ab|) -- measured against the fp32-MFMA kernel and the oracle '
+                          'in parity_at_bench; SG_CONV_SPLIT=0 selects the fp32-MFMA kernel',
         },
         'ranks_seen': world, 'devices': devices,
         # ms/scan of each third of the timed region on rank 0, and their median
@@ -582,7 +587,11 @@ def main():
         # kernel: AI = 2*Cout/4.25 flop/B of gathered data); the other one is kept alongside
         bound = 'mfma' if mfma['frac'] >= hbm['frac'] else 'hbm'
         out['roofline'] = {
-            'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv, fp32 MFMA)',
+            'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv; fp32 products as six '
+                      'bf16 MFMAs on split operands, fp32 accumulate; priced against the fp32-MFMA peak)',
+            'bf16_mfma_issued': {'achieved': round(6 * tflops, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                 'frac': round(6 * tflops / 2500.0, 4),
+                                 'note': 'six bf16 MFMA flops are issued per algorithmic fp32 flop'},
             'bound': bound, **(mfma if bound == 'mfma' else hbm),
             'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_scan': s['launches'] // n_pass,

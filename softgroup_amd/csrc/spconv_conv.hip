@@ -1167,8 +1167,9 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   const bool split = persistent && split_env != 0 && Cin >= split_min_cin;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
-  static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 2048;   // developer knob
-  const int target = target_env;
+  static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 0;   // developer knob
+  // (the split-precision kernel's units are shorter: it wants half as many offset splits, measured)
+  const int target = target_env > 0 ? target_env : split ? 1024 : 2048;
   const int waves_per_unit = persistent ? kWavesPerWg : 1;
   int bpu = 1;
   if (!persistent) {
