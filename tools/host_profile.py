@@ -1,8 +1,12 @@
-"""Developer tool: where the HOST time of one forward goes (cProfile, no extra syncs)."""
+"""Developer tool: where does the HOST time of one scan go?  cProfile over N forward_test calls
+(one scan at a time, results in line), top functions by cumulative and by own time.
+Usage (GPU box): python tools/host_profile.py [scans]"""
 import cProfile
+import io
 import os
 import pstats
 import sys
+import time
 
 import torch
 
@@ -11,30 +15,28 @@ from softgroup_amd import synthetic  # noqa: E402
 
 
 def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     xyz, rgb, inst = synthetic.scene_s2(seed=1, n=150000)
     batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     model = synthetic.build_model(seed=0)
+    model.async_results = False
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(5):
             model(batch)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
         pr = cProfile.Profile()
-        n = 10
         pr.enable()
         for _ in range(n):
             model(batch)
-        torch.cuda.synchronize()
         pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats('cumulative')
-    rows = []
-    for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
-        rows.append((ct / n * 1e3, tt / n * 1e3, nc / n, f'{os.path.basename(fn)}:{line}:{name}'))
-    rows.sort(reverse=True)
-    print('cum ms/scan  self ms/scan  calls/scan  function')
-    for ct, tt, nc, nm in rows[:70]:
-        print(f'{ct:10.3f} {tt:12.3f} {nc:10.1f}  {nm}')
+        torch.cuda.synchronize()
+        print(f'{(time.perf_counter() - t0) / n * 1e3:.3f} ms/scan under the profiler')
+    for key in ('cumulative', 'tottime'):
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+        print(s.getvalue()[:9000])
 
 
 if __name__ == '__main__':
