@@ -22,7 +22,7 @@ SOURCES = [
     ('bfs.hip', ['-ffp-contract=off']),
     ('spconv_rulebook.hip', ['-ffp-contract=off']),
     # (atomic optimizer off: it would wait for the unit-ticket atomic right where it is issued)
-    ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None']),
+    ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'] + os.environ.get('SG_CONV_EXTRA_FLAGS', '').split()),
     ('spconv_train.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
