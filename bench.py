@@ -579,8 +579,9 @@ def main():
                 factor = float(rec.get('fetch_size_factor', 2.0))
                 traffic = int((factor * pmc['FETCH_SIZE']['per_dispatch'] +
                                pmc['WRITE_SIZE']['per_dispatch']) * 1024)
-                traffic_source = (f'profiles/{fn} (separate rocprofv3 --pmc run of the same workload; '
-                                  f'FETCH_SIZE x {factor:g} + WRITE_SIZE, per dispatch)')
+                traffic_source = (f'profiles/{fn} (separate rocprofv3 --pmc passes; FETCH_SIZE x {factor:g} + '
+                                  f'WRITE_SIZE per dispatch of the conv kernel, over {rec["counters"]["FETCH_SIZE"]["dispatches"]} '
+                                  f'dispatches; ' + rec.get('note', 'same workload') + ')')
                 break
             except (OSError, ValueError, KeyError):
                 continue
