@@ -178,6 +178,41 @@ def config_legs(args):
             stages, info = stage_times(model, batch, reps=2)
         return {'ms_per_scan_unpipelined': round(ms, 3), 'stages_ms': stages, 'scene': info}
 
+    # ---- config 2 again, but with a stand-in for a TRAINED checkpoint (synthetic.fit_model_to_scenes:
+    #      colour pass-through backbone, calibrated BatchNorms, heads fitted to the synthetic labels of
+    #      4 class-coloured scenes): the proposals are the 12 furniture-sized objects of a scene, and
+    #      the predictions can be scored against the synthetic ground truth (AP of the evaluator that
+    #      equals the reference's ScanNetEval, tests/test_eval.py) -- "at reference AP" has no
+    #      checkpoint or dataset to stand on offline; this is its stand-in
+    from softgroup_amd.evaluation import ScanNetEval
+    fit_batches, eval_batches = [], []
+    for i in range(6):
+        x, c, ins = synthetic.scene_s2(seed=200 + i, n=args.points, class_colour=True)
+        (fit_batches if i < 4 else eval_batches).append(cuda(synthetic.make_batch(x, c, instance_labels=ins)))
+    fmodel = synthetic.build_model(seed=0, head_std=None)
+    fit = synthetic.fit_model_to_scenes(fmodel, fit_batches)
+    fmodel.async_results = False
+    with torch.no_grad():
+        res = [fmodel(b) for b in eval_batches]        # held-out scenes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for b in eval_batches:
+                fmodel(b)
+        torch.cuda.synchronize()
+        fitted_ms = (time.perf_counter() - t0) / (3 * len(eval_batches)) * 1e3
+        fstages, finfo = stage_times(fmodel, eval_batches[0], reps=2)
+    classes = ['c%d' % i for i in range(18)]
+    avgs = ScanNetEval(classes).evaluate([r['pred_instances'] for r in res], [r['gt_instances'] for r in res],
+                                         verbose=False)
+    legs['fitted_checkpoint'] = {
+        'ms_per_scan_unpipelined': round(fitted_ms, 3), 'stages_ms': fstages, 'scene': finfo, 'fit': fit,
+        'held_out_scenes': len(eval_batches),
+        'AP': round(float(avgs['all_ap']), 4), 'AP50': round(float(avgs['all_ap_50%']), 4),
+        'AP25': round(float(avgs['all_ap_25%']), 4),
+        'note': 'synthetic class-coloured S2 scenes, stand-in checkpoint fitted on 4 other scenes'}
+    del fmodel, fit_batches, eval_batches, res
+
     # ---- config 4
     xyz, rgb, inst = synthetic.scene_s2(seed=1, n=args.points)
     xyz = (xyz * np.float32(40)).astype(np.float32)

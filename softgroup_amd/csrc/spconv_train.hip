@@ -17,6 +17,13 @@
 //     for its column are one 16-B read, a wave reads 1 KB fully coalesced per (slice, column block);
 //   * deep U-Net levels (few tiles) split the kernel offsets over several units; fp32 partial sums
 //     are reduced in a fixed order.
+// Tried in round 3 and not kept: a workgroup-shared variant (four consecutive tiles per workgroup
+// walking the union of their offsets in lockstep, the step's weight block fetched once per
+// workgroup and staged in LDS, double buffered, one barrier per step; gathers line-wise through a
+// swizzled LDS transpose).  Correct (tests/test_train_gpu.py green) but slower where it applies:
+// 32->32 x 124 k rows 30.6 us against 20.2 us, 64->64 x 77 k rows 48.8 against 42.5, 96->96 41.4
+// against 42.6 -- a step is only 2-6 MFMAs of 32 cycles, the barrier per step costs more than the
+// weight loads it saves (profiles/r03_train_conv_wg.txt).
 // Weight gradient: grid = (row chunks, K); a workgroup walks its chunk two rows per fp32 MFMA
 // (v_mfma_f32_32x32x2_f32: the products are exact, accumulation fp32 -- bf16 operands are widened
 // on load); every lane loads VI consecutive input channels and VO consecutive gradient channels
