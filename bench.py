@@ -260,7 +260,7 @@ def config_legs(args):
             fw.append((t1 - t0) * 1e3)
         ts, fw = sorted(ts[2:]), sorted(fw[2:])
         rec[name] = {'ms_per_step': round(ts[len(ts) // 2], 2), 'forward_ms': round(fw[len(fw) // 2], 2),
-                     'loss': round(float(loss), 4)}
+                     'loss': round(float(loss.detach()), 4)}
     legs['train_step_s3dis'] = rec
     return legs
 

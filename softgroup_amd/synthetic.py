@@ -289,10 +289,15 @@ def _lstsq_head(linear, a, target, ridge=1e-4):
     linear.bias.copy_(w[-1])
 
 
-def fit_point_heads(model, feats, semantic_labels, instance_labels, pt_offset_labels, steps=300, lr=0.02):
-    """A few hundred Adam steps on the two point-wise heads (both layers, BatchNorm in eval mode)
-    over fixed backbone features: cross-entropy on the semantic labels, L1 on the offsets of
-    instance points.  Works on any device; returns the final loss."""
+def fit_point_heads(model, feats, semantic_labels, instance_labels, pt_offset_labels, steps=300, lr=0.02,
+                    fit_offsets=False):
+    """A few hundred Adam steps on the point-wise heads (both layers, BatchNorm in eval mode) over
+    fixed backbone features: cross-entropy on the semantic labels and, with ``fit_offsets``, L1 on
+    the offsets of instance points.  By default the offset head is set to predict ZERO instead: the
+    centre of a box-shaped object is not a function of local colour / geometry, a fitted head is
+    off by ~8 cm (twice the grouping radius) and tears the surfaces apart, whereas the synthetic
+    objects are connected surfaces of one class each and cluster on their raw coordinates.
+    Works on any device; returns the final loss."""
     heads = [model.semantic_linear, model.offset_linear]
     params = [p for h in heads for p in h.parameters()]
     was = [p.requires_grad for p in params]
@@ -307,7 +312,7 @@ def fit_point_heads(model, feats, semantic_labels, instance_labels, pt_offset_la
         opt = torch.optim.Adam(params, lr=lr)
         for _ in range(steps):
             loss = torch.nn.functional.cross_entropy(model.semantic_linear(feats)[valid], semantic_labels[valid])
-            if pos.any():
+            if fit_offsets and pos.any():
                 loss = loss + (model.offset_linear(feats)[pos] - pt_offset_labels[pos]).abs().mean()
             opt.zero_grad()
             loss.backward()
@@ -315,6 +320,10 @@ def fit_point_heads(model, feats, semantic_labels, instance_labels, pt_offset_la
         for p, w in zip(params, was):
             p.requires_grad_(w)
             p.grad = None
+    if not fit_offsets:
+        with torch.no_grad():
+            model.offset_linear[-1].weight.zero_()
+            model.offset_linear[-1].bias.zero_()
     return float(loss.detach())
 
 
