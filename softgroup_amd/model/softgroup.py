@@ -134,6 +134,9 @@ class SoftGroup(nn.Module):
         initialisers): such writes do not bump the tensors' version counters, so the cached
         packed weights / BatchNorm affines would otherwise go stale.  load_state_dict, .to(),
         train()/eval() and optimizer steps are covered without it."""
+        pool = self.__dict__.get('_scan_pool')
+        if pool is not None:          # scans still in flight must not see half-replaced derived state
+            pool.shutdown(wait=True)
         spconv.invalidate_caches()
         for k in self._DERIVED:
             self.__dict__.pop(k, None)

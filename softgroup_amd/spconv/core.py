@@ -14,6 +14,7 @@ All arithmetic runs in libsoftgroup_hip.so (spconv_rulebook.hip, spconv_conv.hip
 """
 import ctypes as C
 import math
+import threading
 from collections import OrderedDict
 
 import torch
@@ -407,23 +408,31 @@ class SparseConvolution(SparseModule):
     def weight_packed(self, transposed=False, bf16=False, flip_k=False):
         w = self.weight
         key = (_CACHE_EPOCH[0], w._version, w.data_ptr(), w.device, w.dtype)
-        if self._kio_cache is None or self._kio_cache[0] != key:
-            self._kio_cache = (key, {})
-        slot = self._kio_cache[1]
+        cache = self._kio_cache
         which = (transposed, bf16, flip_k)
-        if which not in slot:
-            kvol = int(torch.tensor(self.kernel_size).prod())
-            cout, cin = self.out_channels, self.in_channels
-            pack = pack_weight_bf16 if bf16 else pack_weight
-            if not transposed:
-                slot[which] = pack(w, cout, kvol, cin, False)
-            else:
-                # w_t[k'][co][ci] = W[co][k][ci], k' = K-1-k for SubM (mirrored offset), k otherwise
-                w_t = w.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
-                if flip_k:
-                    w_t = w_t.flip(0)
-                slot[which] = pack(w_t.contiguous(), cin, kvol, cout, True)
-        return slot[which]
+        if cache is not None and cache[0] == key and which in cache[1]:
+            return cache[1][which]
+        with _CACHE_FILL_LOCK:            # a miss: pack once, publish only when the data is there
+            cache = self._kio_cache
+            if cache is None or cache[0] != key:
+                cache = (key, {})
+            slot = cache[1]
+            if which not in slot:
+                kvol = int(torch.tensor(self.kernel_size).prod())
+                cout, cin = self.out_channels, self.in_channels
+                pack = pack_weight_bf16 if bf16 else pack_weight
+                if not transposed:
+                    packed = pack(w, cout, kvol, cin, False)
+                else:
+                    # w_t[k'][co][ci] = W[co][k][ci], k' = K-1-k for SubM (mirrored offset), k otherwise
+                    w_t = w.detach().float().reshape(cout, kvol, cin).permute(1, 0, 2)
+                    if flip_k:
+                        w_t = w_t.flip(0)
+                    packed = pack(w_t.contiguous(), cin, kvol, cout, True)
+                _published(packed)
+                slot[which] = packed
+            self._kio_cache = cache
+            return slot[which]
 
     def _rule_and_plan(self, input):
         """-> (plan, out_indices, out_spatial_shape, backward-plan getter, mirrored offsets?)"""
@@ -512,6 +521,17 @@ class SparseInverseConv3d(SparseConvolution):
 
 
 # ------------------------------------------------------------------------------------------------
+_CACHE_FILL_LOCK = threading.Lock()    # cache MISSES only: scans on several streams may share modules
+
+
+def _published(*tensors):
+    """a freshly derived tensor was written on THIS thread's stream; other streams (concurrent scans,
+    model.scan_contexts > 1) read it without an event in between: finish the writes before the cache
+    entry becomes visible (once per weight version)"""
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+
+
 def _bn_affine(bn):
     """eval-mode BatchNorm1d as y = x*scale + shift; cached until any of its tensors changes"""
     tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -519,14 +539,18 @@ def _bn_affine(bn):
                                       for t in tensors)
     cache = bn.__dict__.get('_sg_affine')
     if cache is None or cache[0] != key:
-        with torch.no_grad():
-            inv = torch.rsqrt(bn.running_var.float() + bn.eps)
-            scale = inv * bn.weight.float() if bn.weight is not None else inv
-            shift = -bn.running_mean.float() * scale
-            if bn.bias is not None:
-                shift = shift + bn.bias.float()
-        cache = (key, scale.contiguous(), shift.contiguous())
-        bn.__dict__['_sg_affine'] = cache
+        with _CACHE_FILL_LOCK:
+            cache = bn.__dict__.get('_sg_affine')
+            if cache is None or cache[0] != key:
+                with torch.no_grad():
+                    inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+                    scale = inv * bn.weight.float() if bn.weight is not None else inv
+                    shift = -bn.running_mean.float() * scale
+                    if bn.bias is not None:
+                        shift = shift + bn.bias.float()
+                cache = (key, scale.contiguous(), shift.contiguous())
+                _published(cache[1])
+                bn.__dict__['_sg_affine'] = cache
     return cache[1], cache[2]
 
 
