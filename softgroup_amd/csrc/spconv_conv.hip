@@ -554,6 +554,10 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   };
 
   f32x16 acc[NBW];
+  // (Tried: a second accumulator for the second sub-slice of an item, i.e. two independent MFMA
+  // chains per wave: 2.31 against 2.28 ms per scan, not kept.  A wave alone on its SIMD spends its
+  // ~0.75 us per item on the ~200 instructions of the item -- gathers, LDS transpose, conversions,
+  // MFMAs, address arithmetic -- at one issue per 4-5 cycles, not on any single dependency chain.)
   auto compute = [&](Slice &S) {
     if constexpr (AT) {
       // rows as loaded -> LDS (row r at r * 128 B, chunk c at position c ^ ((r >> 1) & 7)), then
@@ -687,7 +691,6 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     for (int n = 0; n < NBW; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
     // ---- matrix loop over this wave's items.  S[0..DEPTH-2] already hold items 0..DEPTH-2
     //      (setup).  Past the end the last item is re-read and dropped, so every load is
     //      unconditional and the wait counts stay exact; whole groups of DEPTH items keep the loop
@@ -978,14 +981,17 @@ struct SplitVariant {
   size_t lds;
   int occ;      // resident workgroups per CU (0 = not asked yet)
 };
-#define SG_SPLIT_VARIANT(CK, WPE, NBW, WV, AT)                                                   \
-  {gather_conv_persistent_kernel<CK, 2, 0, WPE, NBW, 1, WV, AT>,                                  \
-   gather_conv_persistent_kernel<CK, 2, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
+#define SG_SPLIT_VARIANT(CK, DEPTH, WPE, NBW, WV, AT)                                            \
+  {gather_conv_persistent_kernel<CK, DEPTH, 0, WPE, NBW, 1, WV, AT>,                              \
+   gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
 static SplitVariant g_split_variants[7] = {
-    SG_SPLIT_VARIANT(32, 2, 2, 4, 1),  SG_SPLIT_VARIANT(32, 3, 1, 4, 1), SG_SPLIT_VARIANT(32, 1, 1, 8, 1),
-    SG_SPLIT_VARIANT(16, 3, 2, 4, 0),  SG_SPLIT_VARIANT(16, 4, 1, 4, 0), SG_SPLIT_VARIANT(16, 2, 1, 8, 0),
-    SG_SPLIT_VARIANT(16, 1, 1, 16, 0),
+    SG_SPLIT_VARIANT(32, 2, 2, 2, 4, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 4, 1), SG_SPLIT_VARIANT(32, 2, 1, 1, 8, 1),
+    SG_SPLIT_VARIANT(16, 2, 3, 2, 4, 0),  SG_SPLIT_VARIANT(16, 2, 4, 1, 4, 0), SG_SPLIT_VARIANT(16, 2, 2, 1, 8, 0),
+    SG_SPLIT_VARIANT(16, 2, 1, 1, 16, 0),
 };
+// (Tried for the offset-split layers, whose waves run alone on their SIMDs at 0.75 us per item: a
+// 3-deep operand ring -- 2.31 instead of 2.28 ms of conv time per scan, not kept; what such a wave
+// waits for is its own chain of dependent MFMAs and conversions, not its loads.)
 
 static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes, long long w_bytes,
                                    hipStream_t stream) {
@@ -996,13 +1002,14 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (num_cu <= 0) num_cu = 256;
-    for (SplitVariant &v : g_split_variants) {
+    auto prepare = [](SplitVariant &v) {
       v.lds = static_cast<size_t>(v.wv) * v.nbw * 16 * 64 * sizeof(float) + 2 * kMetaInts * sizeof(int32_t) + 16 +
               (v.at ? static_cast<size_t>(v.wv) * 4096 : 0);
       int o = 0;
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn, 64 * v.wv, v.lds);
       v.occ = o < 1 ? 1 : o;
-    }
+    };
+    for (SplitVariant &v : g_split_variants) prepare(v);
   });
   static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;          // developer knobs
   static const int wv_env = getenv("SG_CONV_WV") ? atoi(getenv("SG_CONV_WV")) : 0;             // force 4 / 8 / 16
