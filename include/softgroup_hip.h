@@ -310,6 +310,14 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
                               const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
                               void *ws, size_t ws_bytes, sg_stream_t stream);
 
+/* Arithmetic of the fp32 sparse convolution's products (process-wide, not thread-safe; meant for
+ * tests and A/B measurements): 1 = on the bf16 matrix pipe at fp32 accuracy (operands split three
+ * ways, six v_mfma_f32_32x32x16_bf16 per 16-channel slice, fp32 accumulation; dropped terms
+ * <= 2^-24 |a b|) -- the default; 0 = v_mfma_f32_32x32x2_f32; -1 = back to the environment
+ * (SG_CONV_SPLIT).  No counterpart in the reference: spconv 2.1 multiplies in fp32 (or fp16 under
+ * autocast). */
+int sg_spconv_set_arithmetic(int mode);
+
 /* Measurement hook (bench.py roofline): while enabled, every sg_spconv_gather_conv_f32 call -- from
  * Python or from inside sg_unet_forward -- is bracketed by a HIP event pair on its launch stream.
  * sg_spconv_profile_read waits for the events and returns the summed kernel time and the number of

@@ -934,6 +934,10 @@ struct ConvProf {
 };
 static ConvProf g_conv_prof;
 
+// arithmetic of the persistent kernel: -1 = from the environment (SG_CONV_SPLIT, default 1), 0 = fp32
+// MFMA, 1 = split-precision bf16 MFMA (sg_spconv_set_arithmetic; tests compare the two in one process)
+static int g_arith_override = -1;
+
 // Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
 // of 8 counters (one per XCD) out of a per-(device, stream) pool; the pool is cleared again, in
 // stream order, when it has been used up.  Launches on one stream run in order, so a block is
@@ -1082,6 +1086,12 @@ using namespace sg;
 
 extern "C" {
 
+int sg_spconv_set_arithmetic(int mode) {
+  SG_REQUIRE(mode >= -1 && mode <= 1, "sg_spconv_set_arithmetic: mode must be -1, 0 or 1");
+  g_arith_override = mode;
+  return SG_OK;
+}
+
 int sg_spconv_profile(int enable) {
   g_conv_prof.enabled = enable != 0;
   if (enable) g_conv_prof.used = 0;
@@ -1174,7 +1184,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   // kernel, kept for A/B)
   static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
   static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 32;
-  const bool split = persistent && split_env != 0 && Cin >= split_min_cin;
+  const int split_on = g_arith_override >= 0 ? g_arith_override : split_env;
+  const bool split = persistent && split_on != 0 && Cin >= split_min_cin;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
   static const int target_env = getenv("SG_CONV_TARGET") ? atoi(getenv("SG_CONV_TARGET")) : 0;   // developer knob
