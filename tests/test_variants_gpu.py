@@ -51,7 +51,7 @@ def run_case(cfg, batch, get_level=None, min_props=1):
     # (1) backbone + heads
     osem, ooff, ofeat = ora.point_wise(batch, x4, lvl)
     np.testing.assert_allclose(n(of), ofeat, **TOL)
-    np.testing.assert_allclose(n(sem), osem, atol=2e-3, rtol=1e-4)   # logits are O(10) here
+    np.testing.assert_allclose(n(sem), osem, **TOL)                  # (logits are O(10..100) here; measured 3e-5)
     np.testing.assert_allclose(n(off), ooff, **TOL)
     # (2) grouping on the same scores
     rp, ro = ora.grouping(n(sem), n(off), n(bi), n(cf), lvl)
