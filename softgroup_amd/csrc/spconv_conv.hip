@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) gather_conv_tile_kernel(ConvArgs p) {
 constexpr int kRowsAt = kTileRows * kMaxK, kMaskAt = kRowsAt + kTileRows;
 constexpr int kMetaInts = kMaskAt + 4;
 
-//   * WV waves per workgroup (4, 8 or 16) share a unit: the unit's items are split WV ways.  More
+//   * WV waves per workgroup (2, 4, 8 or 16) share a unit: the unit's items are split WV ways.  More
 //     waves = shorter units and more rounds of units per workgroup slot, which is what evens out
 //     layers with few units (22 649 rows x 96 columns: 2 124 units for 1 280 four-wave slots = 1.7
 //     rounds, workgroups ended between 42 k and 110 k ticks; the deep levels used to split their
@@ -325,9 +325,9 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   // (Tried: reading the weights as fp32 -- 4 B instead of the 6 B of three bf16 planes -- and
   // splitting them in registers like the activations: a third fewer weight loads, but 2.46 instead
   // of 2.28 ms of conv time per scan; the extra VALU work costs more than the loads it saves.)
-  static_assert(WV == 4 || WV == 8 || WV == 16, "4, 8 or 16 waves per workgroup");
+  static_assert(WV == 2 || WV == 4 || WV == 8 || WV == 16, "2, 4, 8 or 16 waves per workgroup");
   constexpr int RR = 16 / WV;          // accumulator registers (row groups) each wave finalises
-  constexpr int WV_SHIFT = WV == 4 ? 2 : WV == 8 ? 3 : 4;
+  constexpr int WV_SHIFT = WV == 2 ? 1 : WV == 4 ? 2 : WV == 8 ? 3 : 4;
   constexpr int HC = CK / 2;   // channels per lane per slice (8 or 16)
   constexpr int NQ = HC / 4;   // dwordx4 loads per lane per operand per slice
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -974,9 +974,10 @@ static unsigned *take_tickets(hipStream_t stream) {
 // Launch of the split-precision persistent kernel.  Decomposition: unit = (32-row tile, one or
 // two 32-column blocks, ALL offsets); the unit's items are split over the WV waves of one
 // workgroup and meet in LDS -- no partial sums through memory, no reduce kernel.  (NBW, WV) is the
-// first of (2,4) (1,4) (1,8) (1,16) that gives every workgroup slot >= 2.5 units on average, else
-// (1,16): large layers keep the gathered rows in registers for two column blocks, small layers
-// put more waves on fewer, shorter units.
+// first of (2,2) (1,2) -- >= 1.5 units per workgroup slot, K * Cin / 32 <= 108 -- then (2,4) (1,4)
+// (1,8) (1,16) -- >= 2.5 units per slot, else the last: large layers keep the gathered rows in
+// registers for two column blocks and split their few items per tile over two waves only, small
+// layers put more waves on fewer, shorter units.
 // ---------------------------------------------------------------------------------------------
 typedef void (*PersistentFn)(ConvArgs, unsigned, unsigned);
 struct SplitVariant {
@@ -988,7 +989,9 @@ struct SplitVariant {
 #define SG_SPLIT_VARIANT(CK, DEPTH, WPE, NBW, WV, AT)                                            \
   {gather_conv_persistent_kernel<CK, DEPTH, 0, WPE, NBW, 1, WV, AT>,                              \
    gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
-static SplitVariant g_split_variants[7] = {
+constexpr int kSplitVariants = 9;
+static SplitVariant g_split_variants[kSplitVariants] = {
+    SG_SPLIT_VARIANT(32, 2, 2, 2, 2, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 2, 1),
     SG_SPLIT_VARIANT(32, 2, 2, 2, 4, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 4, 1), SG_SPLIT_VARIANT(32, 2, 1, 1, 8, 1),
     SG_SPLIT_VARIANT(16, 2, 3, 2, 4, 0),  SG_SPLIT_VARIANT(16, 2, 4, 1, 4, 0), SG_SPLIT_VARIANT(16, 2, 2, 1, 8, 0),
     SG_SPLIT_VARIANT(16, 2, 1, 1, 16, 0),
@@ -1025,9 +1028,20 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
   // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units
   // (141 rows x 192 columns: 22.6 us against 42.7 us).  They run as 4-wave, one-block units.
-  for (int i = 0; i < 7; ++i) {
+  // Two-wave units.  On the big levels a mask-sorted tile holds 3-5 of the 27 offsets: split four
+  // ways that is ~1 item per wave inside a unit whose fixed cost (two barriers, LDS reduction, set-up
+  // of the next unit) is 4 k ticks (profiles/r03_conv_trace_final.txt).  Two waves per unit halve
+  // the waves that pay that cost and double the units in flight per CU: 32->32 x 124 k rows 30.8 ->
+  // 25.6 us, 96->96 x 22.6 k 66 -> 52 us, 64->64 x 76.8 k 57 -> 53 us; layers with too few units to
+  // fill the two-wave slots 1.5 times over keep four or eight waves (128->128 x 4.7 k rows: 35 -> 60 us
+  // if forced).  SG_CONV_W2_MAX = largest K * Cin / 32 (items of a full tile) they are used for.
+  static const int w2_max = getenv("SG_CONV_W2_MAX") ? atoi(getenv("SG_CONV_W2_MAX")) : 108;
+  static const float w2_rounds = getenv("SG_CONV_W2_ROUNDS") ? atof(getenv("SG_CONV_W2_ROUNDS")) : 1.5f;
+  const bool use_w2 = wv_env == 2 || (wv_env == 0 && a.K * (a.Cin / 32) <= w2_max);
+  for (int i = 0; i < kSplitVariants; ++i) {
     const SplitVariant &v = g_split_variants[i];
     if (v.at != use_at) continue;
+    if (v.wv == 2 && (!use_w2 || a.ksplit > 1)) continue;
     if (a.ksplit > 1) {
       if (v.nbw == 1 && v.wv == 4) { pick = i; break; }
       continue;
@@ -1036,7 +1050,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
     if (v.nbw == 2 && (a.Cout % 64 != 0 || nbw_env < 2)) continue;
     if (wv_env && v.wv != wv_env) continue;
     const long long units = static_cast<long long>(num_tiles) * (NB / v.nbw);
-    if (wv_env || units >= static_cast<long long>(min_rounds * num_cu * v.occ)) {
+    if (wv_env || units >= static_cast<long long>((v.wv == 2 ? w2_rounds : min_rounds) * num_cu * v.occ)) {
       pick = i;
       break;
     }
