@@ -1038,6 +1038,9 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   static const int w2_max = getenv("SG_CONV_W2_MAX") ? atoi(getenv("SG_CONV_W2_MAX")) : 108;
   static const float w2_rounds = getenv("SG_CONV_W2_ROUNDS") ? atof(getenv("SG_CONV_W2_ROUNDS")) : 1.5f;
   const bool use_w2 = wv_env == 2 || (wv_env == 0 && a.K * (a.Cin / 32) <= w2_max);
+  // (One wave per unit was measured too: the heaviest tiles -- 27 offsets in a single wave -- then
+  // set the span of the big layers, 32->32 x 124 k rows 28.5 -> 32.1 us, 64->64 x 77 k 52 -> 69 us; on
+  // the K = 8 strided / inverse convs alone it changes nothing, 2.22 ms per scan either way.)
   for (int i = 0; i < kSplitVariants; ++i) {
     const SplitVariant &v = g_split_variants[i];
     if (v.at != use_at) continue;
