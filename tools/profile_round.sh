@@ -21,9 +21,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv 49 60 > $OUT/${TAG}_kernel_top.txt 2>&1
 python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) 49 > $OUT/${TAG}_conv_by_grid.txt 2>&1
+if [ -z "$QUICK" ]; then      # QUICK=1: bench line + kernel trace only
 python $R/tools/conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
 python $R/tools/train_conv_bench.py > $OUT/${TAG}_train_conv.txt 2>/dev/null < /dev/null
 python $R/tools/train_step_bench.py 2>/dev/null < /dev/null | grep "ms/step" > $OUT/${TAG}_train_step.txt
+fi
 if [ -n "$PMC" ]; then
   rm -f $OUT/${TAG}_conv_pmc.txt $OUT/${TAG}_conv_pmc.json
   for S in "FETCH_SIZE" "WRITE_SIZE"; do
