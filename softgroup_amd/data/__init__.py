@@ -15,6 +15,7 @@ dict (keys, dtypes, values), but
 
 Every tensor of the result is already resident: ``forward_test``'s ``cuda_cast`` is a no-op.
 """
+import math
 import threading
 
 import numpy as np
@@ -79,6 +80,49 @@ def make_item(xyz, rgb, scale=50, semantic_label=None, instance_label=None, scan
             torch.from_numpy(np.ascontiguousarray(rgb)).float(), torch.from_numpy(semantic_label),
             torch.from_numpy(instance_label.astype(np.int64)), len(inst_ids), pointnum, inst_cls,
             torch.from_numpy(pt_offset))
+
+
+def scan_item(xyz, rgb, semantic_label, instance_label, scale=50, scan_id='scan', cls_shift=2):
+    """What ``CustomDataset.__getitem__`` returns for one scan at TEST time (data/custom.py:170-194
+    with ``transform_test`` :162-168), value for value and dtype for dtype:
+
+      * ``dataAugment(xyz, False, False, False, False)`` (:91-113) is NOT the identity: without
+        ``rot`` the scene is turned by the fixed 0.35 pi about z ("empirically ... match the results
+        from checkpoint"), in float64 (float32 points times a float64 matrix);
+      * voxel coordinates = trunc(xyz_middle * scale - min) as int64; ``coords_float`` stays
+        float64 here (``collate_fn`` casts it to float32, :231);
+      * ``getCroppedInstLabel`` (:136-143) closes gaps in the instance ids (the last id moves into
+        a missing one); ``getInstanceInfo`` (:75-89): per-instance mean as float32, offsets
+        ``float32 mean - float64 point``; ``instance_cls`` = semantic label of the instance's first
+        point minus ``cls_shift`` (ScanNet: 2, data/scannetv2.py:27-31; -100 stays).
+    ``semantic_label`` / ``instance_label`` as the prepared ``.pth`` files hold them (any real
+    dtype; unlabelled = -100)."""
+    theta = 0.35 * math.pi
+    m = np.matmul(np.eye(3), [[math.cos(theta), math.sin(theta), 0], [-math.sin(theta), math.cos(theta), 0],
+                              [0, 0, 1]])
+    xyz_middle = np.matmul(np.asarray(xyz), m)                       # float64
+    v = xyz_middle * scale
+    v -= v.min(0)
+    instance_label = np.array(instance_label, copy=True)
+    j = 0
+    while j < instance_label.max():                                  # getCroppedInstLabel, all points kept
+        if not (instance_label == j).any():
+            instance_label[instance_label == instance_label.max()] = j
+        j += 1
+    lab32 = instance_label.astype(np.int32)
+    n_inst = max(int(lab32.max()) + 1, 0) if lab32.size else 0
+    pt_mean = np.full((xyz_middle.shape[0], 3), -100.0, np.float32)
+    pointnum, inst_cls = [], []
+    for i in range(n_inst):
+        sel = np.where(lab32 == i)
+        pt_mean[sel] = xyz_middle[sel].mean(0)
+        pointnum.append(sel[0].size)
+        c = semantic_label[sel[0][0]]
+        inst_cls.append(c - cls_shift if c != -100 else c)
+    pt_offset = pt_mean - xyz_middle                                 # float64
+    return (scan_id, torch.from_numpy(v).long(), torch.from_numpy(xyz_middle),
+            torch.from_numpy(np.asarray(rgb)).float(), torch.from_numpy(np.asarray(semantic_label)),
+            torch.from_numpy(instance_label), n_inst, pointnum, inst_cls, torch.from_numpy(pt_offset))
 
 
 def collate_device(batch, min_spatial=128, device='cuda'):

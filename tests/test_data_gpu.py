@@ -63,3 +63,26 @@ def test_make_item_matches_make_batch_and_runs_the_model():
         a, b = model(b_dev), model(b_cpu)
     assert len(a['pred_instances']) == len(b['pred_instances']) > 0
     assert all(x['pred_mask'] == y['pred_mask'] for x, y in zip(a['pred_instances'], b['pred_instances']))
+
+
+def test_collate_device_equals_the_reference_dataset_and_collate_fn():
+    """The reference's own ``ScanNetDataset.__getitem__`` + ``collate_fn`` (run as written on two
+    synthetic scans, tests/golden/make_ref_collate.py -> ref_collate.npz; second scan with a gap in
+    its instance ids, unlabelled points, float64 labels as in the prepared files) against
+    ``data.scan_item`` + ``collate_device``: every key of the batch dict, dtype and value."""
+    from test_data_golden import GOLD, items_from_golden
+    g = np.load(GOLD)
+    batch = collate_device(items_from_golden(g))
+    torch.cuda.synchronize()
+    keys = [k[len('batch_'):] for k in g.files if k.startswith('batch_')]
+    assert set(keys) == set(batch.keys())
+    for k in keys:
+        ref, got = g['batch_' + k], batch[k]
+        if isinstance(got, torch.Tensor):
+            assert got.is_cuda, k
+            got = got.cpu().numpy()
+        got = np.asarray(got)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if ref.dtype.kind in 'fiu':
+            assert got.dtype == ref.dtype, (k, got.dtype, ref.dtype)
+        assert np.array_equal(got, ref), k
