@@ -82,33 +82,87 @@ def make_item(xyz, rgb, scale=50, semantic_label=None, instance_label=None, scan
             torch.from_numpy(pt_offset))
 
 
-def scan_item(xyz, rgb, semantic_label, instance_label, scale=50, scan_id='scan', cls_shift=2):
-    """What ``CustomDataset.__getitem__`` returns for one scan at TEST time (data/custom.py:170-194
-    with ``transform_test`` :162-168), value for value and dtype for dtype:
+def _fill_gaps(instance_label):
+    """``CustomDataset.getCroppedInstLabel`` with every point kept (data/custom.py:136-143): while an
+    id below the maximum is unused, the LAST id moves into it"""
+    instance_label = np.array(instance_label, copy=True)
+    j = 0
+    while j < instance_label.max():
+        if not (instance_label == j).any():
+            instance_label[instance_label == instance_label.max()] = j
+        j += 1
+    return instance_label
+
+
+def _rank_ids(instance_label):
+    """``KITTIDataset.getCroppedInstLabel`` (data/kitti.py:76-88): ids replaced by their rank among
+    the ids present, -100 kept (SemanticKITTI instance ids are 32-bit label words, not 0..n-1)"""
+    ids = np.unique(instance_label)
+    rank = np.cumsum(ids != -100) - 1
+    out = np.where(ids == -100, -100, rank)[np.searchsorted(ids, instance_label)]
+    # (dtype as np.vectorize infers it from the FIRST point: an unlabelled one maps to itself and
+    # keeps the input's dtype, a labelled one to a Python int)
+    keep = instance_label.size and instance_label.flat[0] == -100
+    return out.astype(instance_label.dtype if keep else np.int64)
+
+
+def kitti_labels(label, learning_map):
+    """The label decoding of ``KITTIDataset`` (data/kitti.py:30-46 and 60-70): ``label`` = the int32
+    words of a ``.label`` file, ``learning_map`` = the table of semantic-kitti.yaml.  Classes are
+    re-ordered stuff 0..10, thing 11..18, unlabelled -100; the instance label is the WHOLE word for
+    thing points and -100 for stuff points.  -> (semantic_label int64, instance_label int32)"""
+    remap = {}
+    for k, v in learning_map.items():
+        remap[k] = -100 if v == 0 else (v + 10 if v < 9 else v - 9)
+    label = np.array(label, dtype=np.int32, copy=True)
+    sem = np.vectorize(remap.__getitem__)(label & 0xFFFF)
+    label[sem <= 10] = -100
+    return sem, label
+
+
+def scan_item(xyz, rgb, semantic_label, instance_label, scale=50, scan_id='scan', cls_shift=2,
+              x4_split=False, relabel='fill_gaps'):
+    """What the reference's datasets return from ``__getitem__`` for one scan at TEST time
+    (data/custom.py:170-194 with ``transform_test`` :162-168), value for value and dtype for dtype:
 
       * ``dataAugment(xyz, False, False, False, False)`` (:91-113) is NOT the identity: without
         ``rot`` the scene is turned by the fixed 0.35 pi about z ("empirically ... match the results
         from checkpoint"), in float64 (float32 points times a float64 matrix);
       * voxel coordinates = trunc(xyz_middle * scale - min) as int64; ``coords_float`` stays
         float64 here (``collate_fn`` casts it to float32, :231);
-      * ``getCroppedInstLabel`` (:136-143) closes gaps in the instance ids (the last id moves into
-        a missing one); ``getInstanceInfo`` (:75-89): per-instance mean as float32, offsets
-        ``float32 mean - float64 point``; ``instance_cls`` = semantic label of the instance's first
-        point minus ``cls_shift`` (ScanNet: 2, data/scannetv2.py:27-31; -100 stays).
-    ``semantic_label`` / ``instance_label`` as the prepared ``.pth`` files hold them (any real
-    dtype; unlabelled = -100)."""
+      * instance ids are made dense -- ``relabel='fill_gaps'``: ``getCroppedInstLabel`` (:136-143),
+        the last id moves into a missing one; ``'rank'``: the SemanticKITTI override
+        (data/kitti.py:76-88);
+      * ``getInstanceInfo`` (:75-89): per-instance mean as float32, offsets ``float32 mean - float64
+        point``; ``instance_cls`` = semantic label of the instance's first point minus ``cls_shift``
+        (-100 stays): ScanNet 2 (data/scannetv2.py:27-31), STPLS3D 1 (data/stpls3d.py:10-15),
+        SemanticKITTI 11 (data/kitti.py:117-121), S3DIS 0;
+      * ``x4_split`` (S3DIS, data/s3dis.py:46-78): the rotated scene is cut into the four interleaved
+        sub-clouds i, i+4, ...; each is shifted to ITS OWN minimum; everything is stored piece after
+        piece and the voxel coordinates get the piece number as column 0 ([N, 4]).
+    ``semantic_label`` / ``instance_label`` as the dataset's ``load`` yields them (any real dtype;
+    unlabelled = -100)."""
     theta = 0.35 * math.pi
     m = np.matmul(np.eye(3), [[math.cos(theta), math.sin(theta), 0], [-math.sin(theta), math.cos(theta), 0],
                               [0, 0, 1]])
     xyz_middle = np.matmul(np.asarray(xyz), m)                       # float64
-    v = xyz_middle * scale
-    v -= v.min(0)
-    instance_label = np.array(instance_label, copy=True)
-    j = 0
-    while j < instance_label.max():                                  # getCroppedInstLabel, all points kept
-        if not (instance_label == j).any():
-            instance_label[instance_label == instance_label.max()] = j
-        j += 1
+    rgb, semantic_label, instance_label = np.asarray(rgb), np.asarray(semantic_label), np.asarray(instance_label)
+    if x4_split:
+        pieces = [np.arange(i, xyz_middle.shape[0], 4) for i in range(4)]
+        vs = []
+        for b, piece in enumerate(pieces):
+            vp = xyz_middle[piece] * scale
+            vp -= vp.min(0)
+            vs.append(np.concatenate([np.full((vp.shape[0], 1), b), vp], 1))
+        v = np.concatenate(vs, 0)
+        order = np.concatenate(pieces)
+        xyz_middle, rgb = xyz_middle[order], rgb[order]
+        semantic_label, instance_label = semantic_label[order], instance_label[order]
+    else:
+        v = xyz_middle * scale
+        v -= v.min(0)
+    assert relabel in ('fill_gaps', 'rank')
+    instance_label = _fill_gaps(instance_label) if relabel == 'fill_gaps' else _rank_ids(instance_label)
     lab32 = instance_label.astype(np.int32)
     n_inst = max(int(lab32.max()) + 1, 0) if lab32.size else 0
     pt_mean = np.full((xyz_middle.shape[0], 3), -100.0, np.float32)
@@ -118,11 +172,38 @@ def scan_item(xyz, rgb, semantic_label, instance_label, scale=50, scan_id='scan'
         pt_mean[sel] = xyz_middle[sel].mean(0)
         pointnum.append(sel[0].size)
         c = semantic_label[sel[0][0]]
-        inst_cls.append(c - cls_shift if c != -100 else c)
+        inst_cls.append(c - cls_shift if (cls_shift and c != -100) else c)
     pt_offset = pt_mean - xyz_middle                                 # float64
     return (scan_id, torch.from_numpy(v).long(), torch.from_numpy(xyz_middle),
-            torch.from_numpy(np.asarray(rgb)).float(), torch.from_numpy(np.asarray(semantic_label)),
+            torch.from_numpy(rgb).float(), torch.from_numpy(semantic_label),
             torch.from_numpy(instance_label), n_inst, pointnum, inst_cls, torch.from_numpy(pt_offset))
+
+
+def collate_x4_device(batch, min_spatial=128, device='cuda'):
+    """Device-side version of the S3DIS test-time ``collate_fn`` (data/s3dis.py:80-115): ONE scan
+    whose item already carries the four sub-clouds (``scan_item(..., x4_split=True)``).  Same dict:
+    no ``coords`` key, ``batch_idxs`` all zero, ``batch_size`` 4, the instance lists wrapped in one
+    more dimension -- quirks included, ``forward_test`` (x4_split) expects exactly this."""
+    (scan_id, coord, coord_float, feat, semantic_label, instance_label, inst_num, inst_pointnum,
+     inst_cls, pt_offset_label) = batch[0]
+    dev = torch.device(device)
+    d_coords = _to_device('coords', [coord], torch.int64, dev)
+    out = {
+        'scan_ids': [scan_id],
+        'batch_idxs': torch.zeros(coord.shape[0], dtype=torch.int32, device=dev),
+        'coords_float': _to_device('coords_float', [coord_float], torch.float32, dev),
+        'feats': _to_device('feats', [feat], torch.float32, dev),
+        'semantic_labels': _to_device('semantic_labels', [semantic_label], torch.int64, dev),
+        'instance_labels': _to_device('instance_labels', [instance_label], torch.int64, dev),
+        'instance_pointnum': torch.tensor([inst_pointnum], dtype=torch.int).to(dev, non_blocking=True),
+        'instance_cls': torch.tensor([inst_cls], dtype=torch.long).to(dev, non_blocking=True),
+        'pt_offset_labels': _to_device('pt_offset_labels', [pt_offset_label], torch.float32, dev),
+        'spatial_shape': np.clip(coord.numpy().max(0)[1:] + 1, min_spatial, None),
+        'batch_size': 4,
+    }
+    voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(d_coords, 4)
+    out.update(voxel_coords=voxel_coords, v2p_map=v2p_map, p2v_map=p2v_map)
+    return out
 
 
 def collate_device(batch, min_spatial=128, device='cuda'):

@@ -86,3 +86,27 @@ def test_collate_device_equals_the_reference_dataset_and_collate_fn():
         if ref.dtype.kind in 'fiu':
             assert got.dtype == ref.dtype, (k, got.dtype, ref.dtype)
         assert np.array_equal(got, ref), k
+
+
+def test_collate_x4_device_equals_the_reference_s3dis_test_collate():
+    """S3DIS at test time (x4_split): the reference's ``S3DISDataset.collate_fn`` branch for one scan
+    whose item holds four interleaved sub-clouds (golden ref_collate_variants.npz) against
+    ``scan_item(x4_split=True)`` + ``collate_x4_device`` -- every key, dtype and value, quirks
+    included (no ``coords``, ``batch_idxs`` all zero, instance lists with a leading dimension)."""
+    from softgroup_amd.data import collate_x4_device
+    from test_data_golden import VARIANTS, variant_item
+    g = np.load(VARIANTS)
+    batch = collate_x4_device([variant_item(g, 's3dis')])
+    torch.cuda.synchronize()
+    keys = [k[len('s3dis_batch_'):] for k in g.files if k.startswith('s3dis_batch_')]
+    assert set(keys) == set(batch.keys())
+    for k in keys:
+        ref, got = g['s3dis_batch_' + k], batch[k]
+        if isinstance(got, torch.Tensor):
+            assert got.is_cuda, k
+            got = got.cpu().numpy()
+        got = np.asarray(got)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if ref.dtype.kind in 'fiu':
+            assert got.dtype == ref.dtype, (k, got.dtype, ref.dtype)
+        assert np.array_equal(got, ref), k
