@@ -1036,6 +1036,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   // fill the two-wave slots 1.5 times over keep four or eight waves (128->128 x 4.7 k rows: 35 -> 60 us
   // if forced).  SG_CONV_W2_MAX = largest K * Cin / 32 (items of a full tile) they are used for.
   static const int w2_max = getenv("SG_CONV_W2_MAX") ? atoi(getenv("SG_CONV_W2_MAX")) : 108;
+  static const int w2_nbw = getenv("SG_CONV_W2_NBW") ? atoi(getenv("SG_CONV_W2_NBW")) : 2;      // A/B knob
   static const float w2_rounds = getenv("SG_CONV_W2_ROUNDS") ? atof(getenv("SG_CONV_W2_ROUNDS")) : 1.5f;
   const bool use_w2 = wv_env == 2 || (wv_env == 0 && a.K * (a.Cin / 32) <= w2_max);
   // (One wave per unit was measured too: the heaviest tiles -- 27 offsets in a single wave -- then
@@ -1044,7 +1045,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   for (int i = 0; i < kSplitVariants; ++i) {
     const SplitVariant &v = g_split_variants[i];
     if (v.at != use_at) continue;
-    if (v.wv == 2 && (!use_w2 || a.ksplit > 1)) continue;
+    if (v.wv == 2 && (!use_w2 || a.ksplit > 1 || v.nbw > w2_nbw)) continue;
     if (a.ksplit > 1) {
       if (v.nbw == 1 && v.wv == 4) { pick = i; break; }
       continue;
