@@ -19,6 +19,7 @@ class Spy(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.cnt = collections.Counter()
+        self.bytes = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.__name__.split('.')[0]
@@ -29,6 +30,10 @@ class Spy(TorchDispatchMode):
                     where = f'{f.filename.split("softgroup_amd/")[-1]}:{f.lineno}'
                     break
             self.cnt[(where, name)] += 1
+            out = func(*args, **(kwargs or {}))
+            if isinstance(out, torch.Tensor):
+                self.bytes[(where, name)] += out.numel() * out.element_size()
+            return out
         return func(*args, **(kwargs or {}))
 
 
@@ -46,7 +51,7 @@ def main():
             model(batch)
             torch.cuda.synchronize()
     for (where, n), c in sorted(spy.cnt.items()):
-        print(f'{c:3d} {n:22s} {where}')
+        print(f'{c:3d} {n:22s} {spy.bytes[(where, n)] / 1e6:9.2f} MB  {where}')
 
 
 if __name__ == '__main__':
