@@ -318,6 +318,13 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
  * autocast). */
 int sg_spconv_set_arithmetic(int mode);
 
+/* Where the partial sums of a layer whose kernel offsets are split over several workgroups (layers
+ * with few output rows) are added up (process-wide, not thread-safe; tests and A/B measurements):
+ * 0 = by a second kernel (conv_reduce_kernel) -- the default; 1 = inside the launch, by the last
+ * workgroup to arrive at each (tile, column unit), in the same fixed order (identical results);
+ * -1 = back to the environment (SG_CONV_COMBINE). */
+int sg_spconv_set_combine(int mode);
+
 /* Measurement hook (bench.py roofline): while enabled, every sg_spconv_gather_conv_f32 call -- from
  * Python or from inside sg_unet_forward -- is bracketed by a HIP event pair on its launch stream.
  * sg_spconv_profile_read waits for the events and returns the summed kernel time and the number of

@@ -58,6 +58,7 @@ SIGNATURES = {
     'sg_spconv_plan_workspace_bytes': (_sz, [_i]),
     'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_set_arithmetic': (_i, [_i]),
+    'sg_spconv_set_combine': (_i, [_i]),
     'sg_spconv_profile': (_i, [_i]),
     'sg_spconv_profile_read': (_i, [_vp, _vp]),
     'sg_unet_arena_bytes': (_sz, [_vp, _i]),

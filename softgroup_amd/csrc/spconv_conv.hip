@@ -125,6 +125,10 @@ struct ConvArgs {
   unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per
                                // XCD, 128 B apart), or null = static hand-out
   unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
+  // persistent kernel, ksplit > 1, in-launch combine (else null): zeroed arrival counters, one per
+  // (tile, column unit), and the real output (`out` then holds the partial sums)
+  unsigned *done;
+  float *out_final;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -349,6 +353,14 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   const bool add_res = p.residual != nullptr && final_out;
   const bool post = p.post_scale != nullptr && final_out;
   const bool act = p.out_act != nullptr && final_out;
+  // In-launch combine of the offset-split partial sums (ksplit > 1 and p.done): every unit stores
+  // its partial tile write-through, then its workgroup draws from the (tile, column unit) counter;
+  // the workgroup that draws ksplit - 1 adds the partial tiles in the fixed order 0 .. ksplit-1,
+  // applies the epilogue and writes the output -- the same numbers as conv_reduce_kernel, without
+  // its launch.  Hand-off as cdna_hip_programming.md prescribes for a split-K reducer: sc1 stores,
+  // every wave drains them, workgroup barrier, ONE relaxed agent-scope fetch_add, sc1 loads by the
+  // reducer; correct wherever the units of a tile run.
+  const bool combine = p.done != nullptr && !final_out;
   const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
   const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;
 
@@ -362,6 +374,14 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
       p.out, 0, out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
       act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
+  // the reducer's operands (zero-sized unless this launch combines)
+  const bool c_res = combine && p.residual != nullptr, c_act = combine && p.out_act != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_cres = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(c_res ? p.residual : p.in), 0, c_res ? out_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cout = __builtin_amdgcn_make_buffer_rsrc(
+      combine ? p.out_final : p.out, 0, combine ? out_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cact = __builtin_amdgcn_make_buffer_rsrc(
+      c_act ? p.out_act : p.out, 0, c_act ? out_bytes : 0u, 0x00020000);
 
   // x / d for the few small wave-uniform divisors of the unit arithmetic: one s_mul_hi with a
   // host-made reciprocal (exact for x * d < 2^32; magic 0 means d == 1)
@@ -418,6 +438,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     const int32_t *meta;   // LDS block of the unit
     uint32_t wg_mask;
     int col, ks, k, s, kp, sp, rem;   // (k, s) first item, (kp, sp) last item requested
+    int pair;              // tile * col_units + column unit (arrival counter of the in-launch combine)
     int v_w;
     float ps[NBW], pb[NBW], as[NBW], ab[NBW];
     unsigned o_off[RR];    // byte offsets of the output rows this lane stores (kOob: padding row)
@@ -493,6 +514,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   // residual rows and the epilogue constants.  Needs the unit's metadata in LDS.
   auto setup = [&](const Unit &d, int buf, Ctx &c) {
     c.ks = d.ks;
+    c.pair = d.tile * p.col_units + d.cu;
     c.meta = meta_lds + buf * kMetaInts;
     uint32_t m = static_cast<uint32_t>(c.meta[kMaskAt]);
     if (!final_out) {
@@ -777,14 +799,24 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     }
     const unsigned o_base = final_out ? 0u : static_cast<unsigned>(c.ks) * out_bytes;
     const int rem_done = c.rem;
+    const int pair_done = c.pair, col_done = c.col;
     setup(dn, has_next ? (buf ^ 1) : buf, c);
     mark(4);
+    if (combine) {      // uniform: partial tile, write-through (visible to whichever workgroup reduces)
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
+                                                o_base + n * 128, 16);
+    } else {
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
                                               o_base + n * 128, 0);
+    }
     if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr)
@@ -792,6 +824,84 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
         for (int n = 0; n < NBW; ++n)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[n][rr]), rs_act, o_off[rr],
                                                 n * 128, 0);
+    }
+    if (combine) {      // uniform
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial stores are out
+      barrier();
+      if (wave == 0 && lane == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(p.done + pair_done, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+        ctl[3] = arrived == static_cast<unsigned>(p.ksplit - 1);
+      }
+      barrier();
+      if (__builtin_amdgcn_readfirstlane(ctl[3]) != 0) {         // this workgroup reduces the tile
+        const int colc = min(col_done, p.Cout - 1);
+        float ps[NBW], pb[NBW], as[NBW], ab[NBW];
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          ps[n] = pb[n] = as[n] = ab[n] = 0.f;
+          if (p.post_scale) { ps[n] = p.post_scale[colc + 32 * n]; pb[n] = p.post_shift[colc + 32 * n]; }
+          if (c_act) { as[n] = p.act_scale[colc + 32 * n]; ab[n] = p.act_shift[colc + 32 * n]; }
+        }
+        // partial tiles 0 .. ksplit-1 in that order (what conv_reduce_kernel does), four at a time in
+        // flight; sc1 loads: served past this CU's L1 and this XCD's L2 lines of other XCDs' data
+        auto part = [&](int ks, int rr, int n) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rs_out, o_off[rr], static_cast<unsigned>(ks) * out_bytes + n * 128, 16));
+        };
+        float t[NBW][RR];
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+          for (int n = 0; n < NBW; ++n) t[n][rr] = part(0, rr, n);
+        int ks = 1;
+        for (; ks + 3 < p.ksplit; ks += 4) {
+          float q[4][NBW][RR];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+              for (int n = 0; n < NBW; ++n) q[j][n][rr] = part(ks + j, rr, n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+              for (int n = 0; n < NBW; ++n) t[n][rr] += q[j][n][rr];
+        }
+        for (; ks < p.ksplit; ++ks) {
+          float q[NBW][RR];
+#pragma unroll
+          for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) q[n][rr] = part(ks, rr, n);
+#pragma unroll
+          for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) t[n][rr] += q[n][rr];
+        }
+        float res[NBW][RR];     // (a zero-sized descriptor without a residual: + 0)
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+          for (int n = 0; n < NBW; ++n)
+            res[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cres, o_off[rr], n * 128, 0));
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+          for (int n = 0; n < NBW; ++n) {
+            float x = t[n][rr] + res[n][rr];
+            if (p.post_scale) x = fmaxf(fmaf(x, ps[n], pb[n]), 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs_cout, o_off[rr], n * 128, 0);
+            // (a zero-sized descriptor without a second output: the store is dropped)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(x, as[n], ab[n]), 0.f)),
+                                                  rs_cact, o_off[rr], n * 128, 0);
+          }
+        // counter back to zero for the next launch on this stream (nobody else touches it any more)
+        if (wave == 0 && lane == 0)
+          __hip_atomic_store(p.done + pair_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     mark(5);
     if constexpr (TRACE) {
@@ -937,6 +1047,7 @@ static ConvProf g_conv_prof;
 // arithmetic of the persistent kernel: -1 = from the environment (SG_CONV_SPLIT, default 1), 0 = fp32
 // MFMA, 1 = split-precision bf16 MFMA (sg_spconv_set_arithmetic; tests compare the two in one process)
 static int g_arith_override = -1;
+static int g_combine_override = -1;   // in-launch combine of offset-split layers: -1 = SG_CONV_COMBINE (default 0)
 
 // Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
 // of 8 counters (one per XCD) out of a per-(device, stream) pool; the pool is cleared again, in
@@ -952,6 +1063,27 @@ constexpr size_t kTicketBlockBytes = 8 * kTicketStride * sizeof(unsigned);
 constexpr size_t kTicketBlocks = 1 << 12;     // x 1 KB = 4 MB per stream
 static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, TicketPool> g_ticket_pools;
+
+// Arrival counters of the in-launch combine: one zeroed block per (device, stream), used by every
+// launch on that stream in turn (the reducing workgroup puts its counter back to zero, and launches
+// of one stream do not overlap).
+constexpr int kDoneCounters = 4096;
+static std::map<std::pair<int, hipStream_t>, unsigned *> g_done_pools;
+
+static unsigned *take_done(hipStream_t stream) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_ticket_mu);
+  unsigned *&slot = g_done_pools[{dev, stream}];
+  if (slot == nullptr) {
+    if (hipMalloc(&slot, kDoneCounters * sizeof(unsigned)) != hipSuccess) {
+      slot = nullptr;
+      return nullptr;
+    }
+    hipMemsetAsync(slot, 0, kDoneCounters * sizeof(unsigned), stream);
+  }
+  return slot;
+}
 
 static unsigned *take_tickets(hipStream_t stream) {
   int dev = 0;
@@ -1110,6 +1242,12 @@ int sg_spconv_set_arithmetic(int mode) {
   return SG_OK;
 }
 
+int sg_spconv_set_combine(int mode) {
+  SG_REQUIRE(mode >= -1 && mode <= 1, "sg_spconv_set_combine: mode must be -1, 0 or 1");
+  g_combine_override = mode;
+  return SG_OK;
+}
+
 int sg_spconv_profile(int enable) {
   g_conv_prof.enabled = enable != 0;
   if (enable) g_conv_prof.used = 0;
@@ -1243,6 +1381,15 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
   a.trace = nullptr;
   a.queue = nullptr;
+  // offset-split layers of the persistent kernel: partial sums combined inside the launch by the last
+  // workgroup of each (tile, column unit) instead of by conv_reduce_kernel (SG_CONV_COMBINE=1; off by
+  // default until it has been through the whole GPU suite)
+  static const int combine_env = getenv("SG_CONV_COMBINE") ? atoi(getenv("SG_CONV_COMBINE")) : 0;
+  a.done = nullptr;
+  a.out_final = out;
+  if ((g_combine_override >= 0 ? g_combine_override : combine_env) != 0 && persistent && ksplit > 1 &&
+      static_cast<long long>(num_tiles) * col_units <= kDoneCounters)
+    a.done = take_done(stream);
   const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
   a.num_units = static_cast<int>(units);
   auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
@@ -1341,7 +1488,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
       default: launch_tile<4>(a, grid, lds, vec, stream); break;
     }
   }
-  if (ksplit > 1) {
+  if (ksplit > 1 && a.done == nullptr) {
     const long long n4 = static_cast<long long>(M_out) * Cout / 4;
     conv_reduce_kernel<<<grid_for(n4, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4 *>(ws), reinterpret_cast<const float4 *>(residual), post_scale,

@@ -477,3 +477,60 @@ def test_unet_executor_degenerate_sizes(n, shape):
         ref = out_layer(unet(inp(x))).features
     assert torch.isfinite(got).all()
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('cin,cout,n,split', [(128, 96, 300, 1), (192, 192, 141, 1), (224, 224, 18, 1),
+                                              (160, 160, 755, 1), (64, 64, 1500, 1), (64, 64, 1500, 0)])
+def test_in_launch_combine_equals_the_reduce_kernel(cin, cout, n, split):
+    """Layers with few output rows split their kernel offsets over several workgroups; the partial
+    sums are added by conv_reduce_kernel (default) or inside the launch by the last workgroup to
+    arrive at each tile (sg_spconv_set_combine(1): write-through partial stores, one agent-scope
+    counter per tile, sc1 loads).  Same fixed order, so the outputs must be IDENTICAL -- with every
+    epilogue at once and without any, over repeated launches on the same stream (the counters are
+    reused; a stale one would drop or double a tile), for both arithmetics."""
+    from softgroup_amd import _lib as L
+    rng = np.random.default_rng(cin + cout + n)
+    shape = [24, 24, 16]
+    idx = _scene(rng, n, shape)
+    M = len(idx)
+    plan = core.SubMRule(t(idx), shape).plan
+    w = torch.randn(cout, 27, cin, device=DEV) * 0.1
+    w_k8 = core.pack_weight(w, cout, 27, cin, False)
+    res = torch.randn(M, cout, device=DEV)
+    ps, pb = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    as_, ab = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    lib = L.lib()
+    nb = lib.sg_spconv_conv_workspace_bytes(M, cout)
+    assert nb > 256, 'shape does not take the offset-split path'
+    ws = L.workspace(nb, DEV)
+    null = None
+
+    def run(f, epilogue):
+        out = torch.full((M, cout), float('nan'), device=DEV)
+        out_act = torch.full((M, cout), float('nan'), device=DEV)
+        args = (L.ptr(ps), L.ptr(pb), L.ptr(res), L.ptr(as_), L.ptr(ab), L.ptr(out_act)) if epilogue \
+            else (null, null, null, null, null, null)
+        L.check(lib.sg_spconv_gather_conv_f32(
+            L.ptr(f), M, L.ptr(plan.nbr), M, 27, cin, cout, L.ptr(w_k8), *args, L.ptr(plan.order),
+            L.ptr(plan.tile_mask), L.ptr(plan.nbr_tiles), L.ptr(out), L.ptr(ws), nb, L.stream()),
+            'sg_spconv_gather_conv_f32')
+        return out, out_act
+
+    feats = [torch.randn(M, cin, device=DEV) for _ in range(3)]
+    try:
+        L.check(lib.sg_spconv_set_arithmetic(split), 'sg_spconv_set_arithmetic')
+        outs = {}
+        for mode in (0, 1):
+            L.check(lib.sg_spconv_set_combine(mode), 'sg_spconv_set_combine')
+            outs[mode] = [run(f, ep) for f in feats for ep in (True, False)] * 1
+            outs[mode] += [run(feats[0], True)]          # and once more on the reused counters
+    finally:
+        lib.sg_spconv_set_combine(-1)
+        lib.sg_spconv_set_arithmetic(-1)
+    for (a, a_act), (b, b_act) in zip(outs[0], outs[1]):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b), (a - b).abs().max().item()
+        if torch.isfinite(a_act).all():
+            assert torch.equal(a_act, b_act)
+        else:
+            assert torch.isnan(b_act).all()              # no second output asked: left untouched
