@@ -42,6 +42,11 @@ def main():
         done += 1
         if done != 2:
             continue
+        # the split-precision path stores its waves-per-unit where the fp32 path stores ksplit; units of
+        # fewer than four waves leave the other slots zero: keep the waves that stamped something
+        live = int((rec[:, :, 0] != 0).any(0).sum()) if rec.size else 4
+        if 0 < live < 4:
+            rec = rec[:, :live]
         t = rec[:, :, :6].astype(np.int64)
         wgid = rec[:, 0, 6].astype(np.int64)
         meta = rec[:, :, 7]
