@@ -44,6 +44,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 REF_MS_PER_SCAN = 288.0       # reference README.md:22, 1x Titan X, real ScanNet v2
 
 
@@ -93,15 +94,16 @@ def device_identity(stub, rank):
     return f'index={torch.cuda.current_device()}'
 
 
-def stage_times(model, batch, reps=5):
-    """HIP-event timing of the forward's stages on the current stream (orientation only)."""
+def stage_times(model, batch, reps=5, warm=1):
+    """HIP-event timing of the forward's stages on the current stream (orientation only); `warm`
+    untimed passes first (allocator, plan caches), then the mean of `reps`."""
     from softgroup_amd import ops
     import softgroup_amd.spconv.pytorch as spconv
     names = ['voxelize+backbone+heads', 'grouping', 'proposal_voxelization', 'tiny_unet+heads',
              'instances+rle']
     acc = [0.0] * len(names)
     b = batch
-    for _ in range(reps):
+    for it in range(warm + reps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         with torch.no_grad():
             ev[0].record()
@@ -120,6 +122,8 @@ def stage_times(model, batch, reps=5):
             preds = model.get_instances('s', pidx, sem, cls_s, iou_s, mask_s)
             ev[5].record()
         torch.cuda.synchronize()
+        if it < warm:
+            continue
         for i in range(len(names)):
             acc[i] += ev[i].elapsed_time(ev[i + 1]) / reps
     info = dict(points=int(b['coords_float'].shape[0]), voxels=int(b['voxel_coords'].shape[0]),
@@ -175,7 +179,7 @@ def config_legs(args):
                 model(batch)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / 5 * 1e3
-            stages, info = stage_times(model, batch, reps=2)
+            stages, info = stage_times(model, batch, reps=5)
         return {'ms_per_scan_unpipelined': round(ms, 3), 'stages_ms': stages, 'scene': info}
 
     # ---- config 2 again, but with a stand-in for a TRAINED checkpoint (synthetic.fit_model_to_scenes:
@@ -201,7 +205,7 @@ def config_legs(args):
                 fmodel(b)
         torch.cuda.synchronize()
         fitted_ms = (time.perf_counter() - t0) / (3 * len(eval_batches)) * 1e3
-        fstages, finfo = stage_times(fmodel, eval_batches[0], reps=2)
+        fstages, finfo = stage_times(fmodel, eval_batches[0], reps=5)
     classes = ['c%d' % i for i in range(18)]
     avgs = ScanNetEval(classes).evaluate([r['pred_instances'] for r in res], [r['gt_instances'] for r in res],
                                          verbose=False)
@@ -316,7 +320,7 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
             model(dbatch)
         torch.cuda.synchronize()
         dense_ms = (time.perf_counter() - t0) / 5 * 1e3
-        dstages, dinfo = stage_times(model, dbatch, reps=2)
+        dstages, dinfo = stage_times(model, dbatch, reps=5)
     model.async_results = True
     legs['dense_scene'] = {'ms_per_scan_unpipelined': round(dense_ms, 3), 'stages_ms': dstages,
                            'scene': dinfo}
@@ -607,7 +611,7 @@ def main():
         # which committed counter file the figure comes from and which FETCH_SIZE factor was applied.
         traffic, traffic_source = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for fn in ('r03_conv_pmc.json', 'r02_conv_pmc.json', 'r01_conv_pmc.json'):
+        for fn in ('r04_conv_pmc.json', 'r03_conv_pmc.json', 'r02_conv_pmc.json', 'r01_conv_pmc.json'):
             try:
                 rec = json.load(open(os.path.join(here, 'profiles', fn)))
                 pmc = rec['counters']
@@ -624,16 +628,25 @@ def main():
                'frac': round(gbps / HBM_PEAK_GBPS, 4)}
         mfma = {'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
-        # the roof that actually binds is the one with the larger fraction (fp32 MFMA for this
-        # kernel: AI = 2*Cout/4.25 flop/B of gathered data); the other one is kept alongside
-        bound = 'mfma' if mfma['frac'] >= hbm['frac'] else 'hbm'
+        # Which roof binds: the kernel is priced against the pipe it ISSUES on.  With split-precision
+        # products (the default) every algorithmic fp32 flop is six bf16 MFMA flops, so the matrix
+        # roof is 2500 / 6 = 416.7 TFLOP/s-equivalent and its time floor (flops / that) is below the
+        # HBM floor (B_gs / 8 TB/s): the binding roof is HBM.  With SG_CONV_SPLIT=0 the kernel issues
+        # fp32 MFMAs and is priced against 157.3 TFLOP/s.  The fp32-MFMA-equivalent rate stays in the
+        # line as `mfma_fp32_equivalent` (the series of rounds 1-3).
+        split_on = os.environ.get('SG_CONV_SPLIT', '1') != '0'
+        issued = ({'achieved': round(6 * tflops, 1), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                   'frac': round(6 * tflops / BF16_MFMA_PEAK_TFLOPS, 4),
+                   'note': 'six bf16 MFMA flops are issued per algorithmic fp32 flop'} if split_on else mfma)
+        bound = 'mfma' if issued['frac'] >= hbm['frac'] else 'hbm'
+        bound_rec = hbm if bound == 'hbm' else {k: issued[k] for k in ('achieved', 'peak', 'unit', 'frac')}
         out['roofline'] = {
             'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv; fp32 products as six '
-                      'bf16 MFMAs on split operands, fp32 accumulate; priced against the fp32-MFMA peak)',
-            'bf16_mfma_issued': {'achieved': round(6 * tflops, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                 'frac': round(6 * tflops / 2500.0, 4),
-                                 'note': 'six bf16 MFMA flops are issued per algorithmic fp32 flop'},
-            'bound': bound, **(mfma if bound == 'mfma' else hbm),
+                      'bf16 MFMAs on split operands, fp32 accumulate; bound = the larger of B_gs / 8 TB/s and '
+                      'issued MFMA flops / the peak of the pipe they issue on)',
+            'mfma_issued': issued,
+            'mfma_fp32_equivalent': mfma,
+            'bound': bound, **bound_rec,
             'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_scan': s['launches'] // n_pass,
             'kernel_ms_per_scan': round(s['ms'] / n_pass, 3),
@@ -642,7 +655,7 @@ def main():
             'algorithmic_flops_per_launch': s['flops'] // launches,
             'algorithmic_bytes_per_scan': s['bytes'] // n_pass,
             'flops_per_scan': s['flops'] // n_pass,
-            'hbm': hbm, 'mfma': mfma,
+            'hbm': hbm,
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

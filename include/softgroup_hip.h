@@ -282,8 +282,15 @@ int sg_spconv_pyramid_build(const int32_t *indices, int num_rows, const int32_t 
 
 /* Weight packing for the conv kernel: src [Cout, K, Cin] (spconv "OKKKI", the checkpoint layout,
  * tools/convert_checkpoint.py:17-19; src_is_kio = 0) or [K, Cin, Cout] (src_is_kio = 1) ->
- * "k8" [K][ceil(Cin/8)][Cout][8], zero padded: the 8 reduction steps one lane feeds to 8 consecutive
- * MFMAs are one 32-B read.  w_k8 holds sg_spconv_packed_weight_elems(kvol, cin, cout) floats. */
+ * "k8" [K][ceil(Cin/8)][Cout][8] fp32, zero padded (the 8 reduction steps one lane feeds to 8
+ * consecutive MFMAs are one 32-B read), FOLLOWED IN THE SAME BUFFER by the same elements as three
+ * bf16 planes h, m, l (w = h + m + l, round to nearest even; 2 bytes per element each) for the
+ * split-precision kernel.  The buffer is 2.5x the fp32 block: it MUST be sized with
+ * sg_spconv_packed_weight_elems(kvol, cin, cout) (in floats) and filled by sg_spconv_pack_weight --
+ * sg_spconv_gather_conv_f32 builds its weight descriptor over that full size and, on the default
+ * split path, reads the planes.  Non-finite weights: h carries the Inf/NaN, m and l are NaN-free
+ * only for finite values (x - Inf = NaN); a diverged model shows NaN where the fp32-MFMA kernel
+ * (sg_spconv_set_arithmetic(0)) would show Inf. */
 size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout);
 int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
                           sg_stream_t stream);
@@ -315,14 +322,16 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
  * ways, six v_mfma_f32_32x32x16_bf16 per 16-channel slice, fp32 accumulation; dropped terms
  * <= 2^-24 |a b|) -- the default; 0 = v_mfma_f32_32x32x2_f32; -1 = back to the environment
  * (SG_CONV_SPLIT).  No counterpart in the reference: spconv 2.1 multiplies in fp32 (or fp16 under
- * autocast). */
+ * autocast).  Edge behaviour of mode 1: an activation that is Inf, NaN or above the bf16 maximum
+ * (3.39e38) yields NaN in every output it touches (x - bf16(x) is Inf - Inf), where fp32 products
+ * would give Inf; finite inputs below that are unaffected. */
 int sg_spconv_set_arithmetic(int mode);
 
 /* Where the partial sums of a layer whose kernel offsets are split over several workgroups (layers
  * with few output rows) are added up (process-wide, not thread-safe; tests and A/B measurements):
- * 0 = by a second kernel (conv_reduce_kernel) -- the default; 1 = inside the launch, by the last
- * workgroup to arrive at each (tile, column unit), in the same fixed order (identical results);
- * -1 = back to the environment (SG_CONV_COMBINE). */
+ * 1 = inside the launch, by the last workgroup to arrive at each (tile, column unit), partial tiles
+ * added in the fixed order 0 .. ksplit-1 -- the default; 0 = by a second kernel (conv_reduce_kernel),
+ * same order, identical results; -1 = back to the environment (SG_CONV_COMBINE). */
 int sg_spconv_set_combine(int mode);
 
 /* Measurement hook (bench.py roofline): while enabled, every sg_spconv_gather_conv_f32 call -- from
@@ -393,6 +402,10 @@ typedef struct sg_unet_desc {
   int input_cin;
   const float *input_w;              /* SubMConv3d(input_cin, planes[0]) before the UBlock, or NULL */
   const float *out_bn_scale, *out_bn_shift;   /* BatchNorm1d + ReLU after the UBlock, or NULL */
+  int input_cin_packed;              /* Cin `input_w` was packed for: 0 or input_cin = as is; a larger
+                                        multiple of 16 (weights zero-padded along Cin before packing)
+                                        makes the executor convolve a zero-padded copy of the features
+                                        on the persistent MFMA kernel instead of the general one */
 } sg_unet_desc;
 /* upper bound of the arena sg_unet_forward needs for num_rows input voxels */
 size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);

@@ -30,6 +30,7 @@
 // gather/scatter bytes B_gs of SURVEY 8(d); the weights (<= 8 MB) are served from L2/MALL.
 #include <stdlib.h>
 
+#include <atomic>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -125,8 +126,8 @@ struct ConvArgs {
   unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per
                                // XCD, 128 B apart), or null = static hand-out
   unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
-  // persistent kernel, ksplit > 1, in-launch combine (else null): zeroed arrival counters, one per
-  // (tile, column unit), and the real output (`out` then holds the partial sums)
+  // persistent kernel, ksplit > 1, in-launch combine (else null): zeroed arrival counters of THIS
+  // launch, one per (tile, column unit), and the real output (`out` then holds the partial sums)
   unsigned *done;
   float *out_final;
 };
@@ -657,9 +658,10 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter();
   };
 
-  // ---- work distribution.  The unit list is heaviest-first.  Rounds 0 and 1 are static (round 0
-  //      forward, round 1 reversed: one heavy + one light unit each); from round 2 on the units are
-  //      HANDED OUT: one ticket counter per XCD (unit u always runs on XCD u % 8, so the column
+  // ---- work distribution.  The unit list is heaviest-first.  Default: the static snake (round r
+  //      forward or reversed after the Thue-Morse word) all the way.  Optional (p.queue != null,
+  //      SG_CONV_STATIC=0; measured neutral, profiles/r03_conv_experiments.txt): rounds 0 and 1
+  //      static, from round 2 on the units are HANDED OUT: one ticket counter per XCD (unit u always runs on XCD u % 8, so the column
   //      blocks of a tile share that XCD's L2), drawn by lane 0 of wave 0 right after its matrix
   //      loop -- two units ahead, so the ticket's round trip (and the LDS-DMA of the next unit's
   //      metadata, which needs the ticket) hides behind a whole unit; nothing ever waits for it.
@@ -898,9 +900,6 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(x, as[n], ab[n]), 0.f)),
                                                   rs_cact, o_off[rr], n * 128, 0);
           }
-        // counter back to zero for the next launch on this stream (nobody else touches it any more)
-        if (wave == 0 && lane == 0)
-          __hip_atomic_store(p.done + pair_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     mark(5);
@@ -1046,8 +1045,8 @@ static ConvProf g_conv_prof;
 
 // arithmetic of the persistent kernel: -1 = from the environment (SG_CONV_SPLIT, default 1), 0 = fp32
 // MFMA, 1 = split-precision bf16 MFMA (sg_spconv_set_arithmetic; tests compare the two in one process)
-static int g_arith_override = -1;
-static int g_combine_override = -1;   // in-launch combine of offset-split layers: -1 = SG_CONV_COMBINE (default 0)
+static std::atomic<int> g_arith_override{-1};
+static std::atomic<int> g_combine_override{-1};   // in-launch combine of offset-split layers: -1 = SG_CONV_COMBINE (default 1)
 
 // Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
 // of 8 counters (one per XCD) out of a per-(device, stream) pool; the pool is cleared again, in
@@ -1064,25 +1063,37 @@ constexpr size_t kTicketBlocks = 1 << 12;     // x 1 KB = 4 MB per stream
 static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, TicketPool> g_ticket_pools;
 
-// Arrival counters of the in-launch combine: one zeroed block per (device, stream), used by every
-// launch on that stream in turn (the reducing workgroup puts its counter back to zero, and launches
-// of one stream do not overlap).
-constexpr int kDoneCounters = 4096;
-static std::map<std::pair<int, hipStream_t>, unsigned *> g_done_pools;
+// Arrival counters of the in-launch combine: every launch takes a fresh, zeroed range out of a
+// per-(device, stream) pool; when the pool has been used up it is cleared again in stream order
+// (launches of one stream do not overlap, so a range is never shared by two kernels, and a kernel
+// that was aborted half way cannot leave counts behind for a later launch).
+constexpr int kDoneCounters = 4096;                 // most (tile, column unit) pairs of one launch
+constexpr size_t kDonePoolCounters = 1 << 20;       // x 4 B = 4 MB per stream
+struct DonePool {
+  unsigned *dev = nullptr;
+  size_t next = 0;
+};
+static std::map<std::pair<int, hipStream_t>, DonePool> g_done_pools;
 
-static unsigned *take_done(hipStream_t stream) {
+static unsigned *take_done(hipStream_t stream, size_t count) {
   int dev = 0;
   hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_ticket_mu);
-  unsigned *&slot = g_done_pools[{dev, stream}];
-  if (slot == nullptr) {
-    if (hipMalloc(&slot, kDoneCounters * sizeof(unsigned)) != hipSuccess) {
-      slot = nullptr;
+  DonePool &dp = g_done_pools[{dev, stream}];
+  if (dp.dev == nullptr) {
+    if (hipMalloc(&dp.dev, kDonePoolCounters * sizeof(unsigned)) != hipSuccess) {
+      dp.dev = nullptr;
       return nullptr;
     }
-    hipMemsetAsync(slot, 0, kDoneCounters * sizeof(unsigned), stream);
+    dp.next = kDonePoolCounters;
   }
-  return slot;
+  if (dp.next + count > kDonePoolCounters) {
+    hipMemsetAsync(dp.dev, 0, kDonePoolCounters * sizeof(unsigned), stream);
+    dp.next = 0;
+  }
+  unsigned *r = dp.dev + dp.next;
+  dp.next += count;
+  return r;
 }
 
 static unsigned *take_tickets(hipStream_t stream) {
@@ -1339,8 +1350,9 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   // the persistent kernel takes with Cin >= SG_CONV_SPLIT_MIN_CIN (SG_CONV_SPLIT=0: the fp32-MFMA
   // kernel, kept for A/B)
   static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
-  static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 32;
-  const int split_on = g_arith_override >= 0 ? g_arith_override : split_env;
+  static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 16;
+  const int arith_ov = g_arith_override.load(std::memory_order_relaxed);
+  const int split_on = arith_ov >= 0 ? arith_ov : split_env;
   const bool split = persistent && split_on != 0 && Cin >= split_min_cin;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
   //      that still fills the chip, the persistent kernel always works on 32-column blocks
@@ -1353,13 +1365,6 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     bpu = NB < 4 ? NB : 4;
     while (bpu > 1 && static_cast<long long>(num_tiles) * ((NB + bpu - 1) / bpu) < target) --bpu;
   }
-  // persistent kernel, large layers with an even number of column blocks: 2 blocks per unit (the
-  // gathered rows are read once for both, half as many unit boundaries).  SG_CONV_NBW=1 disables it.
-  static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;   // developer knob
-  // (Cout % 64 == 0: the second column block of a unit is addressed without its own bounds check)
-  const bool wide = persistent && !split && nbw_env >= 2 && Cout % 64 == 0 &&
-                    static_cast<long long>(num_tiles) * (NB / 2) >= 2048;
-  if (wide) bpu = 2;
   const int col_units = (NB + bpu - 1) / bpu;
   int ksplit = 1;
   const long long waves = static_cast<long long>(num_tiles) * col_units * waves_per_unit;
@@ -1382,14 +1387,15 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.trace = nullptr;
   a.queue = nullptr;
   // offset-split layers of the persistent kernel: partial sums combined inside the launch by the last
-  // workgroup of each (tile, column unit) instead of by conv_reduce_kernel (SG_CONV_COMBINE=1; off by
-  // default until it has been through the whole GPU suite)
-  static const int combine_env = getenv("SG_CONV_COMBINE") ? atoi(getenv("SG_CONV_COMBINE")) : 0;
+  // workgroup of each (tile, column unit) instead of by conv_reduce_kernel (the default; SG_CONV_COMBINE=0
+  // / sg_spconv_set_combine(0): the separate reduce kernel, same numbers)
+  static const int combine_env = getenv("SG_CONV_COMBINE") ? atoi(getenv("SG_CONV_COMBINE")) : 1;
   a.done = nullptr;
   a.out_final = out;
-  if ((g_combine_override >= 0 ? g_combine_override : combine_env) != 0 && persistent && ksplit > 1 &&
+  const int combine_ov = g_combine_override.load(std::memory_order_relaxed);
+  if ((combine_ov >= 0 ? combine_ov : combine_env) != 0 && persistent && ksplit > 1 &&
       static_cast<long long>(num_tiles) * col_units <= kDoneCounters)
-    a.done = take_done(stream);
+    a.done = take_done(stream, static_cast<size_t>(num_tiles) * col_units);
   const long long units = static_cast<long long>(num_tiles) * col_units * ksplit;
   a.num_units = static_cast<int>(units);
   auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
@@ -1401,61 +1407,31 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream);
     if (rc != SG_OK) return rc;
   } else if (persistent) {
-    // as many workgroups as are resident at once (a multiple of 8 so that unit u always runs on
-    // XCD u % 8)
-    const size_t lds = static_cast<size_t>(kWavesPerWg) * (wide ? 2 : 1) * 16 * 64 * sizeof(float) +
+    // fp32-MFMA kernel (SG_CONV_SPLIT=0 / sg_spconv_set_arithmetic(0), and layers below
+    // SG_CONV_SPLIT_MIN_CIN): 16-channel slices, 2-deep operand ring, 4 waves per unit, one column
+    // block; as many workgroups as are resident at once (a multiple of 8 so that unit u always runs
+    // on XCD u % 8).  (Rounds 1-3 also carried 4- and 8-deep rings, an 80-VGPR build and 64-column
+    // units of this kernel; none of them was faster and they are gone.)
+    const size_t lds = static_cast<size_t>(kWavesPerWg) * 16 * 64 * sizeof(float) +
                        2 * kMetaInts * sizeof(int32_t) + 16;
-    static int num_cu = 0;
-    if (num_cu == 0) {
+    constexpr int kSliceCh = 16;
+    static int num_cu = 0, occ = 0;
+    static std::once_flag once;
+    std::call_once(once, [&] {
       int dev = 0;
       hipGetDevice(&dev);
       hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (num_cu <= 0) num_cu = 256;
-    }
-    // 16-channel slices.  Operand ring: 2 deep on the big layers (several rounds of units per
-    // workgroup, 4-5 workgroups per CU hide the load latency; deeper rings measured slower there,
-    // profiles/README.md); `ring_small` deep on layers that run as a single round of units, where a
-    // wave's time is the chain of its dependent memory round trips, not the matrix pipe.
-    constexpr int kSliceCh = 16;
-    static const int ring_small_env = getenv("SG_CONV_RING_SMALL") ? atoi(getenv("SG_CONV_RING_SMALL")) : 2;   // developer knob
-    // register budget: 5 waves per SIMD (<= 96 VGPRs) by default; SG_CONV_WPE=6 selects the build
-    // held to 80 VGPRs, 6 workgroups per CU (developer knob for the occupancy A/B)
-    static const int wpe_env = getenv("SG_CONV_WPE") ? atoi(getenv("SG_CONV_WPE")) : 5;
-    const bool wpe6 = wpe_env >= 6;
-    static int occ_tab[5] = {0, 0, 0, 0, 0};  // resident workgroups per CU: ring 2, 4, 8; ring 2 @ 6 waves; wide
-    auto occupancy = [&](int which) {
-      if (occ_tab[which] == 0) {
-        int o = 0;
-        if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 5>, 256, lds);
-        else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 4, 0, 4>, 256, lds);
-        else if (which == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 8, 0, 2>, 256, lds);
-        else if (which == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 6>, 256, lds);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2>, 256, lds);
-        if (const char *e = getenv("SG_CONV_OCC")) o = atoi(e) > 0 && atoi(e) < o ? atoi(e) : o;   // developer knob
-        occ_tab[which] = o < 1 ? 1 : o;
-      }
-      return occ_tab[which];
-    };
-    int which = wide ? 4 : wpe6 ? 3 : 0;
-    if (!wide && units <= static_cast<long long>(num_cu) * occupancy(which))      // single round of units
-      which = ring_small_env >= 8 ? 2 : ring_small_env >= 4 ? 1 : which;
-    const int occ = occupancy(which);
-    auto launch = [&](int g_, bool trace) {
-      const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
-      if (which == 4) gather_conv_persistent_kernel<kSliceCh, 2, 0, 4, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (trace) gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 3) gather_conv_persistent_kernel<kSliceCh, 2, 0, 6><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 2) gather_conv_persistent_kernel<kSliceCh, 8, 0, 2><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else if (which == 1) gather_conv_persistent_kernel<kSliceCh, 4, 0, 4><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-      else gather_conv_persistent_kernel<kSliceCh, 2, 0, 5><<<g_, 256, lds, stream>>>(a, ib_, wb_);
-    };
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gather_conv_persistent_kernel<kSliceCh, 2, 0, 5>, 256, lds);
+      if (occ < 1) occ = 1;
+    });
     a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
-    static const bool static_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC"));   // developer knob
-    a.queue = static_env ? nullptr : take_tickets(stream);       // (null: static hand-out)
+    static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
+    a.queue = dyn_env ? take_tickets(stream) : nullptr;          // (null: static snake, the default)
     long long g = static_cast<long long>(num_cu) * occ;
     if (g > units) g = units;
     if (g >= 8) g -= g % 8;
-
+    const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
     static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
     if (trace_env) {
       const size_t nb = static_cast<size_t>(units) * kWavesPerWg * 8 * sizeof(unsigned long long);
@@ -1463,7 +1439,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
       hipMalloc(&dbuf, nb);
       hipMemsetAsync(dbuf, 0, nb, stream);
       a.trace = dbuf;
-      launch(static_cast<int>(g), true);
+      gather_conv_persistent_kernel<kSliceCh, 2, 1, 5><<<static_cast<int>(g), 256, lds, stream>>>(a, ib_, wb_);
       hipStreamSynchronize(stream);
       std::vector<unsigned long long> h(nb / 8);
       hipMemcpy(h.data(), dbuf, nb, hipMemcpyDeviceToHost);
@@ -1475,7 +1451,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
         fclose(f);
       }
     } else {
-      launch(static_cast<int>(g), false);
+      gather_conv_persistent_kernel<kSliceCh, 2, 0, 5><<<static_cast<int>(g), 256, lds, stream>>>(a, ib_, wb_);
     }
   } else {
     const size_t lds = kWavesPerWg * kTileRows * kMaxK * sizeof(int32_t);

@@ -46,8 +46,32 @@ __global__ void __launch_bounds__(256) concat2_kernel(const float4 *__restrict__
   }
 }
 
-__global__ void __launch_bounds__(256) iota_kernel(int32_t *out, int n) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = i;
+// Trivial plans of the 1x1 convs on the identity branches (kernel volume 1, neighbour = the row
+// itself): order[l][i] = i for i < rows, -1 up to whole 32-row tiles -- with K = 1 the same buffer is
+// the gather table, the plan's row order and its per-tile gather blocks; ones[t] = 1 is every tile's
+// offset mask.  blockIdx.y = level.
+struct IdentSegs {
+  int32_t *order[SG_PYRAMID_MAX_LEVELS];
+  int rows[SG_PYRAMID_MAX_LEVELS];
+  int n;
+};
+__global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s, uint32_t *ones, int n_ones) {
+  const int l = blockIdx.y;
+  const int rows = s.rows[l], padded = (rows + 31) / 32 * 32;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < padded; i += gridDim.x * 256) s.order[l][i] = i < rows ? i : -1;
+  if (l == 0)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_ones; i += gridDim.x * 256) ones[i] = 1u;
+}
+
+// feature rows zero-padded to `cpad` channels (the input conv on the persistent kernel: Cin % 16 == 0)
+__global__ void __launch_bounds__(256) pad_channels_kernel(const float *__restrict__ in, int64_t rows, int cin,
+                                                          int cpad, float *__restrict__ out) {
+  const int64_t total = rows * cpad;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int64_t r = t / cpad;
+    const int c = static_cast<int>(t - r * cpad);
+    out[t] = c < cin ? in[r * cin + c] : 0.f;
+  }
 }
 
 // bump allocator with stack discipline
@@ -164,7 +188,16 @@ struct Exec {
       SG_ALLOC(x0, float, feat);
       SG_ALLOC(x0a, float, feat);
       const Act a0{L.blocks[0].bn1_scale, L.blocks[0].bn1_shift, x0a};
-      SG_TRY(conv(pre_in, rows, subm, pre_cin, c, d->input_w, nullptr, nullptr, nullptr, a0, x0));
+      // weights packed for more input channels than the features have (a multiple of 16: the
+      // persistent MFMA kernel instead of the general one): convolve a zero-padded copy
+      const int cpk = d->input_cin_packed > pre_cin ? d->input_cin_packed : pre_cin;
+      if (cpk != pre_cin && rows) {
+        SG_ALLOC(xp, float, static_cast<size_t>(rows) * cpk);
+        pad_channels_kernel<<<grid_for(static_cast<int64_t>(rows) * cpk, 256), 256, 0, as_stream(stream)>>>(
+            pre_in, rows, pre_cin, cpk, xp);
+        pre_in = xp;
+      }
+      SG_TRY(conv(pre_in, rows, subm, cpk, c, d->input_w, nullptr, nullptr, nullptr, a0, x0));
       x = x0;
       xa = x0a;
     } else if (xa == nullptr) {
@@ -269,7 +302,8 @@ static size_t level_index_bytes(size_t rows, size_t rows_next, bool deeper) {
 static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
   const int L = d->n_levels;
-  size_t total = (1 << 20) + sg_spconv_pyramid_workspace_bytes(num_rows, L) + align_up(rows * 4);
+  size_t total = (1 << 20) + sg_spconv_pyramid_workspace_bytes(num_rows, L) +
+                 (L + 1) * (align_up(rows * 4) + 4096);       // trivial plans of the 1x1 convs
   sg_pyramid_level bound[SG_PYRAMID_MAX_LEVELS];
   for (int l = 0; l < L && l < SG_PYRAMID_MAX_LEVELS; ++l) {
     total += level_index_bytes(rows, rows, l + 1 < L);
@@ -411,12 +445,21 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     SG_IALLOC(ws2, char, nb);
     SG_TRY(sg_spconv_pyramid_build(indices, num_rows, spatial_shape_host, L, pl, pws, pws_bytes, ws2, nb, is));
   }
-  if (L > 1) {      // identity table of the 1x1 convs on the tail's identity branches (any level: a prefix)
-    SG_IALLOC(iota, int32_t, num_rows);
-    iota_kernel<<<grid_for(num_rows, 256), 256, 0, istream>>>(iota, num_rows);
+  if (L > 1) {      // trivial plans of the 1x1 convs on the tail's identity branches
+    IdentSegs segs;
+    segs.n = L - 1;
+    const int n_ones = (num_rows + 31) / 32;
+    SG_IALLOC(ones, uint32_t, n_ones);
     for (int l = 0; l + 1 < L; ++l) {
-      li[l].ident.nbr = iota; li[l].ident.rows = li[l].rows; li[l].ident.kvol = 1;
+      const size_t padded = (static_cast<size_t>(li[l].rows) + 31) / 32 * 32;
+      SG_IALLOC(ord, int32_t, padded ? padded : 32);
+      segs.order[l] = ord;
+      segs.rows[l] = li[l].rows;
+      Plan &P = li[l].ident;
+      P.nbr = ord; P.order = ord; P.nbr_tiles = ord; P.tile_mask = ones;
+      P.rows = li[l].rows; P.kvol = 1;
     }
+    ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs, ones, n_ones);
   }
 #undef SG_IALLOC
   if (hipEventRecord(st.ev_index, istream) != hipSuccess ||

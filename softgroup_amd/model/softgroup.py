@@ -32,6 +32,7 @@ from .blocks import MLP, ResidualBlock, UBlock
 
 
 _scan_local = threading.local()      # per worker thread: its HIP stream
+_POOL_LOCK = threading.Lock()        # creation / retirement of a model's scan pool
 
 
 def _cfg(cfg, key, default=None):
@@ -134,9 +135,15 @@ class SoftGroup(nn.Module):
         initialisers): such writes do not bump the tensors' version counters, so the cached
         packed weights / BatchNorm affines would otherwise go stale.  load_state_dict, .to(),
         train()/eval() and optimizer steps are covered without it."""
-        pool = self.__dict__.get('_scan_pool')
-        if pool is not None:          # scans still in flight must not see half-replaced derived state
-            pool.shutdown(wait=True)
+        # the pool leaves the module first (a concurrent model(batch) then builds a new one instead of
+        # submitting to a pool that is shutting down); scans still in flight must not see
+        # half-replaced derived state, so they are waited for -- unless this IS one of the pool's
+        # threads (a hook inside forward_test): joining itself would never return
+        with _POOL_LOCK:
+            pool = self.__dict__.pop('_scan_pool', None)
+        if pool is not None:
+            own = threading.current_thread() in getattr(pool, '_threads', ())
+            pool.shutdown(wait=not own)
         spconv.invalidate_caches()
         for k in self._DERIVED:
             self.__dict__.pop(k, None)
@@ -174,11 +181,6 @@ class SoftGroup(nn.Module):
     def _submit_scan(self, batch):
         """Run forward_test for this batch on a worker thread with its own stream; the returned
         dict resolves (waits) on first access, like the lazily formatted results."""
-        pool = self.__dict__.get('_scan_pool')
-        if pool is None or pool._max_workers != self.scan_contexts:
-            from concurrent.futures import ThreadPoolExecutor
-            pool = self.__dict__['_scan_pool'] = ThreadPoolExecutor(
-                max_workers=self.scan_contexts, thread_name_prefix='softgroup-scan')
         dev = torch.cuda.current_device()
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())        # the batch tensors are ready from here on
@@ -195,8 +197,15 @@ class SoftGroup(nn.Module):
                     st.synchronize()
             return dict(out)
 
+        with _POOL_LOCK:
+            pool = self.__dict__.get('_scan_pool')
+            if pool is None or pool._max_workers != self.scan_contexts:
+                from concurrent.futures import ThreadPoolExecutor
+                pool = self.__dict__['_scan_pool'] = ThreadPoolExecutor(
+                    max_workers=self.scan_contexts, thread_name_prefix='softgroup-scan')
+            fut = pool.submit(job)       # (under the lock: the pool cannot be retired in between)
         ret = LazyResults(scan_id=batch['scan_ids'][0])
-        ret.defer(pool.submit(job))
+        ret.defer(fut)
         return ret
 
     # ------------------------------------------------------------------ inference

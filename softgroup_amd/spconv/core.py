@@ -411,7 +411,7 @@ class SparseConvolution(SparseModule):
         cache = self._kio_cache
         which = (transposed, bf16, flip_k)
         if cache is not None and cache[0] == key and which in cache[1]:
-            return cache[1][which]
+            return _acquired(cache[1][which])
         with _CACHE_FILL_LOCK:            # a miss: pack once, publish only when the data is there
             cache = self._kio_cache
             if cache is None or cache[0] != key:
@@ -429,10 +429,9 @@ class SparseConvolution(SparseModule):
                     if flip_k:
                         w_t = w_t.flip(0)
                     packed = pack(w_t.contiguous(), cin, kvol, cout, True)
-                _published(packed)
-                slot[which] = packed
+                slot[which] = (packed, _published(packed))
             self._kio_cache = cache
-            return slot[which]
+            return _acquired(slot[which])
 
     def _rule_and_plan(self, input):
         """-> (plan, out_indices, out_spatial_shape, backward-plan getter, mirrored offsets?)"""
@@ -524,12 +523,40 @@ class SparseInverseConv3d(SparseConvolution):
 _CACHE_FILL_LOCK = threading.Lock()    # cache MISSES only: scans on several streams may share modules
 
 
+class _Publication:
+    """where and when a derived tensor was written: the producing stream and an event behind the
+    write.  Consumers on another stream wait for the event ON THE DEVICE (once per stream); nobody
+    blocks the host.  (Round 3 drained the producing stream instead, under the cache lock: with an
+    unfrozen backbone every optimizer step invalidates every packed weight, i.e. two host-device
+    drains per conv per step.)"""
+    __slots__ = ('event', 'stream', 'seen')
+
+    def __init__(self, device):
+        st = torch.cuda.current_stream(device)
+        self.event = torch.cuda.Event()
+        self.event.record(st)
+        self.stream = st.cuda_stream
+        self.seen = {self.stream}
+
+
 def _published(*tensors):
-    """a freshly derived tensor was written on THIS thread's stream; other streams (concurrent scans,
-    model.scan_contexts > 1) read it without an event in between: finish the writes before the cache
-    entry becomes visible (once per weight version)"""
+    """call right after enqueuing the writes of a freshly derived tensor on this thread's stream"""
     if tensors and tensors[0].is_cuda:
-        torch.cuda.current_stream(tensors[0].device).synchronize()
+        return _Publication(tensors[0].device)
+    return None
+
+
+def _acquired(entry):
+    """(tensor(s)..., publication) -> the tensor(s), ordered after their writes on this stream"""
+    pub = entry[-1]
+    if pub is not None:
+        st = torch.cuda.current_stream()
+        if st.cuda_stream not in pub.seen:
+            st.wait_event(pub.event)
+            for t in entry[:-1]:          # the allocator must not recycle it under this stream
+                t.record_stream(st)
+            pub.seen.add(st.cuda_stream)
+    return entry[0] if len(entry) == 2 else entry[:-1]
 
 
 def _bn_affine(bn):
@@ -548,10 +575,10 @@ def _bn_affine(bn):
                     shift = -bn.running_mean.float() * scale
                     if bn.bias is not None:
                         shift = shift + bn.bias.float()
-                cache = (key, scale.contiguous(), shift.contiguous())
-                _published(cache[1])
+                scale, shift = scale.contiguous(), shift.contiguous()
+                cache = (key, scale, shift, _published(scale))
                 bn.__dict__['_sg_affine'] = cache
-    return cache[1], cache[2]
+    return _acquired(cache[1:])
 
 
 def _needs_grad(*tensors):

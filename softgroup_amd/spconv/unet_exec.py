@@ -32,7 +32,8 @@ class _Level(C.Structure):
 class _Desc(C.Structure):
     _fields_ = [('n_levels', C.c_int), ('levels', C.POINTER(_Level)),
                 ('input_cin', C.c_int), ('input_w', C.c_void_p),
-                ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p)]
+                ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p),
+                ('input_cin_packed', C.c_int)]
 
 
 _desc_lock = threading.Lock()
@@ -182,8 +183,21 @@ class UNetExecutor:
             if self.input_conv is not None:
                 ic = list(self.input_conv._modules.values())
                 assert len(ic) == 1 and isinstance(ic[0], core.SubMConv3d) and ic[0].bias is None
-                d.input_cin = ic[0].in_channels
-                d.input_w = self._w(ic[0])
+                d.input_cin = cin = ic[0].in_channels
+                if cin % 16 == 0:
+                    d.input_w = self._w(ic[0])
+                else:
+                    # weights zero-padded along Cin to a multiple of 16: the executor convolves a
+                    # zero-padded copy of the features on the persistent MFMA kernel (the general
+                    # kernel's scalar gather took 54 us on the 6 -> 32 conv of the bench scene)
+                    cpk = (cin + 15) // 16 * 16
+                    cout, kvol = ic[0].out_channels, 27
+                    wp = torch.zeros((cout, kvol, cpk), dtype=torch.float32, device=ic[0].weight.device)
+                    wp[:, :, :cin] = ic[0].weight.detach().float().reshape(cout, kvol, cin)
+                    w = core.pack_weight(wp, cout, kvol, cpk, False)
+                    self._keep.append(w)
+                    d.input_w = w.data_ptr()
+                    d.input_cin_packed = cpk
             if self.output_layer is not None:
                 ol = list(self.output_layer._modules.values())
                 assert len(ol) == 2 and isinstance(ol[0], nn.BatchNorm1d) and isinstance(ol[1], nn.ReLU)
