@@ -479,6 +479,93 @@ int sg_rle_format_runs_host(const int32_t *starts_host, const int32_t *ends_host
                             int64_t out_capacity, int64_t *out_offsets_host);
 
 /* ------------------------------------------------------------------------------------------
+ * Panoptic fusion (SoftGroup.panoptic_fusion, softgroup/model/softgroup.py:606-639) over the bit rows
+ * of the kept instances (row k = N-bit mask of instance k, ceil(N/32) words per row; the rows
+ * sg_instance_runs builds, see sg_instances_result.bits): instances are visited in `order`
+ * (descending confidence -- the caller sorts, like the reference's np.argsort(scores)[::-1]); one
+ * whose overlap with already pasted points exceeds skip_iou (intersect / (npoint + 1e-5) > skip_iou,
+ * evaluated in double) is skipped, otherwise its free points take the next panoptic id (from 1) and
+ * class label_id[k] + cls_offset.  out[i] = (class & 0xFFFF) | (id << 16); points of thing classes
+ * (class >= thing_class_min; the reference hard-codes 11) without an id become semantic_classes.
+ * semantic_preds int64 [N].  ws >= sg_panoptic_fusion_workspace_bytes. */
+size_t sg_panoptic_fusion_workspace_bytes(int n_inst, int n_points);
+int sg_panoptic_fusion(const uint32_t *bits, int n_inst, int n_points, const int32_t *order,
+                       const int32_t *label_id, const int64_t *semantic_preds, int cls_offset,
+                       double skip_iou, int semantic_classes, int thing_class_min, uint32_t *out,
+                       void *ws, size_t ws_bytes, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Native host driver of the grouping head and of the result extraction (csrc/scan_exec.hip): what
+ * SoftGroup.forward_grouping + clusters_voxelization (softgroup/model/softgroup.py:411-480,655-709)
+ * and get_instances (:537-604) do between the network's dense heads, as one C call each --
+ * class selection, ball query, BFS clustering, proposal voxel index and pooled features in the
+ * first; kept-instance table, mask runs, RLE text and the copy to the host in the second.  Same
+ * kernels as the per-operator entry points above plus fused replacements of the torch glue; same
+ * results, bit for bit (every float operation of the glue is the separate IEEE operation torch
+ * performs).  Covers the plain SoftGroup path (no pyramid / octree grouping, no lvl_fusion, no
+ * sem2ins classes); anything else stays on the per-operator path.
+ * Device memory: ONE caller-provided arena per call, carved in call order; results are returned as
+ * BYTE OFFSETS into it.  SG_ERR_WORKSPACE + arena_needed (an estimate; retry may ask again) when it
+ * is too small.  Both calls synchronise `stream` several times (data-dependent sizes).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sg_grouping_cfg {
+  int n_points;              /* N */
+  int n_sem_classes;         /* columns of `scores` */
+  int n_seg;                 /* grouped classes, <= 32 (semantic classes minus ignore_classes) */
+  const int32_t *seg_class;  /* device [n_seg], ascending: semantic class of segment s */
+  const float *seg_thr;      /* device [n_seg]: npoint_thr, or npoint_thr * class_numpoint_mean (fp32 product) */
+  float score_thr;           /* grouping_cfg.score_thr (strict >) */
+  int min_npoint;            /* test_cfg.min_npoint: classes with fewer selected points are skipped */
+  float radius;              /* grouping_cfg.radius */
+  int batch_size;
+  float voxel_scale;         /* instance_voxel_cfg.scale */
+  int voxel_shape;           /* instance_voxel_cfg.spatial_shape */
+  int feat_channels;         /* C of point_feats */
+} sg_grouping_cfg;
+typedef struct sg_grouping_result {   /* host */
+  int n_selected, n_neighbours, n_proposals, sum_npoint, n_voxels, max_active;
+  size_t proposals_idx;      /* int32 [sum_npoint, 2] = (proposal, scene point) */
+  size_t proposals_offset;   /* int32 [n_proposals + 1] */
+  size_t voxel_coords;       /* int32 [n_voxels, 4] = (proposal, x, y, z) */
+  size_t voxel_offsets;      /* int32 [n_proposals + 1]: first voxel of every proposal */
+  size_t voxel_feats;        /* float [n_voxels, C] */
+  size_t point_to_voxel;     /* int32 [sum_npoint] */
+  size_t arena_used, arena_needed;
+} sg_grouping_result;
+/* scores f32 [N, n_sem_classes] = softmax of the semantic logits; pt_offsets, coords_float f32 [N,3];
+ * batch_idxs int32 [N]; point_feats f32 [N, C] = backbone features per point. */
+int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const float *pt_offsets,
+                     const float *coords_float, const int32_t *batch_idxs, const float *point_feats,
+                     void *arena, size_t arena_bytes, sg_grouping_result *result_host,
+                     sg_stream_t stream);
+
+typedef struct sg_instances_cfg {
+  int n_proposals, n_classes;   /* instance classes (without the background column) */
+  int score_stride;             /* columns of cls_prob / iou_scores / mask_scores (n_classes + 1) */
+  int64_t sum_npoint;           /* rows of proposals_idx / mask_scores */
+  int n_points;                 /* mask length N */
+  float cls_score_thr, mask_score_thr;
+  int min_npoint;
+} sg_instances_cfg;
+typedef struct sg_instances_result {   /* host */
+  int n_kept;
+  size_t off_class, off_score, off_text, text_bytes;   /* byte offsets into host_out */
+  size_t host_needed, arena_used, arena_needed;
+  size_t bits;        /* arena offset: uint32 [n_kept, ceil(n_points / 32)] bit rows of the kept masks */
+  size_t label_id;    /* arena offset: int32 [n_kept] (device copy of the labels) */
+} sg_instances_result;
+/* proposals_idx int32 [S,2]; mask_scores f32 [S, stride] (per pair); cls_prob f32 [nP, stride] =
+ * softmax of the class logits; iou_scores f32 [nP, stride].  host_out (pinned host memory) receives
+ *   int64 text_off[n_kept + 1] | int32 label_id[n_kept] at off_class | f32 conf[n_kept] at off_score
+ *   | the RLE text at off_text: instance k's "start len ..." string is
+ *   text[text_off[k] .. text_off[k+1] - 1) (sg_rle_format_device's convention).
+ * Instances come in the reference's order (class-major, proposal-ascending, softgroup.py:566-603). */
+int sg_scan_instances(const sg_instances_cfg *cfg, const int32_t *proposals_idx, const float *mask_scores,
+                      const float *cls_prob, const float *iou_scores, void *arena, size_t arena_bytes,
+                      void *host_out, size_t host_bytes, sg_instances_result *result_host,
+                      sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Evaluation (ScanNetEval.assign_instances_for_scan, softgroup/evaluation/instance_eval.py:228-309):
  * counts[p*n_slots + s] = number of points of prediction p's mask whose ground-truth slot is s.
  * Masks come as runs: run r covers points run_start[r] .. run_start[r] + len(r) - 1 of prediction

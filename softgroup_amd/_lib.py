@@ -85,6 +85,10 @@ SIGNATURES = {
     'sg_rle_format_device_text_bytes': (_i64, [_i64, _i64]),
     'sg_rle_format_device': (_i, [_vp, _vp, _vp, _i, _i64, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     'sg_rle_format_runs_host': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    'sg_panoptic_fusion_workspace_bytes': (_sz, [_i, _i]),
+    'sg_panoptic_fusion': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.c_double, _i, _i, _vp, _vp, _sz, _vp]),
+    'sg_scan_grouping': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'sg_scan_instances': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     'sg_eval_intersections': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'sg_gather_rows_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),

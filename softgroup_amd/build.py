@@ -26,6 +26,7 @@ SOURCES = [
     ('spconv_train.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
+    ('scan_exec.hip', ['-ffp-contract=off']),
     ('eval_ops.hip', ['-ffp-contract=off']),
     ('host_ops.cpp', ['-ffp-contract=off']),
 ]

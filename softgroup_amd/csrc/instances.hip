@@ -158,6 +158,80 @@ __global__ void instance_runs_total_kernel(const int32_t *__restrict__ total, in
   bounds[n_kept] = *total;
 }
 
+// ---- panoptic fusion (SoftGroup.panoptic_fusion, softgroup/model/softgroup.py:606-639) on the bit
+// rows of the kept instances: in the given order (descending confidence, decided by the caller like
+// the reference's np.argsort) an instance is skipped when more than skip_iou of its points are
+// already taken (intersect / (npoint + 1e-5) in double, like numpy), otherwise its free points get
+// the next panoptic id and the instance's class.  The order makes it a sequential scan over the
+// instances: ONE workgroup walks them, every thread owning a fixed set of 32-point words of the
+// `taken` row (no hazards between threads; two block reductions per instance).  The reference
+// decodes every RLE string to a dense N-vector on the host (and round 3 re-parsed the RLE text):
+// 21 ms per LiDAR sweep with ~1000 instances, profiles/r04_kitti_host_profile.txt.
+constexpr int kFuseThreads = 1024;
+__global__ void __launch_bounds__(kFuseThreads) panoptic_fusion_kernel(
+    const uint32_t *__restrict__ bits, int words, int n_inst, const int32_t *__restrict__ order,
+    const int32_t *__restrict__ label_id, const int64_t *__restrict__ semantic_preds, int n_points,
+    int cls_offset, double skip_iou, int semantic_classes, int thing_class_min, uint32_t *__restrict__ taken,
+    uint32_t *__restrict__ ids, int32_t *__restrict__ label_of_id, uint32_t *__restrict__ out) {
+  __shared__ int red[2][kFuseThreads / 64];
+  __shared__ int decide;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int w = threadIdx.x; w < words; w += kFuseThreads) taken[w] = 0u;
+  for (int i = threadIdx.x; i < n_points; i += kFuseThreads) ids[i] = 0u;
+  int next_id = 1;
+  for (int r = 0; r < n_inst; ++r) {
+    const int k = order[r];
+    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
+    int inter = 0, cnt = 0;
+    for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+      const uint32_t b = row[w];
+      cnt += __popc(b);
+      inter += __popc(b & taken[w]);
+    }
+    inter = wave_sum(inter);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+      red[0][wave] = inter;
+      red[1][wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long ti = 0, tc = 0;
+      for (int v = 0; v < kFuseThreads / 64; ++v) {
+        ti += red[0][v];
+        tc += red[1][v];
+      }
+      decide = (static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou) ? 0 : 1;
+      if (decide) label_of_id[next_id] = label_id[k] + cls_offset;
+    }
+    __syncthreads();
+    if (decide) {          // uniform
+      for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+        uint32_t paste = row[w] & ~taken[w];
+        if (paste == 0u) continue;
+        taken[w] |= paste;
+        while (paste) {
+          const int b = __ffs(static_cast<int>(paste)) - 1;
+          paste &= paste - 1;
+          ids[w * 32 + b] = static_cast<uint32_t>(next_id);
+        }
+      }
+      ++next_id;
+    }
+    __syncthreads();       // `decide` / `red` are rewritten by the next instance
+  }
+  __threadfence_block();
+  __syncthreads();
+  // encode: class | id << 16; thing classes that nobody claimed -> ignore (semantic_classes)
+  for (int i = threadIdx.x; i < n_points; i += kFuseThreads) {
+    const uint32_t id = ids[i];
+    const uint32_t cls = id ? static_cast<uint32_t>(label_of_id[id]) : static_cast<uint32_t>(semantic_preds[i]);
+    uint32_t v = (cls & 0xFFFFu) | (id << 16);
+    if (cls >= static_cast<uint32_t>(thing_class_min) && id == 0u) v = static_cast<uint32_t>(semantic_classes);
+    out[i] = v;
+  }
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -266,6 +340,32 @@ int sg_rle_format_device(const int32_t *starts, const int32_t *ends, const int64
   rle_text_kernel<<<grid_for(n, 256, 4096), 256, 0, stream>>>(starts, ends, off, n_runs_p, n, text);
   rle_offsets_kernel<<<(n_inst + 256) / 256, 256, 0, stream>>>(bounds, n_inst, off, total, text_off);
   return check_launch("sg_rle_format_device");
+}
+
+size_t sg_panoptic_fusion_workspace_bytes(int n_inst, int n_points) {
+  return align_up(static_cast<size_t>(instance_words(n_points)) * 4) + align_up(static_cast<size_t>(n_points > 0 ? n_points : 1) * 4) +
+         align_up((static_cast<size_t>(n_inst) + 2) * 4) + 256;
+}
+
+int sg_panoptic_fusion(const uint32_t *bits, int n_inst, int n_points, const int32_t *order,
+                       const int32_t *label_id, const int64_t *semantic_preds, int cls_offset,
+                       double skip_iou, int semantic_classes, int thing_class_min, uint32_t *out, void *ws,
+                       size_t ws_bytes, sg_stream_t stream_) {
+  SG_REQUIRE(n_inst >= 0 && n_points >= 0 && out != nullptr && semantic_preds != nullptr,
+             "sg_panoptic_fusion: bad arguments");
+  SG_REQUIRE(n_inst < 65536, "sg_panoptic_fusion: %d instances exceed the 16-bit panoptic id", n_inst);
+  SG_REQUIRE(ws != nullptr && ws_bytes >= sg_panoptic_fusion_workspace_bytes(n_inst, n_points),
+             "sg_panoptic_fusion: workspace too small");
+  if (n_points == 0) return SG_OK;
+  Workspace a(ws, ws_bytes);
+  const int words = static_cast<int>(instance_words(n_points));
+  uint32_t *taken = a.take<uint32_t>(words);
+  uint32_t *ids = a.take<uint32_t>(n_points);
+  int32_t *label_of_id = a.take<int32_t>(static_cast<size_t>(n_inst) + 2);
+  panoptic_fusion_kernel<<<1, kFuseThreads, 0, as_stream(stream_)>>>(
+      bits, words, n_inst, order, label_id, semantic_preds, n_points, cls_offset, skip_iou, semantic_classes,
+      thing_class_min, taken, ids, label_of_id, out);
+  return check_launch("sg_panoptic_fusion");
 }
 
 }  // extern "C"

@@ -79,6 +79,8 @@ class SoftGroup(nn.Module):
         self.test_cfg = test_cfg
         self.fixed_modules = fixed_modules
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
+        self.use_native_scan = True  # grouping head + proposal voxelisation + instance extraction as
+        #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
         self.scan_contexts = 1       # > 1: model(batch) hands the scan to one of that many worker
         #                              threads (own HIP stream each) and returns at once -- several
@@ -237,14 +239,19 @@ class SoftGroup(nn.Module):
             if lvl_fusion:
                 batch_idxs = x.indices[:, 0].int()
                 coords_float = ops.voxelization(coords_float, p2v_map)
-            proposals_idx, proposals_offset = self.forward_grouping(
-                semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
-                lvl_fusion=lvl_fusion, batch_size=None if x4_split else batch_size)
-            inst_feats, inst_map = self.clusters_voxelization(
-                proposals_idx, proposals_offset, output_feats, coords_float,
-                **self.instance_voxel_cfg)
-            _, cls_scores, iou_scores, mask_scores = self.forward_instance(inst_feats, inst_map)
-            inst = (proposals_idx, cls_scores, iou_scores, mask_scores)
+            inst = None
+            if self._native_scan_usable(semantic_scores, output_feats, lvl_fusion, x4_split):
+                inst = self._native_grouping_and_refinement(semantic_scores, pt_offsets, batch_idxs,
+                                                            coords_float, output_feats, batch_size)
+            if inst is None:
+                proposals_idx, proposals_offset = self.forward_grouping(
+                    semantic_scores, pt_offsets, batch_idxs, coords_float, self.grouping_cfg,
+                    lvl_fusion=lvl_fusion, batch_size=None if x4_split else batch_size)
+                inst_feats, inst_map = self.clusters_voxelization(
+                    proposals_idx, proposals_offset, output_feats, coords_float,
+                    **self.instance_voxel_cfg)
+                _, cls_scores, iou_scores, mask_scores = self.forward_instance(inst_feats, inst_map)
+                inst = (proposals_idx, cls_scores, iou_scores, mask_scores)
 
         # ---- everything below only turns device results into host objects (numpy arrays, RLE
         #      strings): it can run on the results thread, on its own stream, while the caller
@@ -259,15 +266,24 @@ class SoftGroup(nn.Module):
                                                        pt_offsets, pt_offset_labels, v2p_map,
                                                        lvl_fusion))
             if inst is not None:
+                # panoptic fusion runs on the device, on the instances' bit rows, where the native
+                # instance extraction applies; else on the host over the RLE strings
+                fuse_native = ('panoptic' in tasks and self.use_native_scan and not lvl_fusion
+                               and not self.sem2ins_classes and inst[1].is_cuda and inst[0].size(0) > 0)
                 pred_instances = self.get_instances(scan_ids[0], inst[0], semantic_scores, inst[1],
                                                     inst[2], inst[3], v2p_map=v2p_map,
-                                                    lvl_fusion=lvl_fusion)
+                                                    lvl_fusion=lvl_fusion,
+                                                    _panoptic_sem=semantic_preds if fuse_native else None)
+                fused = None
+                if fuse_native:
+                    pred_instances, fused = pred_instances
                 if 'instance' in tasks:
                     out.update(pred_instances=pred_instances,
                                gt_instances=self.get_gt_instances(semantic_labels, instance_labels))
                 if 'panoptic' in tasks:
-                    out.update(panoptic_preds=self.panoptic_fusion(semantic_preds.cpu().numpy(),
-                                                                   pred_instances))
+                    if fused is None:
+                        fused = self.panoptic_fusion(semantic_preds.cpu().numpy(), pred_instances)
+                    out.update(panoptic_preds=fused)
             return out
 
         if _inline_results or not (self.async_results and semantic_scores.is_cuda):
@@ -290,6 +306,73 @@ class SoftGroup(nn.Module):
 
         ret.defer(lazy_worker().submit(job))
         return ret
+
+    # ------------------------------------------------------------------ native scan driver
+    def _native_scan_usable(self, semantic_scores, output_feats, lvl_fusion, x4_split):
+        g = self.grouping_cfg
+        n_seg = self.semantic_classes - len(set(_cfg(g, 'ignore_classes')))
+        return (self.use_native_scan and self.use_executor and semantic_scores.is_cuda
+                and output_feats.dtype == torch.float32 and not lvl_fusion and not x4_split
+                and not self.sem2ins_classes and not _cfg(g, 'with_pyramid', False)
+                and not _cfg(g, 'with_octree', False) and 0 < n_seg <= 32
+                and not _cfg(self.instance_voxel_cfg, 'rand_quantize', False))
+
+    def _grouping_constants(self, dev):
+        """(class ids, per-class cluster-size thresholds, dummy offsets) on the device, once per
+        configuration: thr = npoint_thr (absolute) if the class mean is -1 else npoint_thr * mean,
+        the fp32 product of bfs_cluster.cpp:73-79"""
+        g = self.grouping_cfg
+        npoint_thr = _cfg(g, 'npoint_thr')
+        class_mean = torch.tensor(_cfg(g, 'class_numpoint_mean'), dtype=torch.float32)
+        assert class_mean.size(0) == self.semantic_classes
+        ignore = set(_cfg(g, 'ignore_classes'))
+        classes = [c for c in range(self.semantic_classes) if c not in ignore]
+        const = self.__dict__.setdefault('_grouping_const', {})
+        ck = (str(dev), tuple(classes), float(npoint_thr), tuple(class_mean.tolist()))
+        if ck not in const:
+            m = class_mean[classes].numpy()
+            thr = np.where(m == np.float32(-1), np.float32(npoint_thr), np.float32(npoint_thr) * m)
+            const[ck] = (torch.tensor(classes, device=dev),
+                         torch.from_numpy(thr.astype(np.float32)).to(dev),
+                         torch.zeros(2, dtype=torch.int32, device=dev),
+                         torch.tensor(classes, dtype=torch.int32, device=dev))
+            torch.cuda.current_stream().synchronize()      # once: other streams may use them next
+        return const[ck]
+
+    def _native_grouping_and_refinement(self, semantic_scores, pt_offsets, batch_idxs, coords_float,
+                                        output_feats, batch_size):
+        """forward_grouping + clusters_voxelization + forward_instance with the grouping head and the
+        proposal voxelisation in one C call (native_scan.grouping); the dense heads stay torch
+        modules.  -> (proposals_idx, cls_scores, iou_scores, mask_scores) or None when there is no
+        proposal (the caller's module path builds the reference's dummy tensor)."""
+        from . import native_scan as NS
+        g, v = self.grouping_cfg, self.instance_voxel_cfg
+        dev = semantic_scores.device
+        _, seg_thr, _, cls32 = self._grouping_constants(dev)
+        scores = semantic_scores.float().softmax(dim=-1)
+        offs = pt_offsets.float().contiguous()
+        feats = output_feats.contiguous()
+        cfg = NS.GroupingCfg(
+            n_points=scores.size(0), n_sem_classes=scores.size(1), n_seg=cls32.numel(),
+            seg_class=cls32.data_ptr(), seg_thr=seg_thr.data_ptr(), score_thr=_cfg(g, 'score_thr'),
+            min_npoint=_cfg(self.test_cfg, 'min_npoint'), radius=_cfg(g, 'radius'), batch_size=int(batch_size),
+            voxel_scale=_cfg(v, 'scale'), voxel_shape=_cfg(v, 'spatial_shape'), feat_channels=feats.size(1))
+        r = NS.grouping(cfg, scores, offs, coords_float.contiguous(), batch_idxs.int().contiguous(), feats)
+        if r is None:
+            return None
+        ss = _cfg(v, 'spatial_shape')
+        x = spconv.SparseConvTensor(r['voxel_feats'], r['voxel_coords'], [ss] * 3, r['n_proposals'])
+        ex = self.__dict__.get('_tiny_exec')
+        if ex is None:
+            ex = self.__dict__['_tiny_exec'] = UNetExecutor(self.tiny_unet, None,
+                                                             self.tiny_unet_outputlayer)
+        if ex.usable(x.features):
+            vfeats = ex(x)
+        else:
+            vfeats = self.tiny_unet_outputlayer(self.tiny_unet(x)).features
+        mask_scores = self.mask_linear(vfeats)[r['point_to_voxel'].long()]
+        pooled = ops.global_avg_pool(vfeats, r['voxel_offsets'])
+        return r['proposals_idx'], self.cls_linear(pooled), self.iou_score_linear(pooled), mask_scores
 
     def _unet_features(self, x):
         """input_conv -> unet -> output_layer.  Inference runs in the native executor (one C call,
@@ -365,17 +448,7 @@ class SoftGroup(nn.Module):
 
         # ---- all classes at once: segment s = position of the class in `classes`
         # (constants of the configuration live on the device once, not re-uploaded per scan)
-        const = self.__dict__.setdefault('_grouping_const', {})
-        ck = (str(dev), tuple(classes), float(npoint_thr), tuple(class_mean.tolist()))
-        if ck not in const:
-            m = class_mean[classes].numpy()
-            # thr = npoint_thr (absolute) if class mean == -1 else npoint_thr * mean, fp32
-            thr = np.where(m == np.float32(-1), np.float32(npoint_thr), np.float32(npoint_thr) * m)
-            const[ck] = (torch.tensor(classes, device=dev),
-                         torch.from_numpy(thr.astype(np.float32)).to(dev),
-                         torch.zeros(2, dtype=torch.int32, device=dev))
-            torch.cuda.current_stream().synchronize()      # once: other streams may use them next
-        cls_t, seg_thr, dummy_offsets = const[ck]
+        cls_t, seg_thr, dummy_offsets, _ = self._grouping_constants(dev)
         sel = scores[:, cls_t].t() > _cfg(g, 'score_thr')                  # [n_seg, N]
         sel &= (sel.sum(1, keepdim=True) >= min_npoint)                    # small classes are skipped
         seg, obj = sel.nonzero(as_tuple=True)                              # class-major, point-ascending
@@ -558,7 +631,7 @@ class SoftGroup(nn.Module):
 
     @force_fp32(apply_to=('semantic_scores', 'cls_scores', 'iou_scores', 'mask_scores'))
     def get_instances(self, scan_id, proposals_idx, semantic_scores, cls_scores, iou_scores,
-                      mask_scores, v2p_map=None, lvl_fusion=False):
+                      mask_scores, v2p_map=None, lvl_fusion=False, _panoptic_sem=None):
         """Same instances, order and RLE strings as the reference (softgroup.py:537-604).  For
         instance class i a proposal survives iff cls_score > cls_score_thr and its mask
         (mask_score > mask_score_thr) has >= min_npoint points; masks are encoded from sorted
@@ -571,6 +644,33 @@ class SoftGroup(nn.Module):
         n_out = v2p_map.numel() if lvl_fusion else n_pts
         cls_prob = cls_scores.softmax(1)
         prop, pt = proposals_idx[:, 0].long().to(dev), proposals_idx[:, 1].long().to(dev)
+        if not lvl_fusion and not self.sem2ins_classes and cls_scores.is_cuda and self.use_native_scan:
+            # one C call (csrc/scan_exec.hip): per-(proposal, class) point counts, the keep table and
+            # its class-major numbering on the device, one bit row per kept instance -> runs -> RLE
+            # text; labels, scores, offsets and the text arrive in one pinned host buffer
+            from . import native_scan as NS
+            nc = self.instance_classes
+            pairs = proposals_idx.int().contiguous()
+            ms = mask_scores.float().contiguous()
+            cfg = NS.InstancesCfg(
+                n_proposals=n_inst, n_classes=nc, score_stride=ms.size(1), sum_npoint=pairs.size(0),
+                n_points=n_out, cls_score_thr=_cfg(tcfg, 'cls_score_thr'),
+                mask_score_thr=_cfg(tcfg, 'mask_score_thr'), min_npoint=_cfg(tcfg, 'min_npoint'))
+            assert cls_prob.size(1) == ms.size(1) == iou_scores.size(1)
+            pan = None
+            if _panoptic_sem is not None:       # fuse on the device while the bit rows are there
+                pan = dict(semantic_preds=_panoptic_sem,
+                           cls_offset=self.semantic_classes - self.instance_classes - 1,
+                           skip_iou=_cfg(tcfg, 'panoptic_skip_iou'), semantic_classes=self.semantic_classes)
+            label, conf, text, off, fused = NS.instances(cfg, pairs, ms, cls_prob.float().contiguous(),
+                                                         iou_scores.float().contiguous(), pan)
+            label = label.astype(np.int64)
+            insts = [dict(scan_id=scan_id, label_id=label[k], conf=conf[k],
+                          pred_mask=dict(length=int(n_out), counts=text[off[k]:max(off[k + 1] - 1, off[k])]))
+                     for k in range(label.shape[0])]
+            if _panoptic_sem is not None:
+                return insts, fused
+            return insts
         if not lvl_fusion and not self.sem2ins_classes and cls_scores.is_cuda:
             # all instance classes in one pass on the GPU (csrc/instances.hip): per-(proposal,
             # class) point counts, then one bit row per KEPT instance -> runs; two small read-backs

@@ -1,0 +1,179 @@
+"""The native scan driver (csrc/scan_exec.hip: sg_scan_grouping / sg_scan_instances) against the
+per-operator path it replaces -- SoftGroup.forward_grouping + clusters_voxelization +
+forward_instance + get_instances on the operator surface (softgroup/model/softgroup.py:411-480,
+537-604, 655-709), which the other GPU tests pin to the oracle and to the reference itself.
+Integer products (proposals, voxel index, maps, labels, RLE text) must be identical, float
+products bit-identical too: both paths run the same kernels on the same inputs, and the fused
+glue kernels perform the same IEEE operations torch does."""
+import numpy as np
+import pytest
+import torch
+
+from softgroup_amd import ops, synthetic
+import softgroup_amd.spconv.pytorch as spconv
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda(batch):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+def _backbone(model, b):
+    feats = torch.cat((b['feats'], b['coords_float']), 1)
+    vf = ops.voxelization(feats, b['p2v_map'])
+    x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], b['batch_size'])
+    return model.forward_backbone(x, b['v2p_map'])
+
+
+SCENES = [
+    ('s2_30k', lambda: synthetic.scene_s2(seed=3, n=30000, room_scale=0.45)),
+    ('s2_150k', lambda: synthetic.scene_s2(seed=1, n=150000)),
+]
+
+
+@pytest.mark.parametrize('name,make', SCENES, ids=[s[0] for s in SCENES])
+def test_native_grouping_equals_operator_path(name, make):
+    xyz, rgb, inst = make()
+    b = _cuda(synthetic.make_batch(xyz, rgb, instance_labels=inst))
+    model = synthetic.build_model(seed=0)
+    with torch.no_grad():
+        sem, off, out_feats = _backbone(model, b)
+        # operator path
+        pidx, poff = model.forward_grouping(sem, off, b['batch_idxs'], b['coords_float'], model.grouping_cfg)
+        assert pidx.shape[0] > 1000 and poff.numel() > 3, 'scene must exercise the grouping head'
+        it, imap = model.clusters_voxelization(pidx, poff, out_feats, b['coords_float'],
+                                               **model.instance_voxel_cfg)
+        _, cls_s, iou_s, mask_s = model.forward_instance(it, imap)
+        model.use_native_scan = False
+        preds_op = model.get_instances('s', pidx, sem, cls_s, iou_s, mask_s)
+        model.use_native_scan = True
+        # native driver
+        assert model._native_scan_usable(sem, out_feats, False, False)
+        n_pidx, n_cls, n_iou, n_mask = model._native_grouping_and_refinement(
+            sem, off, b['batch_idxs'], b['coords_float'], out_feats, b['batch_size'])
+        preds_nat = model.get_instances('s', n_pidx, sem, n_cls, n_iou, n_mask)
+    assert torch.equal(n_pidx, pidx)
+    assert torch.equal(n_cls, cls_s) and torch.equal(n_iou, iou_s) and torch.equal(n_mask, mask_s)
+    assert len(preds_nat) == len(preds_op) > 0
+    for a, c in zip(preds_nat, preds_op):
+        assert a['label_id'] == c['label_id'] and a['conf'] == c['conf']
+        assert a['pred_mask'] == c['pred_mask']
+        assert type(a['label_id']) is type(c['label_id']) and type(a['conf']) is type(c['conf'])
+
+
+def test_native_grouping_pieces_equal_operator_path():
+    """the driver's intermediate products, one by one: proposals, voxel coordinates, voxel features,
+    point -> voxel map, voxel offsets"""
+    from softgroup_amd.model import native_scan as NS
+    xyz, rgb, inst = synthetic.scene_s2(seed=5, n=60000, room_scale=0.6)
+    b = _cuda(synthetic.make_batch(xyz, rgb, instance_labels=inst))
+    model = synthetic.build_model(seed=1)
+    g, v = model.grouping_cfg, model.instance_voxel_cfg
+    with torch.no_grad():
+        sem, off, out_feats = _backbone(model, b)
+        pidx, poff = model.forward_grouping(sem, off, b['batch_idxs'], b['coords_float'], g)
+        it, imap = model.clusters_voxelization(pidx, poff, out_feats, b['coords_float'], **v)
+        _, seg_thr, _, cls32 = model._grouping_constants(sem.device)
+        scores = sem.softmax(-1)
+        cfg = NS.GroupingCfg(
+            n_points=scores.size(0), n_sem_classes=scores.size(1), n_seg=cls32.numel(),
+            seg_class=cls32.data_ptr(), seg_thr=seg_thr.data_ptr(), score_thr=g['score_thr'],
+            min_npoint=model.test_cfg['min_npoint'], radius=g['radius'], batch_size=1,
+            voxel_scale=v['scale'], voxel_shape=v['spatial_shape'], feat_channels=out_feats.size(1))
+        r = NS.grouping(cfg, scores, off.contiguous(), b['coords_float'].contiguous(),
+                        b['batch_idxs'].int().contiguous(), out_feats.contiguous())
+    assert torch.equal(r['proposals_idx'], pidx) and torch.equal(r['proposals_offset'], poff.int())
+    assert torch.equal(r['voxel_coords'], it.indices)
+    assert torch.equal(r['voxel_feats'], it.features)
+    assert torch.equal(r['point_to_voxel'], imap.int())
+    counts = torch.bincount(it.indices[:, 0].long(), minlength=r['n_proposals'])
+    assert torch.equal(r['voxel_offsets'][1:].long(), torch.cumsum(counts, 0))
+    assert int(r['voxel_offsets'][0]) == 0
+
+
+def test_native_grouping_without_proposals_falls_back_to_the_dummy_tensor():
+    """no class passes the score threshold -> the driver reports nothing and forward_test takes the
+    reference's dummy 2-voxel path (softgroup.py:664-673)"""
+    xyz, rgb, inst = synthetic.scene_s1(seed=0)
+    b = _cuda(synthetic.make_batch(xyz, rgb, instance_labels=np.full(xyz.shape[0], -100, np.int64)))
+    model = synthetic.build_model(seed=0, head_std=None)      # untrained head: flat class scores
+    model.async_results = False
+    with torch.no_grad():
+        sem, off, out_feats = _backbone(model, b)
+        r = model._native_grouping_and_refinement(sem, off, b['batch_idxs'], b['coords_float'], out_feats, 1)
+        out_nat = model(b)
+        model.use_native_scan = False
+        out_op = model(b)
+    if r is None:
+        assert out_nat['pred_instances'] == [] or len(out_nat['pred_instances']) == len(out_op['pred_instances'])
+    assert len(out_nat['pred_instances']) == len(out_op['pred_instances'])
+
+
+def test_forward_test_native_equals_operator_path_end_to_end():
+    xyz, rgb, inst = synthetic.scene_s2(seed=7, n=80000, room_scale=0.7)
+    b = _cuda(synthetic.make_batch(xyz, rgb, instance_labels=inst))
+    model = synthetic.build_model(seed=0)
+    model.async_results = False
+    with torch.no_grad():
+        out_nat = dict(model(b))
+        model.use_native_scan = False
+        out_op = dict(model(b))
+    assert len(out_nat['pred_instances']) == len(out_op['pred_instances']) > 0
+    for a, c in zip(out_nat['pred_instances'], out_op['pred_instances']):
+        assert a['label_id'] == c['label_id'] and a['conf'] == c['conf'] and a['pred_mask'] == c['pred_mask']
+    np.testing.assert_array_equal(out_nat['semantic_preds'], out_op['semantic_preds'])
+
+
+def test_panoptic_fusion_on_the_device_equals_the_reference_loop():
+    """softgroup_kitti.yaml model section on a LiDAR-like sweep: sg_panoptic_fusion over the bit rows
+    == SoftGroup.panoptic_fusion over the RLE strings (the reference's loop, softgroup.py:606-639,
+    pinned to the reference's own forward in tests/test_ref_forward_golden.py)"""
+    import copy
+    xyz, intensity, inst = synthetic.scene_lidar(seed=3, n=60000)
+    b = _cuda(synthetic.make_batch(xyz, intensity, scale=20, instance_labels=inst))
+    model = synthetic.build_model(copy.deepcopy(synthetic.KITTI_MODEL_CFG), seed=0)
+    model.async_results = False
+    with torch.no_grad():
+        out_nat = dict(model(b))
+        # the same instances through the host loop
+        sem_pred = torch.from_numpy(out_nat['semantic_preds']) if 'semantic_preds' in out_nat else None
+        model.use_native_scan = False
+        out_op = dict(model(b))
+    assert out_nat['panoptic_preds'].dtype == np.uint32 == out_op['panoptic_preds'].dtype
+    np.testing.assert_array_equal(out_nat['panoptic_preds'], out_op['panoptic_preds'])
+    assert (out_nat['panoptic_preds'] >> 16).max() > 3, 'sweep must paste several instances'
+
+
+def test_panoptic_fusion_skips_overlapping_instances():
+    """hand-made bit rows: the second instance overlaps the first by more than skip_iou and is
+    skipped, the third is pasted on its free points only"""
+    from softgroup_amd import _lib as L
+    lib = L.lib()
+    n = 200
+    words = (n + 31) // 32
+    masks = np.zeros((3, n), bool)
+    masks[0, 10:60] = True
+    masks[1, 20:70] = True          # 40 of 50 points taken -> 0.8 > 0.5: skipped
+    masks[2, 50:120] = True         # 10 of 70 taken: pasted on 60..119
+    bits = np.zeros((3, words), np.uint32)
+    for k in range(3):
+        for i in np.nonzero(masks[k])[0]:
+            bits[k, i >> 5] |= np.uint32(1) << np.uint32(i & 31)
+    sem = np.full(n, 2, np.int64)
+    sem[150:] = 12                  # thing class nobody claims -> ignore label
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    bits_d, order_d = d(bits.view(np.int32)), d(np.array([0, 1, 2], np.int32))
+    lab_d, sem_d = d(np.array([1, 2, 3], np.int32)), d(sem)
+    out = torch.empty(n, dtype=torch.int32, device='cuda')
+    ws = torch.empty(lib.sg_panoptic_fusion_workspace_bytes(3, n), dtype=torch.uint8, device='cuda')
+    L.check(lib.sg_panoptic_fusion(L.ptr(bits_d), 3, n, L.ptr(order_d), L.ptr(lab_d), L.ptr(sem_d), 10, 0.5, 19,
+                                   11, L.ptr(out), L.ptr(ws), ws.numel(), L.stream()), 'sg_panoptic_fusion')
+    got = out.cpu().numpy().view(np.uint32)
+    want = sem.astype(np.uint32)
+    ids = np.zeros(n, np.uint32)
+    want[10:60], ids[10:60] = 1 + 10, 1
+    want[60:120], ids[60:120] = 3 + 10, 2
+    exp = (want & 0xFFFF) | (ids << 16)
+    exp[(want >= 11) & (ids == 0)] = 19
+    np.testing.assert_array_equal(got, exp)
