@@ -14,6 +14,7 @@ What differs is how the forward is driven:
     [nProposal, N] int masks (reference softgroup.py:568-603).
 """
 import functools
+import os
 import threading
 from collections import OrderedDict
 
@@ -79,7 +80,7 @@ class SoftGroup(nn.Module):
         self.test_cfg = test_cfg
         self.fixed_modules = fixed_modules
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
-        self.use_native_scan = True  # grouping head + proposal voxelisation + instance extraction as
+        self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
         self.scan_contexts = 1       # > 1: model(batch) hands the scan to one of that many worker
