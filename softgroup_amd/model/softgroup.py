@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..spconv import pytorch as spconv
-from ..util import cuda_cast, force_fp32, rle_decode, rle_encode_many, rle_encode_runs, rle_text_to_dicts
+from ..util import cuda_cast, force_fp32, to_host, rle_decode, rle_encode_many, rle_encode_runs, rle_text_to_dicts
 from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
 from .blocks import MLP, ResidualBlock, UBlock
@@ -259,13 +259,18 @@ class SoftGroup(nn.Module):
         #      already enqueues the next scan
         def finish():
             out = {}
+            # every dense per-point result goes to the host in one pinned block with one wait
+            dense = {}
             if 'semantic' in tasks or 'panoptic' in tasks:
-                out.update(semantic_labels=semantic_labels.cpu().numpy(),
-                           instance_labels=instance_labels.cpu().numpy())
+                dense.update(semantic_labels=semantic_labels, instance_labels=instance_labels)
             if 'semantic' in tasks:
-                out.update(self.get_point_wise_results(coords_float, color_feats, semantic_preds,
-                                                       pt_offsets, pt_offset_labels, v2p_map,
-                                                       lvl_fusion))
+                dense.update(self.get_point_wise_results(coords_float, color_feats, semantic_preds,
+                                                         pt_offsets, pt_offset_labels, v2p_map,
+                                                         lvl_fusion, _device=True))
+            if inst is not None and 'instance' in tasks:
+                dense.update(gt_instances=self.get_gt_instances(semantic_labels, instance_labels,
+                                                                _device=True))
+            out.update(to_host(dense))
             if inst is not None:
                 # panoptic fusion runs on the device, on the instances' bit rows, where the native
                 # instance extraction applies; else on the host over the RLE strings
@@ -279,8 +284,7 @@ class SoftGroup(nn.Module):
                 if fuse_native:
                     pred_instances, fused = pred_instances
                 if 'instance' in tasks:
-                    out.update(pred_instances=pred_instances,
-                               gt_instances=self.get_gt_instances(semantic_labels, instance_labels))
+                    out.update(pred_instances=pred_instances)
                 if 'panoptic' in tasks:
                     if fused is None:
                         fused = self.panoptic_fusion(semantic_preds.cpu().numpy(), pred_instances)
@@ -621,14 +625,13 @@ class SoftGroup(nn.Module):
     # ------------------------------------------------------------------ results
     @force_fp32(apply_to=('semantic_preds', 'offset_preds'))
     def get_point_wise_results(self, coords_float, color_feats, semantic_preds, offset_preds,
-                               offset_labels, v2p_map, lvl_fusion):
+                               offset_labels, v2p_map, lvl_fusion, _device=False):
         if lvl_fusion:
             semantic_preds = semantic_preds[v2p_map.long()]
             offset_preds = offset_preds[v2p_map.long()]
-        return dict(coords_float=coords_float.cpu().numpy(), color_feats=color_feats.cpu().numpy(),
-                    semantic_preds=semantic_preds.cpu().numpy(),
-                    offset_preds=offset_preds.cpu().numpy(),
-                    offset_labels=offset_labels.cpu().numpy())
+        res = dict(coords_float=coords_float, color_feats=color_feats, semantic_preds=semantic_preds,
+                   offset_preds=offset_preds, offset_labels=offset_labels)
+        return res if _device else to_host(res)
 
     @force_fp32(apply_to=('semantic_scores', 'cls_scores', 'iou_scores', 'mask_scores'))
     def get_instances(self, scan_id, proposals_idx, semantic_scores, cls_scores, iou_scores,
@@ -799,7 +802,7 @@ class SoftGroup(nn.Module):
         out[ignore] = self.semantic_classes
         return out.astype(np.uint32)
 
-    def get_gt_instances(self, semantic_labels, instance_labels):
+    def get_gt_instances(self, semantic_labels, instance_labels, _device=False):
         """ScanNet encoding sem*1000 + inst, 0 = ignore (reference softgroup.py:641-653)"""
         shift = self.semantic_classes - self.instance_classes
         sem = semantic_labels - shift + 1
@@ -807,7 +810,7 @@ class SoftGroup(nn.Module):
         instance_labels = instance_labels + 1      # (the reference increments its private copy in place)
         gt = sem * 1000 + instance_labels
         gt[instance_labels < 0] = 0
-        return gt.cpu().numpy()
+        return gt if _device else gt.cpu().numpy()
 
     # ------------------------------------------------------------------ training
     @cuda_cast

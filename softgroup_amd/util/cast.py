@@ -59,3 +59,31 @@ def force_fp32(apply_to=None):
         return wrapper
 
     return deco
+
+
+def to_host(tensors):
+    """dict of tensors -> dict of numpy arrays.  All CUDA tensors travel through ONE pinned staging
+    block (torch's caching host allocator recycles it) with asynchronous copies and a single stream
+    synchronisation, instead of one pageable, synchronous ``.cpu()`` per tensor (the reference's
+    result dicts are built that way, softgroup.py:323-360; round 3 counted 31 copy nodes per scan).
+    The arrays are views of the staging block, which they keep alive."""
+    import numpy as np  # noqa: F401
+    out, plan, total = {}, [], 0
+    for k, t in tensors.items():
+        if not t.is_cuda:
+            out[k] = t.numpy()
+            continue
+        t = t.contiguous()
+        nb = t.numel() * t.element_size()
+        plan.append((k, t, total, nb))
+        total += (nb + 255) // 256 * 256
+    if plan:
+        stage = torch.empty(max(total, 256), dtype=torch.uint8, pin_memory=True)
+        for k, t, off, nb in plan:
+            dst = stage[off:off + nb].view(t.dtype).view(t.shape)
+            dst.copy_(t, non_blocking=True)
+            out[k] = dst
+        torch.cuda.current_stream(plan[0][1].device).synchronize()
+        for k, _, _, _ in plan:
+            out[k] = out[k].numpy()
+    return {k: out[k] for k in tensors}
