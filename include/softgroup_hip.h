@@ -230,10 +230,14 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
  *   order[T*32]       : row ids of every tile, -1 padding.  Rows are sorted by their neighbour mask
  *                       with the bits permuted by offset frequency in this layer (rarest offset =
  *                       most significant bit; ties: lower offset is the more common one)
- *   tile_mask[T]      : OR of the masks of the tile's rows
+ *   tile_mask[T + SG_PLAN_HIST_WORDS] : [0, T) OR of the masks of the tile's rows; behind them the
+ *                       histogram hist[j] = number of tiles with j offsets (j = 0..32, rest 0): with the
+ *                       tiles in descending order it tells a conv kernel where any position of the
+ *                       layer's (tile, offset, channel slice) work list lies without a search
  *   nbr_tiles[T*32*K] : the tile's gather-table rows copied contiguously (-1 for padding rows)
  * Row order behind the API is untouched: a tile computes rows order[32t .. 32t+31] and stores
  * them back at their own row index. */
+#define SG_PLAN_HIST_WORDS 40
 size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
 int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
                    uint32_t *tile_mask, int32_t *nbr_tiles, void *ws, size_t ws_bytes,
@@ -252,8 +256,8 @@ int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *orde
  *      sg_spconv_pyramid_build_workspace_bytes(levels, n_levels).
  * levels[l]: rows (in); indices [rows,4]; nbr [rows,27] + plan `subm`; and for l < n_levels-1:
  * in2out [rows]; child [rows_{l+1},8] + plan `down` (strided conv l -> l+1); inv [rows,8] + plan
- * `up` (inverse conv l+1 -> l).  A plan of a table with R rows: order [T*32], tile_mask [T],
- * nbr_tiles [T*32*K], T = ceil(R/32) (see sg_spconv_plan). */
+ * `up` (inverse conv l+1 -> l).  A plan of a table with R rows: order [T*32], tile_mask
+ * [T + SG_PLAN_HIST_WORDS], nbr_tiles [T*32*K], T = ceil(R/32) (see sg_spconv_plan). */
 #define SG_PYRAMID_MAX_LEVELS 10
 typedef struct sg_plan_ptrs {
   int32_t *order;

@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(256) plan_tiles_kernel(const uint32_t *__restr
 // of heavy and light waves instead of a tail of heavy ones (longest-processing-time-first).
 __global__ void __launch_bounds__(1024) plan_tile_order_kernel(const uint32_t *__restrict__ tile_mask,
                                                               int num_tiles,
-                                                              int32_t *__restrict__ tile_order) {
+                                                              int32_t *__restrict__ tile_order,
+                                                              uint32_t *__restrict__ hist_out) {
   // one workgroup: counting sort of the tiles by popcount, descending (order inside a bucket is
   // irrelevant for load balance, so positions come from LDS atomics)
   __shared__ int hist[33], base[33];
@@ -252,6 +253,8 @@ __global__ void __launch_bounds__(1024) plan_tile_order_kernel(const uint32_t *_
     int run = 0;
     for (int b = 32; b >= 0; --b) { base[b] = run; run += hist[b]; }
   }
+  // tiles per number of offsets, behind the plan's tile masks (SG_PLAN_HIST_WORDS words)
+  if (threadIdx.x < SG_PLAN_HIST_WORDS) hist_out[threadIdx.x] = threadIdx.x < 33 ? hist[threadIdx.x] : 0;
   __syncthreads();
   for (int t = threadIdx.x; t < num_tiles; t += 1024)
     tile_order[atomicAdd(&base[__popc(tile_mask[t])], 1)] = t;
@@ -526,6 +529,8 @@ __global__ void __launch_bounds__(1024) plan_tile_order_all_kernel(PlanSegs P, c
     int run = 0;
     for (int b = 32; b >= 0; --b) { base[b] = run; run += hist[b]; }
   }
+  // tiles per number of offsets, behind the segment's final tile masks (SG_PLAN_HIST_WORDS words)
+  if (threadIdx.x < SG_PLAN_HIST_WORDS) S.tile_mask[nt + threadIdx.x] = threadIdx.x < 33 ? hist[threadIdx.x] : 0;
   __syncthreads();
   for (int t0 = 0; t0 < nt; t0 += 1024) {
     if (threadIdx.x < 16 * 33) (&wcnt[0][0])[threadIdx.x] = 0;
@@ -899,7 +904,7 @@ int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *t
   int rc = radix_sort_pairs(mask, row, M, K, rs_ws, rs_bytes, stream, &ms, &rs);
   if (rc != SG_OK) return rc;
   plan_tiles_kernel<<<grid, 256, 0, stream>>>(ms, freq, M, K, tmask);
-  plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tmask, num_tiles, torder);
+  plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tmask, num_tiles, torder, tile_mask + num_tiles);
   plan_emit_kernel<<<min(num_tiles, 4096), 256, 0, stream>>>(nbr, M, K, rs, tmask, torder, num_tiles,
                                                             order, tile_mask, nbr_tiles);
   return check_launch("sg_spconv_plan");

@@ -48,19 +48,21 @@ __global__ void __launch_bounds__(256) concat2_kernel(const float4 *__restrict__
 
 // Trivial plans of the 1x1 convs on the identity branches (kernel volume 1, neighbour = the row
 // itself): order[l][i] = i for i < rows, -1 up to whole 32-row tiles -- with K = 1 the same buffer is
-// the gather table, the plan's row order and its per-tile gather blocks; ones[t] = 1 is every tile's
-// offset mask.  blockIdx.y = level.
+// the gather table, the plan's row order and its per-tile gather blocks; mask[l][t] = 1 is every
+// tile's offset mask (+ the plan's histogram behind them).  blockIdx.y = level.
 struct IdentSegs {
   int32_t *order[SG_PYRAMID_MAX_LEVELS];
+  uint32_t *mask[SG_PYRAMID_MAX_LEVELS];
   int rows[SG_PYRAMID_MAX_LEVELS];
   int n;
 };
-__global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s, uint32_t *ones, int n_ones) {
+__global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s) {
   const int l = blockIdx.y;
-  const int rows = s.rows[l], padded = (rows + 31) / 32 * 32;
+  const int rows = s.rows[l], tiles = (rows + 31) / 32, padded = tiles * 32;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < padded; i += gridDim.x * 256) s.order[l][i] = i < rows ? i : -1;
-  if (l == 0)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_ones; i += gridDim.x * 256) ones[i] = 1u;
+  // every tile has the one offset; histogram behind the masks: hist[1] = tiles
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles + SG_PLAN_HIST_WORDS; i += gridDim.x * 256)
+    s.mask[l][i] = i < tiles ? 1u : (i == tiles + 1 ? static_cast<uint32_t>(tiles) : 0u);
 }
 
 // feature rows zero-padded to `cpad` channels (the input conv on the persistent kernel: Cin % 16 == 0)
@@ -292,18 +294,18 @@ extern "C" {
 static size_t level_index_bytes(size_t rows, size_t rows_next, bool deeper) {
   const size_t t = (rows + 31) / 32, t2 = (rows_next + 31) / 32;
   size_t b = align_up(rows * 4 * 4) + align_up(rows * 27 * 4) +                       // indices, nbr
-             align_up(t * 32 * 4) + align_up((t + 1) * 4) + align_up(t * 32 * 27 * 4);  // subm plan
+             align_up(t * 32 * 4) + align_up((t + SG_PLAN_HIST_WORDS) * 4) + align_up(t * 32 * 27 * 4);  // subm plan
   if (deeper)
     b += align_up(rows * 4) + align_up(rows_next * 8 * 4) + align_up(rows * 8 * 4) +   // in2out, child, inv
-         align_up(t2 * 32 * 4) + align_up((t2 + 1) * 4) + align_up(t2 * 32 * 8 * 4) +   // down plan
-         align_up(t * 32 * 4) + align_up((t + 1) * 4) + align_up(t * 32 * 8 * 4);       // up plan
+         align_up(t2 * 32 * 4) + align_up((t2 + SG_PLAN_HIST_WORDS) * 4) + align_up(t2 * 32 * 8 * 4) +   // down plan
+         align_up(t * 32 * 4) + align_up((t + SG_PLAN_HIST_WORDS) * 4) + align_up(t * 32 * 8 * 4);       // up plan
   return b + 4096;
 }
 static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
   const int L = d->n_levels;
   size_t total = (1 << 20) + sg_spconv_pyramid_workspace_bytes(num_rows, L) +
-                 (L + 1) * (align_up(rows * 4) + 4096);       // trivial plans of the 1x1 convs
+                 (L + 1) * (align_up(rows * 4) + align_up(rows / 8 + 256) + 4096);   // trivial plans of the 1x1 convs
   sg_pyramid_level bound[SG_PYRAMID_MAX_LEVELS];
   for (int l = 0; l < L && l < SG_PYRAMID_MAX_LEVELS; ++l) {
     total += level_index_bytes(rows, rows, l + 1 < L);
@@ -412,7 +414,7 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     SG_IALLOC(indices_l, int32_t, r * 4);
     SG_IALLOC(nbr, int32_t, r * 27);
     SG_IALLOC(so, int32_t, t * 32);
-    SG_IALLOC(sm, uint32_t, t + 1);
+    SG_IALLOC(sm, uint32_t, t + SG_PLAN_HIST_WORDS);
     SG_IALLOC(sn, int32_t, t * 32 * 27);
     P.indices = indices_l; P.nbr = nbr;
     P.subm = sg_plan_ptrs{so, sm, sn};
@@ -426,10 +428,10 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
       SG_IALLOC(child, int32_t, r2 * 8);
       SG_IALLOC(inv, int32_t, r * 8);
       SG_IALLOC(dord, int32_t, t2 * 32);
-      SG_IALLOC(dm, uint32_t, t2 + 1);
+      SG_IALLOC(dm, uint32_t, t2 + SG_PLAN_HIST_WORDS);
       SG_IALLOC(dn, int32_t, t2 * 32 * 8);
       SG_IALLOC(uo, int32_t, t * 32);
-      SG_IALLOC(um, uint32_t, t + 1);
+      SG_IALLOC(um, uint32_t, t + SG_PLAN_HIST_WORDS);
       SG_IALLOC(un, int32_t, t * 32 * 8);
       P.in2out = in2out; P.child = child; P.inv = inv;
       P.down = sg_plan_ptrs{dord, dm, dn};
@@ -448,18 +450,18 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   if (L > 1) {      // trivial plans of the 1x1 convs on the tail's identity branches
     IdentSegs segs;
     segs.n = L - 1;
-    const int n_ones = (num_rows + 31) / 32;
-    SG_IALLOC(ones, uint32_t, n_ones);
     for (int l = 0; l + 1 < L; ++l) {
-      const size_t padded = (static_cast<size_t>(li[l].rows) + 31) / 32 * 32;
-      SG_IALLOC(ord, int32_t, padded ? padded : 32);
+      const size_t tiles = (static_cast<size_t>(li[l].rows) + 31) / 32;
+      SG_IALLOC(ord, int32_t, tiles ? tiles * 32 : 32);
+      SG_IALLOC(tm, uint32_t, tiles + SG_PLAN_HIST_WORDS);
       segs.order[l] = ord;
+      segs.mask[l] = tm;
       segs.rows[l] = li[l].rows;
       Plan &P = li[l].ident;
-      P.nbr = ord; P.order = ord; P.nbr_tiles = ord; P.tile_mask = ones;
+      P.nbr = ord; P.order = ord; P.nbr_tiles = ord; P.tile_mask = tm;
       P.rows = li[l].rows; P.kvol = 1;
     }
-    ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs, ones, n_ones);
+    ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs);
   }
 #undef SG_IALLOC
   if (hipEventRecord(st.ev_index, istream) != hipSuccess ||

@@ -66,6 +66,9 @@ class SparseConvTensor:
 # ------------------------------------------------------------------------------------------------
 # rulebooks
 # ------------------------------------------------------------------------------------------------
+_PLAN_HIST_WORDS = 40     # SG_PLAN_HIST_WORDS (include/softgroup_hip.h)
+
+
 class _Plan:
     """gather table + mask-sorted tile plan for the implicit-GEMM kernel"""
     __slots__ = ('nbr', 'order', 'tile_mask', 'nbr_tiles', 'num_out', 'kvol', '_pairs', '_nbr_t')
@@ -78,7 +81,7 @@ class _Plan:
         self._nbr_t = None
         nt = (num_out + 31) // 32
         self.order = torch.empty(nt * 32, dtype=torch.int32, device=dev)
-        self.tile_mask = torch.empty(nt, dtype=torch.int32, device=dev)
+        self.tile_mask = torch.empty(nt + _PLAN_HIST_WORDS, dtype=torch.int32, device=dev)   # masks + histogram
         self.nbr_tiles = torch.empty(nt * 32 * kvol, dtype=torch.int32, device=dev)
         if num_out:
             nb = lib.sg_spconv_plan_workspace_bytes(num_out)

@@ -46,10 +46,12 @@ def test_subm_rulebook_and_plan_exact():
     assert valid.sum() == M and np.array_equal(np.sort(order[valid]), np.arange(M))
     mask = ((nbr >= 0) << np.arange(27)).sum(1).astype(np.uint32)
     row_mask = np.where(valid, mask[np.clip(order, 0, None)], 0).astype(np.uint32)
-    tm = rule.plan.tile_mask.cpu().numpy().view(np.uint32)
+    tm = rule.plan.tile_mask.cpu().numpy().view(np.uint32)[:T]
     assert np.array_equal(tm, np.bitwise_or.reduce(row_mask, 1))
     pop = np.array([bin(int(x)).count('1') for x in tm])
     assert (np.diff(pop) <= 0).all()                                   # heaviest tiles first
+    hist = rule.plan.tile_mask.cpu().numpy().view(np.uint32)[T:]
+    assert np.array_equal(hist[:33], np.bincount(pop, minlength=33)) and (hist[33:] == 0).all()
     # rows are sorted by the mask with its bits permuted by offset frequency (rarest offset = MSB,
     # ties: lower offset more common); every tile is a contiguous run of that sequence, so the
     # per-tile key ranges are disjoint and sorted
@@ -92,6 +94,9 @@ def test_down_rulebook_exact_incl_odd_extent_drop():
     assert np.array_equal(inv, exp)
 
 
+HIST = 40      # SG_PLAN_HIST_WORDS: the plan's tile-weight histogram behind its T tile masks
+
+
 def _pyramid(idx, shape, n_levels):
     """sg_spconv_pyramid_rows + _build through the C ABI -> per-level dict of numpy arrays"""
     import ctypes as C
@@ -126,13 +131,14 @@ def _pyramid(idx, shape, n_levels):
     for l in range(n_levels):
         r, r2 = rows[l], rows[l + 1] if l + 1 < n_levels else 0
         T, T2 = (r + 31) // 32, (r2 + 31) // 32
-        d = dict(rows=r, indices=buf(r * 4), nbr=buf(r * 27), subm=(buf(T * 32), buf(T), buf(T * 32 * 27)))
+        d = dict(rows=r, indices=buf(r * 4), nbr=buf(r * 27), subm=(buf(T * 32), buf(T + HIST), buf(T * 32 * 27)))
         lv[l].rows = r
         lv[l].indices, lv[l].nbr = d['indices'].data_ptr(), d['nbr'].data_ptr()
         lv[l].subm = PlanPtrs(*[x.data_ptr() for x in d['subm']])
         if l + 1 < n_levels:
             d.update(in2out=buf(r), child=buf(r2 * 8), inv=buf(r * 8),
-                     down=(buf(T2 * 32), buf(T2), buf(T2 * 32 * 8)), up=(buf(T * 32), buf(T), buf(T * 32 * 8)))
+                     down=(buf(T2 * 32), buf(T2 + HIST), buf(T2 * 32 * 8)),
+                     up=(buf(T * 32), buf(T + HIST), buf(T * 32 * 8)))
             lv[l].in2out, lv[l].child, lv[l].inv = (d[k].data_ptr() for k in ('in2out', 'child', 'inv'))
             lv[l].down = PlanPtrs(*[x.data_ptr() for x in d['down']])
             lv[l].up = PlanPtrs(*[x.data_ptr() for x in d['up']])
@@ -159,6 +165,9 @@ def _check_plan(plan, nbr, rows, K):
     assert np.array_equal(tm, np.bitwise_or.reduce(row_mask, 1))
     pop = np.array([bin(int(x)).count('1') for x in tm])
     assert (np.diff(pop) <= 0).all()                                    # heaviest tiles first
+    # histogram of the tile weights behind the masks (hist[j] = tiles with j offsets)
+    hist = tmask[T:T + HIST].view(np.uint32)
+    assert np.array_equal(hist[:33], np.bincount(pop, minlength=33)) and (hist[33:] == 0).all()
     exp = np.where(valid[:, :, None], nbr[np.clip(order, 0, None)], -1)
     assert np.array_equal(ntiles[:T * 32 * K].reshape(T, 32, K), exp)
     # identical row sequence to sg_spconv_plan (tiles of equal weight may be emitted in another order)

@@ -25,7 +25,7 @@ def main():
           f'share of tiles with <=2 / 3-4 / 5-8 / 9-16 / >16 offsets   share of (tile, offset) pairs in tiles > 8')
     for level in range(7):
         rule = core.SubMRule(idx, shape)
-        m = rule.plan.tile_mask.cpu().numpy().astype(np.uint32)
+        m = rule.plan.tile_mask.cpu().numpy().astype(np.uint32)[:(rule.plan.num_out + 31) // 32]
         pc = np.array([bin(int(v)).count('1') for v in m])
         edges = [(0, 2), (3, 4), (5, 8), (9, 16), (17, 27)]
         share = [float(((pc >= lo) & (pc <= hi)).mean()) for lo, hi in edges]
