@@ -997,15 +997,11 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
   // ---- the plan's histogram as a per-lane table: lane k = the class of tiles with k offsets,
   //      tb = tiles of heavier classes (they come first), ip = their items
   const int nk = (lane >= 1 && lane <= 32) ? static_cast<int>(q.hist[lane]) : 0;
-  int tb = 0;
-  unsigned ip = 0;
-  for (int jj = 32; jj >= 1; --jj) {
-    const int n = uni(__shfl(nk, jj, 64));
-    if (lane < jj) {
-      tb += n;
-      ip += static_cast<unsigned>(n) * static_cast<unsigned>(jj * c);
-    }
-  }
+  // suffix sums over the classes above this lane's: total - inclusive prefix (two wave scans)
+  const int pre_t = wave_incl_scan(nk);
+  const int pre_i = wave_incl_scan(nk * lane);
+  const int tb = uni(__shfl(pre_t, 63, 64)) - pre_t;
+  const unsigned ip = static_cast<unsigned>(uni(__shfl(pre_i, 63, 64)) - pre_i) * static_cast<unsigned>(c);
   const unsigned W = static_cast<unsigned>(uni(static_cast<int>(__shfl(static_cast<int>(ip), 0, 64))));   // all items
   if (W == 0u) return;
   // every range must hold items (two raw boundaries may not coincide inside a shared unit): with
@@ -1040,14 +1036,12 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
   if (lo >= hi) return;
   if (u.kk * ns <= q.snap) u.a = 0;           // (lo moved to the unit's start)
 
-  // ---- metadata: this wave's two LDS blocks, filled by LDS-DMA; the mask word is the last piece of a
-  //      block, and pieces land in issue order: a block is complete when its mask word is no longer
-  //      the poison value written before the transfer (no vmcnt drain of this wave's stores needed)
-  constexpr uint32_t kPoison = 0xffffffffu;
+  // ---- metadata: this wave's two LDS blocks, filled by LDS-DMA.  The block of the NEXT tile is
+  //      requested when a tile is entered and waited for (s_waitcnt vmcnt(0)) right after a unit's
+  //      matrix loop, where nothing else of this wave is in flight any more: the wait is free.
+  //      (Polling a word of the block instead was tried first and is wrong: the pieces of a
+  //      transfer do not land in issue order.)
   auto dma_meta = [&](int tile, int buf) {
-    int32_t *blk_lds = meta_w + buf * kMetaInts;
-    if (lane == 0) blk_lds[kMaskAt] = static_cast<int32_t>(kPoison);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned dst = static_cast<unsigned>(uni(static_cast<int>(meta_addr + static_cast<unsigned>(buf * kMetaInts) * 4u)));
     tile = uni(tile);
     const int32_t *blk = p.nbr_tiles + static_cast<long long>(tile) * tileK;
@@ -1059,11 +1053,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
     if (lane < kTileRows) lds_dma_b32(p.order + tile * kTileRows + lane, dst + kRowsAt * 4);
     if (lane == 0) lds_dma_b32(p.tile_mask + tile, dst + kMaskAt * 4);
   };
-  auto wait_meta = [&](int buf) {
-    const volatile int32_t *m = meta_w + buf * kMetaInts + kMaskAt;
-    while (static_cast<uint32_t>(*m) == kPoison) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-  };
+  auto drain = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   struct Slice { f4 a[4]; f4 b[NBW][6]; };
   const int plane_bytes = K * c8 * p.Cout * 16;
@@ -1166,7 +1156,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
   int buf = 0;
   dma_meta(u.tile, 0);
   if (u.tile + 1 < T) dma_meta(u.tile + 1, 1);
-  wait_meta(0);
+  drain();
   unsigned x = lo;
   while (true) {
     const uint32_t mask = static_cast<uint32_t>(uni(meta[kMaskAt]));
@@ -1214,6 +1204,7 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
       }
       if (rem & 1) compute(S[0]);
     }
+    drain();       // operands consumed; the next tile's block (requested a tile ago) has landed
     if (u.a == 0 && b == n_u) {
       finish(col, col_ok);
     } else {
@@ -1225,14 +1216,17 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
       const int first = j_min - 1, last = j_max;
       const bool first_at_start = raw(first) == xs;          // the first sharer starts its range with this unit
       const int my_slot = (u.a > 0 || (j == first && first_at_start)) ? 2 * j : 2 * j + 1;
+      // partial tile of a wave: piece (n, q) = registers 4q .. 4q+3 of column block n, 16 B per lane
       const unsigned slot_bytes = NBW * 16 * 64 * 4;
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[n][r]), rs_part,
-                                                static_cast<unsigned>(lane) * 4u,
-                                                static_cast<unsigned>(my_slot) * slot_bytes + (n * 16 + r) * 256, 16);
+        for (int qd = 0; qd < 4; ++qd) {
+          const f4 v = {acc[n][4 * qd], acc[n][4 * qd + 1], acc[n][4 * qd + 2], acc[n][4 * qd + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                 rs_part, static_cast<unsigned>(lane) * 16u,
+                                                 static_cast<unsigned>(my_slot) * slot_bytes + (n * 4 + qd) * 1024, 16);
+        }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       unsigned arrived = 0;
       if (lane == 0)
@@ -1243,20 +1237,42 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
         for (int n = 0; n < NBW; ++n)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-        for (int jj = first; jj <= last; ++jj) {
-          const int slot = (jj == first && !first_at_start) ? 2 * jj + 1 : 2 * jj;
-          float t[NBW][16];
+        auto slot_of = [&](int jj) { return (jj == first && !first_at_start) ? 2 * jj + 1 : 2 * jj; };
+        auto piece = [&](int slot, int n, int qd) {
+          return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rs_part, static_cast<unsigned>(lane) * 16u,
+                                            static_cast<unsigned>(slot) * slot_bytes + (n * 4 + qd) * 1024, 16));
+        };
+        int jj = first;
+        for (; jj + 3 <= last; jj += 4) {            // four partial tiles in flight, added in wave order
+          f4 t[4][NBW][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) t[i][n][qd] = piece(slot_of(jj + i), n, qd);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[n][4 * qd + e] += t[i][n][qd][e];
+        }
+        for (; jj <= last; ++jj) {
+          f4 t[NBW][4];
 #pragma unroll
           for (int n = 0; n < NBW; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              t[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_part, static_cast<unsigned>(lane) * 4u,
-                                                      static_cast<unsigned>(slot) * slot_bytes + (n * 16 + r) * 256, 16));
+            for (int qd = 0; qd < 4; ++qd) t[n][qd] = piece(slot_of(jj), n, qd);
 #pragma unroll
           for (int n = 0; n < NBW; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] += t[n][r];
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[n][4 * qd + e] += t[n][qd][e];
         }
         finish(col, col_ok);
       }
@@ -1274,7 +1290,6 @@ __global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the old block is no longer being read
       buf ^= 1;
       meta = meta_w + buf * kMetaInts;
-      wait_meta(buf);
       if (u.tile + 1 < T) dma_meta(u.tile + 1, buf ^ 1);
     }
   }
@@ -1651,6 +1666,10 @@ static int launch_stream(ConvArgs a, int num_tiles, long long in_bytes, long lon
   static const int snap_env = getenv("SG_CONV_STREAM_SNAP") ? atoi(getenv("SG_CONV_STREAM_SNAP")) : 8;   // developer knob
   static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;
   *taken = false;
+  // layers with few (tile, column block) pairs stay on the team kernel (their waves share a unit
+  // through LDS, which is cheaper than through memory when every unit is shared by many waves)
+  static const int min_pairs = getenv("SG_CONV_STREAM_MIN_PAIRS") ? atoi(getenv("SG_CONV_STREAM_MIN_PAIRS")) : 0;
+  if (static_cast<long long>(num_tiles) * ((a.Cout + 31) / 32) < min_pairs) return SG_OK;
   const int NB = (a.Cout + 31) / 32;
   const StreamVariant &v = g_stream_variants[(a.Cout % 64 == 0 && nbw_env >= 2) ? 1 : 0];
   a.col_units = (NB + v.nbw - 1) / v.nbw;

@@ -48,7 +48,24 @@ CASES = {
     'scannet_full': dict(forward='scannet', fixed_modules=[]),         # every BatchNorm on batch statistics
     'stpls3d_pp': dict(forward='stpls3d_pp'),                          # semantic_weight, match_low_quality,
     #                                                                    octree + pyramid grouping in training
+    's3dis_fold5': dict(forward='s3dis', x4_split=False),              # BASELINE config 3's own YAML: 13 classes,
+    #                                                                    sem2ins_classes, its fixed_modules; training
+    #                                                                    batches are whole crops (x4_split is test-only)
 }
+
+
+def case_batch(case):
+    """the deterministic scene + batch dict of a training case (generator and tests)"""
+    c = CASES[case]
+    if 'x4_split' not in c:
+        return G.make_case_batch(c['forward'])
+    fc = G.CASES[c['forward']]
+    xyz, rgb, inst = synthetic.scene_s2(**fc['scene'])
+    xyz = (xyz * np.float32(fc['xyz_scale'])).astype(np.float32)
+    if fc.get('one_channel'):
+        rgb = rgb[:, :1].copy()
+    return synthetic.make_batch(xyz, rgb, scale=fc['vox_scale'], instance_labels=inst,
+                                x4_split=c['x4_split']), xyz
 
 
 def case_cfg(case):
@@ -86,10 +103,13 @@ def apply_gt(batch, gt):
 
 
 def main():
+    only = sys.argv[1:]
     for case, c in CASES.items():
+        if only and case not in only:
+            continue
         fc = G.CASES[c['forward']]
         cfg = case_cfg(case)
-        batch, xyz = G.make_case_batch(c['forward'])
+        batch, xyz = case_batch(case)
         sd = synthetic.build_model(cfg, seed=0, device='cpu').state_dict()
         ora = OracleSoftGroup(sd, cfg)
         if fc.get('force_lvl2'):

@@ -313,7 +313,7 @@ def _train_case(case):
     g = np.load(os.path.join(HERE, 'golden', f'ref_train_{case}.npz'))
     fwd = GT.CASES[case]['forward']
     cfg = GT.case_cfg(case)
-    batch, xyz = G.make_case_batch(fwd)
+    batch, xyz = GT.case_batch(case)
     assert abs(np.abs(xyz.astype(np.float64)).sum() - float(g['xyz_checksum'])) < 1e-6, 'scene drifted'
     GT.apply_gt(batch, {k: g[k] for k in ('instance_labels', 'semantic_labels', 'instance_pointnum',
                                           'instance_cls', 'pt_offset_labels')})
