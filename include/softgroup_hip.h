@@ -232,8 +232,8 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
  *                       most significant bit; ties: lower offset is the more common one)
  *   tile_mask[T + SG_PLAN_HIST_WORDS] : [0, T) OR of the masks of the tile's rows; behind them the
  *                       histogram hist[j] = number of tiles with j offsets (j = 0..32, rest 0): with the
- *                       tiles in descending order it tells a conv kernel where any position of the
- *                       layer's (tile, offset, channel slice) work list lies without a search
+ *                       tiles in descending order it gives a consumer the length of the heavy prefix
+ *                       and the position of any (tile, offset) of the list without a search
  *   nbr_tiles[T*32*K] : the tile's gather-table rows copied contiguously (-1 for padding rows)
  * Row order behind the API is untouched: a tile computes rows order[32t .. 32t+31] and stores
  * them back at their own row index. */

@@ -921,380 +921,6 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stream kernel (round 4): the layer as ONE list of (tile, column unit, offset, 32-channel slice)
-// items, cut into equal shares -- one per WAVE, no matter how the items fall into tiles.
-//   * The persistent kernel above gives a unit (tile x column unit) to a team of 2..16 waves: light
-//     tiles (3-5 offsets on the big levels) then pay two workgroup barriers, an LDS reduction and a
-//     set-up per wave for one or two items each, heavy tiles (27 offsets) set the span of the layer,
-//     and layers with few units run as 2.3 "rounds" of which the last is mostly idle
-//     (profiles/r03_conv_trace_w2.txt: fixed cost 5.4 k of a 10.3 k-tick unit on 32->32 x 124 k rows;
-//     heaviest unit 70.8 k of the 89.6 k-tick span on 64->64 x 77 k rows).
-//   * Here every wave owns a contiguous range of the item list (tiles heaviest first, column units
-//     of a tile adjacent, items in (offset, slice) order) and works alone: its own metadata block in
-//     LDS (LDS-DMA, next tile prefetched), its own operand ring, accumulators straight to memory --
-//     no workgroup barrier anywhere.  Where the list is lies in the plan's histogram of tile weights
-//     (tiles per number of offsets, sg_spconv_plan): position -> (tile, column unit, item) is a
-//     33-entry table lookup done in registers, no search and no host round trip (the total number of
-//     items depends on the data and is never known to the host).
-//   * A range boundary that falls inside a LIGHT unit (<= `snap` items) moves to the unit's start;
-//     inside a heavy unit it stays: the unit is then computed by several waves, each writes its
-//     partial 32 x 32 tile write-through (sc1), drains its stores and draws from the unit's arrival
-//     counter; the wave that draws last adds the partial tiles in wave order (fixed: results do not
-//     depend on timing), applies the epilogue and stores -- the split-K reducer recipe of
-//     cdna_hip_programming.md, per wave instead of per workgroup.  Which waves share a unit follows
-//     from the boundaries alone (floor(j W / P)), so every participant computes the same answer.
-//   * consecutive wave indices live on one XCD (blocks b and b + 8 are neighbours in the list), so
-//     the column units of a tile and the halves of a split unit meet in that XCD's L2.
-// Numerics: the same six-product split-precision MFMA sequence per item, items of a unit added in
-// list order within a wave, partial sums in wave order: deterministic, fp32-accurate.
-// ---------------------------------------------------------------------------------------------
-struct StreamArgs {
-  const uint32_t *hist;     // plan histogram: hist[j] = tiles with j offsets (tile_mask + T)
-  float *partial;           // [2 * P][NBW * 16][64]: head / tail partial tile of every wave
-  unsigned *cnt;            // [P] zeroed arrival counters (indexed by the first wave of a split unit)
-  int P;                    // waves of the launch (gridDim.x * 4)
-  int snap;                 // units with at most this many items are never split
-  int n_slices;             // Cin / 32
-  int num_tiles;
-};
-
-template <int NBW, int WPE>
-__global__ void __launch_bounds__(256, WPE) gather_conv_stream_kernel(ConvArgs p, unsigned in_bytes,
-                                                                     unsigned w_bytes, StreamArgs q) {
-  constexpr int WV = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int arow = lane & 31, ahalf = lane >> 5;
-  int32_t *meta_w = reinterpret_cast<int32_t *>(smem_raw) + wave * (2 * kMetaInts);      // [2][kMetaInts]
-  f4 *tr_lds = reinterpret_cast<f4 *>(reinterpret_cast<int32_t *>(smem_raw) + WV * 2 * kMetaInts) + wave * 256;
-  const unsigned meta_addr = __builtin_amdgcn_readfirstlane(
-      static_cast<unsigned>(reinterpret_cast<uintptr_t>(meta_w)));
-  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-
-  const int G = gridDim.x;
-  const int j = G >= 8 ? ((static_cast<int>(blockIdx.x) & 7) * (G >> 3) + (static_cast<int>(blockIdx.x) >> 3)) * WV + wave
-                       : static_cast<int>(blockIdx.x) * WV + wave;
-  const int K = p.K, CU = p.col_units, ns = q.n_slices, T = q.num_tiles;
-  const int c = CU * ns;                      // items of a tile per offset
-  const int c8 = p.Cin / 8;
-  const int tileK = kTileRows * K;
-  const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;
-  const bool add_res = p.residual != nullptr, post = p.post_scale != nullptr, act = p.out_act != nullptr;
-
-  const __amdgpu_buffer_rsrc_t rs_in =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(add_res ? p.residual : p.in), 0, add_res ? out_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
-      act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-      q.partial, 0, static_cast<unsigned>(q.P) * 2u * (NBW * 16 * 64 * 4), 0x00020000);
-
-  // ---- the plan's histogram as a per-lane table: lane k = the class of tiles with k offsets,
-  //      tb = tiles of heavier classes (they come first), ip = their items
-  const int nk = (lane >= 1 && lane <= 32) ? static_cast<int>(q.hist[lane]) : 0;
-  // suffix sums over the classes above this lane's: total - inclusive prefix (two wave scans)
-  const int pre_t = wave_incl_scan(nk);
-  const int pre_i = wave_incl_scan(nk * lane);
-  const int tb = uni(__shfl(pre_t, 63, 64)) - pre_t;
-  const unsigned ip = static_cast<unsigned>(uni(__shfl(pre_i, 63, 64)) - pre_i) * static_cast<unsigned>(c);
-  const unsigned W = static_cast<unsigned>(uni(static_cast<int>(__shfl(static_cast<int>(ip), 0, 64))));   // all items
-  if (W == 0u) return;
-  // every range must hold items (two raw boundaries may not coincide inside a shared unit): with
-  // fewer than 2 items per wave only the first W / 2 waves take part
-  const int P = static_cast<unsigned>(q.P) <= W / 2u ? q.P : static_cast<int>(W / 2u > 0u ? W / 2u : 1u);
-  if (j >= P) return;
-
-  struct Pos { int kk, tile, tile_end, cu, a; };      // item `a` of unit (tile, cu); tiles of class kk end at tile_end
-  auto locate = [&](unsigned x) {
-    const uint64_t hit = __ballot(nk > 0 && ip <= x && x < ip + static_cast<unsigned>(nk) * static_cast<unsigned>(lane * c));
-    Pos r;
-    r.kk = static_cast<int>(__ffsll(static_cast<long long>(hit))) - 1;
-    const int tbk = uni(__shfl(tb, r.kk, 64)), nkk = uni(__shfl(nk, r.kk, 64));
-    const unsigned ipk = static_cast<unsigned>(uni(static_cast<int>(__shfl(static_cast<int>(ip), r.kk, 64))));
-    const unsigned rel = x - ipk, per_tile = static_cast<unsigned>(r.kk * c), per_unit = static_cast<unsigned>(r.kk * ns);
-    const unsigned t_in = rel / per_tile, rem = rel - t_in * per_tile;
-    r.cu = static_cast<int>(rem / per_unit);
-    r.a = static_cast<int>(rem - static_cast<unsigned>(r.cu) * per_unit);
-    r.tile = tbk + static_cast<int>(t_in);
-    r.tile_end = tbk + nkk;
-    return r;
-  };
-  auto raw = [&](int jx) { return static_cast<unsigned>(static_cast<unsigned long long>(jx) * W / static_cast<unsigned>(P)); };
-  auto snapped = [&](unsigned x, Pos &at) {     // boundary rule: never inside a light unit
-    if (x >= W) return W;
-    at = locate(x);
-    return at.kk * ns <= q.snap ? x - static_cast<unsigned>(at.a) : x;
-  };
-  Pos u, dummy;
-  const unsigned lo = snapped(raw(j), u);
-  const unsigned hi = snapped(raw(j + 1), dummy);
-  if (lo >= hi) return;
-  if (u.kk * ns <= q.snap) u.a = 0;           // (lo moved to the unit's start)
-
-  // ---- metadata: this wave's two LDS blocks, filled by LDS-DMA.  The block of the NEXT tile is
-  //      requested when a tile is entered and waited for (s_waitcnt vmcnt(0)) right after a unit's
-  //      matrix loop, where nothing else of this wave is in flight any more: the wait is free.
-  //      (Polling a word of the block instead was tried first and is wrong: the pieces of a
-  //      transfer do not land in issue order.)
-  auto dma_meta = [&](int tile, int buf) {
-    const unsigned dst = static_cast<unsigned>(uni(static_cast<int>(meta_addr + static_cast<unsigned>(buf * kMetaInts) * 4u)));
-    tile = uni(tile);
-    const int32_t *blk = p.nbr_tiles + static_cast<long long>(tile) * tileK;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int e = qd * 256 + lane * 4;
-      if (e < tileK) lds_dma_b128(blk + e, dst + qd * 1024);
-    }
-    if (lane < kTileRows) lds_dma_b32(p.order + tile * kTileRows + lane, dst + kRowsAt * 4);
-    if (lane == 0) lds_dma_b32(p.tile_mask + tile, dst + kMaskAt * 4);
-  };
-  auto drain = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  struct Slice { f4 a[4]; f4 b[NBW][6]; };
-  const int plane_bytes = K * c8 * p.Cout * 16;
-  const int planes_at = 2 * plane_bytes;
-  const int32_t *meta = meta_w;        // block of the current tile
-  int v_w = 0;
-  auto load = [&](int k, int s, Slice &S) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int src = meta[(8 * qd + (lane >> 3)) * K + k];
-      const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + (lane & 7) * 4) * 4u : kOob;
-      S.a[qd] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, 0));
-    }
-    const int s_w = planes_at + (k * c8 + s * 4) * p.Cout * 16;
-#pragma unroll
-    for (int n = 0; n < NBW; ++n)
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          S.b[n][sl * 3 + pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                           rs_w, v_w + n * 512,
-                                                           s_w + sl * (2 * p.Cout * 16) + pl * plane_bytes, 0));
-  };
-  f32x16 acc[NBW];
-  auto compute = [&](Slice &S) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int r = 8 * qd + (lane >> 3);
-      tr_lds[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = S.a[qd];
-    }
-    f4 fr[2][2];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-        fr[sl][jj] = tr_lds[arow * 8 + ((sl * 4 + ahalf * 2 + jj) ^ ((arow >> 1) & 7))];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const float af[8] = {fr[sl][0][0], fr[sl][0][1], fr[sl][0][2], fr[sl][0][3],
-                           fr[sl][1][0], fr[sl][1][1], fr[sl][1][2], fr[sl][1][3]};
-      bf16x8 ah, am, al;
-      split3(af, ah, am, al);
-#pragma unroll
-      for (int n = 0; n < NBW; ++n) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 0]);
-        const bf16x8 bm = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 1]);
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 2]);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
-      }
-    }
-  };
-
-  // ---- epilogue of a complete unit: residual, BatchNorm+ReLU, second output; register r of lane
-  //      half h is tile row (r & 3) + 8 * (r >> 2) + 4 * h, the lane's column is col (+ 32 n)
-  auto finish = [&](int col, bool col_ok) {
-    const int colc = min(col, p.Cout - 1);
-    float ps[NBW], pb[NBW], as[NBW], ab[NBW];
-#pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-      ps[n] = pb[n] = as[n] = ab[n] = 0.f;
-      if (post) { ps[n] = p.post_scale[colc + 32 * n]; pb[n] = p.post_shift[colc + 32 * n]; }
-      if (act) { as[n] = p.act_scale[colc + 32 * n]; ab[n] = p.act_shift[colc + 32 * n]; }
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {          // two sweeps of 8 rows: fewer live registers
-      unsigned off[8];
-      float res[NBW][8];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int reg = half * 8 + r8;
-        const int row = meta[kRowsAt + (reg & 3) + 8 * (reg >> 2) + 4 * ahalf];
-        off[r8] = (row >= 0 && col_ok) ? static_cast<unsigned>(row * p.Cout + col) * 4u : kOob;
-#pragma unroll
-        for (int n = 0; n < NBW; ++n)
-          res[n][r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off[r8], n * 128, 0));
-      }
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int reg = half * 8 + r8;
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) {
-          float t = acc[n][reg] + res[n][r8];
-          if (post) t = fmaxf(fmaf(t, ps[n], pb[n]), 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs_out, off[r8], n * 128, 0);
-          if (act)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(t, as[n], ab[n]), 0.f)),
-                                                  rs_act, off[r8], n * 128, 0);
-        }
-      }
-    }
-  };
-
-  // ---- walk the range
-  int buf = 0;
-  dma_meta(u.tile, 0);
-  if (u.tile + 1 < T) dma_meta(u.tile + 1, 1);
-  drain();
-  unsigned x = lo;
-  while (true) {
-    const uint32_t mask = static_cast<uint32_t>(uni(meta[kMaskAt]));
-    const int n_u = u.kk * ns;
-    const int b = min(n_u, u.a + static_cast<int>(hi - x));
-    const int rem = b - u.a;
-    const int col = u.cu * (32 * NBW) + arow;
-    const bool col_ok = col < p.Cout;
-    v_w = (ahalf * p.Cout + min(col, p.Cout - 1)) * 16;
-    // first item of the segment: offset number a / ns of the mask, slice a % ns
-    int rank = static_cast<int>(p.magic_nsl ? __umulhi(static_cast<unsigned>(u.a), p.magic_nsl) : static_cast<unsigned>(u.a));
-    int s = u.a - rank * ns;
-    uint32_t mm = mask;
-    for (; rank > 0; --rank) mm &= mm - 1u;
-    int k = mm ? __builtin_ctz(mm) : 0;
-    auto advance = [&](int &kk, int &ss) {
-      if (++ss == ns) {
-        ss = 0;
-        const uint32_t rest = mask & ~((2u << kk) - 1u);
-        kk = rest ? __builtin_ctz(rest) : kk;
-      }
-    };
-#pragma unroll
-    for (int n = 0; n < NBW; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    {
-      Slice S[2];
-      load(k, s, S[0]);
-      int kp = k, sp = s, issued = 1;
-      for (int g = rem >> 1; g > 0; --g) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          int k2 = kp, s2 = sp;
-          advance(k2, s2);
-          const bool more = issued < rem;
-          kp = more ? k2 : kp;
-          sp = more ? s2 : sp;
-          ++issued;
-          load(kp, sp, S[i ^ 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          compute(S[i]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (rem & 1) compute(S[0]);
-    }
-    drain();       // operands consumed; the next tile's block (requested a tile ago) has landed
-    if (u.a == 0 && b == n_u) {
-      finish(col, col_ok);
-    } else {
-      // ---- part of a heavy unit: which waves share it follows from the raw boundaries alone
-      const unsigned xs = x - static_cast<unsigned>(u.a), xe = xs + static_cast<unsigned>(n_u);
-      const unsigned long long Pq = static_cast<unsigned long long>(P);
-      const int j_min = static_cast<int>((static_cast<unsigned long long>(xs + 1u) * Pq + W - 1u) / W);   // first boundary > xs
-      const int j_max = static_cast<int>((static_cast<unsigned long long>(xe) * Pq + W - 1u) / W) - 1;    // last boundary < xe
-      const int first = j_min - 1, last = j_max;
-      const bool first_at_start = raw(first) == xs;          // the first sharer starts its range with this unit
-      const int my_slot = (u.a > 0 || (j == first && first_at_start)) ? 2 * j : 2 * j + 1;
-      // partial tile of a wave: piece (n, q) = registers 4q .. 4q+3 of column block n, 16 B per lane
-      const unsigned slot_bytes = NBW * 16 * 64 * 4;
-#pragma unroll
-      for (int n = 0; n < NBW; ++n)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f4 v = {acc[n][4 * qd], acc[n][4 * qd + 1], acc[n][4 * qd + 2], acc[n][4 * qd + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                 rs_part, static_cast<unsigned>(lane) * 16u,
-                                                 static_cast<unsigned>(my_slot) * slot_bytes + (n * 4 + qd) * 1024, 16);
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned arrived = 0;
-      if (lane == 0)
-        arrived = __hip_atomic_fetch_add(q.cnt + first, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      arrived = static_cast<unsigned>(uni(static_cast<int>(arrived)));
-      if (arrived == static_cast<unsigned>(last - first)) {        // last to arrive: reduce in wave order
-#pragma unroll
-        for (int n = 0; n < NBW; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-        auto slot_of = [&](int jj) { return (jj == first && !first_at_start) ? 2 * jj + 1 : 2 * jj; };
-        auto piece = [&](int slot, int n, int qd) {
-          return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rs_part, static_cast<unsigned>(lane) * 16u,
-                                            static_cast<unsigned>(slot) * slot_bytes + (n * 4 + qd) * 1024, 16));
-        };
-        int jj = first;
-        for (; jj + 3 <= last; jj += 4) {            // four partial tiles in flight, added in wave order
-          f4 t[4][NBW][4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n)
-#pragma unroll
-              for (int qd = 0; qd < 4; ++qd) t[i][n][qd] = piece(slot_of(jj + i), n, qd);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n)
-#pragma unroll
-              for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[n][4 * qd + e] += t[i][n][qd][e];
-        }
-        for (; jj <= last; ++jj) {
-          f4 t[NBW][4];
-#pragma unroll
-          for (int n = 0; n < NBW; ++n)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) t[n][qd] = piece(slot_of(jj), n, qd);
-#pragma unroll
-          for (int n = 0; n < NBW; ++n)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[n][4 * qd + e] += t[n][qd][e];
-        }
-        finish(col, col_ok);
-      }
-    }
-    x += static_cast<unsigned>(rem);
-    if (x >= hi) break;
-    // ---- next unit: next column unit of the tile, else the next tile (its block was prefetched)
-    u.a = 0;
-    if (++u.cu == CU) {
-      u.cu = 0;
-      if (++u.tile == u.tile_end) {
-        do --u.kk; while (u.kk > 0 && uni(__shfl(nk, u.kk, 64)) == 0);
-        u.tile_end = u.tile + uni(__shfl(nk, u.kk, 64));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the old block is no longer being read
-      buf ^= 1;
-      meta = meta_w + buf * kMetaInts;
-      if (u.tile + 1 < T) dma_meta(u.tile + 1, buf ^ 1);
-    }
-  }
-}
-
 // fixed-order reduction of the offset-split partial sums (+ residual, post)
 __global__ void __launch_bounds__(256) conv_reduce_kernel(const float4 *__restrict__ partial,
                                                          const float4 *__restrict__ residual,
@@ -1616,84 +1242,6 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
 }
 
 
-// ---- launch of the stream kernel.  Waves: as many as are resident (occupancy x CUs x 4), fewer when
-//      even the densest possible layer of this shape (every tile with all K offsets) would leave a
-//      wave with less than `min_items` items.
-typedef void (*StreamFn)(ConvArgs, unsigned, unsigned, StreamArgs);
-struct StreamVariant {
-  StreamFn fn;
-  int nbw;
-  int occ;
-};
-static StreamVariant g_stream_variants[2] = {{gather_conv_stream_kernel<1, 3>, 1, 0}, {gather_conv_stream_kernel<2, 2>, 2, 0}};
-constexpr size_t kStreamLds = 4 * (2 * kMetaInts * sizeof(int32_t)) + 4 * 4096;
-constexpr int kStreamMaxWaves = 256 * 4 * 8;      // upper bound of P the workspace is priced for (sg_spconv_conv_workspace_bytes)
-
-static size_t stream_partial_bytes(int P, int nbw) { return static_cast<size_t>(P) * 2 * nbw * 16 * 64 * sizeof(float); }
-
-static int stream_waves(int num_tiles, int K, int Cin, int col_units, int num_cu, int occ) {
-  static const int min_items = getenv("SG_CONV_STREAM_MIN") ? atoi(getenv("SG_CONV_STREAM_MIN")) : 4;   // developer knobs
-  static const int wpc_env = getenv("SG_CONV_STREAM_WPC") ? atoi(getenv("SG_CONV_STREAM_WPC")) : 0;     // workgroups per CU
-  const long long bound = static_cast<long long>(num_tiles) * K * (Cin / 32) * col_units;
-  long long g = static_cast<long long>(num_cu) * (wpc_env > 0 && wpc_env < occ ? wpc_env : occ);
-  const long long want = (bound / (min_items > 0 ? min_items : 1) + 3) / 4;
-  if (g > want) g = want;
-  if (g < 1) g = 1;
-  if (g >= 8) g -= g % 8;
-  return static_cast<int>(g) * 4;
-}
-
-static bool g_conv_trace_off() {
-  static const bool off = getenv("SG_CONV_TRACE") == nullptr;
-  return off;
-}
-
-static int launch_stream(ConvArgs a, int num_tiles, long long in_bytes, long long w_bytes, void *ws,
-                         size_t ws_bytes, hipStream_t stream, bool *taken) {
-  static int num_cu = 0;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    int dev = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (num_cu <= 0) num_cu = 256;
-    for (StreamVariant &v : g_stream_variants) {
-      int o = 0;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn, 256, kStreamLds);
-      v.occ = o < 1 ? 1 : o;
-    }
-  });
-  static const int snap_env = getenv("SG_CONV_STREAM_SNAP") ? atoi(getenv("SG_CONV_STREAM_SNAP")) : 8;   // developer knob
-  static const int nbw_env = getenv("SG_CONV_NBW") ? atoi(getenv("SG_CONV_NBW")) : 2;
-  *taken = false;
-  // layers with few (tile, column block) pairs stay on the team kernel (their waves share a unit
-  // through LDS, which is cheaper than through memory when every unit is shared by many waves)
-  static const int min_pairs = getenv("SG_CONV_STREAM_MIN_PAIRS") ? atoi(getenv("SG_CONV_STREAM_MIN_PAIRS")) : 0;
-  if (static_cast<long long>(num_tiles) * ((a.Cout + 31) / 32) < min_pairs) return SG_OK;
-  const int NB = (a.Cout + 31) / 32;
-  const StreamVariant &v = g_stream_variants[(a.Cout % 64 == 0 && nbw_env >= 2) ? 1 : 0];
-  a.col_units = (NB + v.nbw - 1) / v.nbw;
-  a.blocks_per_unit = v.nbw;
-  a.ksplit = 1;
-  const int P = stream_waves(num_tiles, a.K, a.Cin, a.col_units, num_cu, v.occ);
-  const size_t need = stream_partial_bytes(P, v.nbw);
-  if (ws == nullptr || ws_bytes < need || P > kStreamMaxWaves) return SG_OK;      // no scratch: the team kernel runs
-  StreamArgs q;
-  q.hist = a.tile_mask + num_tiles;
-  q.partial = static_cast<float *>(ws);
-  q.cnt = take_done(stream, static_cast<size_t>(P));
-  if (q.cnt == nullptr) return SG_OK;
-  q.P = P;
-  q.snap = snap_env;
-  q.n_slices = a.Cin / 32;
-  q.num_tiles = num_tiles;
-  auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
-  a.magic_nsl = magic(static_cast<unsigned>(a.Cin / 32));
-  v.fn<<<P / 4, 256, kStreamLds, stream>>>(a, static_cast<unsigned>(in_bytes), static_cast<unsigned>(w_bytes), q);
-  *taken = true;
-  return check_launch("sg_spconv_gather_conv_f32(stream)");
-}
-
 }  // namespace sg
 
 using namespace sg;
@@ -1753,14 +1301,11 @@ int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_i
 }
 
 // workspace for the offset-split path: ksplit_max * M_out * Cout floats
-// workspace of a conv call: the partial tiles of the stream kernel (two per wave, priced for the
-// largest launch) or, for the team kernel's offset-split path, ksplit_max * M_out * Cout floats
+// workspace for the offset-split path: ksplit_max * M_out * Cout floats
 size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
   const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
-  const size_t stream_bytes = stream_partial_bytes(256 * 4 * 3, Cout % 64 == 0 ? 2 : 1) + 256;
-  if (num_tiles * ((Cout + 31) / 32) >= 1024) return stream_bytes;   // big layers never split their offsets
-  const size_t split = static_cast<size_t>(kMaxK) * M_out * Cout * sizeof(float) + 256;
-  return split > stream_bytes ? split : stream_bytes;
+  if (num_tiles * ((Cout + 31) / 32) >= 1024) return 256;   // big layers never split
+  return static_cast<size_t>(kMaxK) * M_out * Cout * sizeof(float) + 256;
 }
 
 int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
@@ -1860,17 +1405,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.magic_cu = magic(static_cast<unsigned>(col_units));
   a.magic_nsl = 0;
 
-  // stream kernel (one equal share of the layer's item list per wave): the default wherever the
-  // split-precision line-wise path applies (Cin % 32 == 0); SG_CONV_STREAM=0: the team kernel
-  static const int stream_env = getenv("SG_CONV_STREAM") ? atoi(getenv("SG_CONV_STREAM")) : 1;
-  bool streamed = false;
-  if (split && stream_env != 0 && Cin % 32 == 0 && g_conv_trace_off()) {
-    const int rc = launch_stream(a, num_tiles, in_bytes_ll, w_bytes_ll, ws, ws_bytes, stream, &streamed);
-    if (rc != SG_OK) return rc;
-  }
-  if (streamed) {
-    return SG_OK;
-  } else if (split) {
+  if (split) {
     const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream);
     if (rc != SG_OK) return rc;
   } else if (persistent) {
