@@ -242,6 +242,22 @@ class _TorchOnCpu:
         return attr
 
 
+class _ScalarLog:
+    """stand-in for tensorboardX.SummaryWriter (softgroup/util/logger.py:26-38 subclasses it):
+    keeps every (tag, value, step) of add_scalar in `.scalars`"""
+    last = None
+
+    def __init__(self, *args, **kwargs):
+        self.scalars = []
+        _ScalarLog.last = self
+
+    def add_scalar(self, tag, value, step=None, *args, **kwargs):
+        self.scalars.append((tag, float(value), step))
+
+    def flush(self, *args, **kwargs):
+        pass
+
+
 class NS(dict):
     """config section with attribute access (the reference uses munch.Munch, not installed here)"""
     __getattr__ = dict.get
@@ -257,7 +273,7 @@ def import_reference(ops_module=None, spconv_modules=None):
         del sys.modules[k]
     sys.modules.update(spconv_modules or _spconv_modules())
     tb = types.ModuleType('tensorboardX')
-    tb.SummaryWriter = object
+    tb.SummaryWriter = _ScalarLog          # tensorboardX is not installed: tools/train.py's writer records here
     sys.modules.setdefault('tensorboardX', tb)
     ply = types.ModuleType('plyfile')          # instance_eval_util imports it for file export only
     ply.PlyData = ply.PlyElement = object

@@ -48,7 +48,8 @@ CASES = {
     'scannet_full': dict(forward='scannet', fixed_modules=[]),         # every BatchNorm on batch statistics
     'stpls3d_pp': dict(forward='stpls3d_pp'),                          # semantic_weight, match_low_quality,
     #                                                                    octree + pyramid grouping in training
-    's3dis_fold5': dict(forward='s3dis', x4_split=False),              # BASELINE config 3's own YAML: 13 classes,
+    's3dis_fold5': dict(forward='s3dis', x4_split=False, scene=dict(seed=3, n=50000, room_scale=0.55)),
+    #                                                                    BASELINE config 3's own YAML: 13 classes,
     #                                                                    sem2ins_classes, its fixed_modules; training
     #                                                                    batches are whole crops (x4_split is test-only)
 }
@@ -60,7 +61,8 @@ def case_batch(case):
     if 'x4_split' not in c:
         return G.make_case_batch(c['forward'])
     fc = G.CASES[c['forward']]
-    xyz, rgb, inst = synthetic.scene_s2(**fc['scene'])
+    xyz, rgb, inst = synthetic.scene_s2(**c.get('scene', fc['scene']))      # (a scene big enough for the
+    #                                 S3DIS class means: 0.05 x 1 724 .. 12 210 points per kept cluster)
     xyz = (xyz * np.float32(fc['xyz_scale'])).astype(np.float32)
     if fc.get('one_channel'):
         rgb = rgb[:, :1].copy()
