@@ -62,7 +62,21 @@ def parse():
                     help="'gloo' + --stub: the launch / sharding / timing plumbing on CPU (tests)")
     ap.add_argument('--stub', action='store_true',
                     help='replace the scan by a fixed host-side delay (plumbing test, no GPU)')
+    ap.add_argument('--stub-fail-rank', type=int, default=-1,
+                    help='(tests) this rank raises before the first barrier: the job must exit non-zero')
     return ap.parse_args()
+
+
+def host_thread_plan(contexts, world):
+    """Host threads of one rank: `contexts` scan threads + the results thread + the main thread, no
+    intra-op pools (OMP_NUM_THREADS=1, torch.set_num_threads(1)).  All ranks of the node together
+    stay within half the host cores: contexts is lowered (never below 1) if 8 ranks x (contexts + 2)
+    would not fit -- the line reports what was used."""
+    cores = os.cpu_count() or 1
+    per_rank_budget = max(3, (cores // 2) // max(world, 1))
+    used = max(1, min(contexts, per_rank_budget - 2))
+    return used, {'scan_threads': used, 'results_thread': 1, 'main_thread': 1, 'per_rank': used + 2,
+                  'all_ranks': world * (used + 2), 'host_cores': cores, 'intra_op_threads': 1}
 
 
 def spawn_ranks(args):
@@ -391,6 +405,77 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
     return legs
 
 
+def reference_cpu_ops_leg(model, batch):
+    """the reference's own CPU operators (voxelize_idx, bfs_cluster,
+    build_and_export_octree -- oracle/_ref/sg_ref_ops.so, compiled from /root/reference by
+    oracle/build_ref.py and shipped like our own .so) timed on this box's host on the bench scan:
+    the voxel index of the whole scan (what the DataLoader workers run, data/custom.py:239), the BFS
+    clustering of every grouped class on the neighbour lists the GPU ball query produced (what
+    forward_grouping runs on the host per class, softgroup.py:459-461) and the octree export of the
+    scan's shifted coordinates.  Single thread, like the reference.  None when the library is absent."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    try:
+        import build_ref
+        ref = build_ref.load()
+    except Exception:          # noqa: BLE001  (checker infrastructure: absence is reported, not fatal)
+        ref = None
+    if ref is None:
+        return None
+    from softgroup_amd import ops
+    rec = {'kind': 'reference', 'cores': 1}
+    # ---- voxelize_idx over the scan's voxel coordinates (mode 4, as the dataset calls it)
+    pts = (batch['coords_float'] * 50).long().cpu()
+    coords = torch.cat([torch.zeros(pts.shape[0], 1, dtype=torch.long), pts - pts.min(0)[0]], 1).contiguous()
+    oc, im, om = coords.new(), torch.IntTensor(coords.shape[0]).zero_(), torch.IntTensor()
+    t0 = time.perf_counter()
+    ref.voxelize_idx(coords, oc, im, om, 1, 4)
+    rec['voxelize_idx_s'] = round(time.perf_counter() - t0, 4)
+    rec['voxelize_idx_points'] = int(coords.shape[0])
+    # ---- bfs_cluster per grouped class, on the GPU's neighbour lists
+    g = model.grouping_cfg
+    with torch.no_grad():
+        b = batch
+        feats = torch.cat((b['feats'], b['coords_float']), 1) if model.with_coords else b['feats']
+        import softgroup_amd.spconv.pytorch as spconv
+        vf = ops.voxelization(feats, b['p2v_map'])
+        x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], b['batch_size'])
+        sem, off, _ = model.forward_backbone(x, b['v2p_map'])
+        scores = sem.softmax(-1)
+        mean = torch.tensor(g['class_numpoint_mean'], dtype=torch.float32)
+        bfs_s, edges, members, shifted = 0.0, 0, 0, None
+        for cls in range(model.semantic_classes):
+            if cls in g['ignore_classes']:
+                continue
+            obj = (scores[:, cls] > g['score_thr']).nonzero().view(-1)
+            if obj.numel() < model.test_cfg['min_npoint']:
+                continue
+            c = (b['coords_float'][obj] + off[obj]).contiguous()
+            shifted = c if shifted is None or c.shape[0] > shifted.shape[0] else shifted
+            bi = torch.zeros(obj.numel(), dtype=torch.int32, device=c.device)
+            bo = torch.tensor([0, obj.numel()], dtype=torch.int32, device=c.device)
+            idx, sl = ops.ballquery_batch_p(c, bi, bo, g['radius'], g['mean_active'])
+            idx_h, sl_h = idx.cpu(), sl.cpu()
+            ci, co = torch.IntTensor(), torch.IntTensor()
+            t0 = time.perf_counter()
+            ref.bfs_cluster(mean, idx_h, sl_h, ci, co, sl_h.shape[0], float(g['npoint_thr']), cls)
+            bfs_s += time.perf_counter() - t0
+            edges += int(idx_h.numel())
+            members += int(sl_h.shape[0])
+    rec.update(bfs_cluster_s=round(bfs_s, 4), bfs_cluster_points=members, bfs_cluster_neighbour_pairs=edges)
+    # ---- octree export (SoftGroup++ grouping, functions.py:29) of the largest class's shifted points
+    if shifted is not None:
+        p = shifted.cpu().float().contiguous()
+        mx, mn = p.max(0)[0], p.min(0)[0]
+        xyzwhl = torch.cat([(mx + mn) / 2, mx - mn]).contiguous()
+        boxes, pt_inds = torch.zeros((585, 6)), torch.zeros(p.shape[0], dtype=torch.int32)
+        psl = torch.zeros((512, 2), dtype=torch.int32)
+        t0 = time.perf_counter()
+        ref.build_and_export_octree(p, xyzwhl, boxes, pt_inds, psl, 3)
+        rec.update(octree_build_s=round(time.perf_counter() - t0, 4), octree_points=int(p.shape[0]))
+    return rec
+
+
 def timed_steps(step, resolve, steps, sync_all):
     """the contract's timed region: EXACTLY `steps` steps between two barrier+synchronize brackets.
     Also returns the ms/step of each third of the region (host time stamps taken as results of
@@ -423,6 +508,8 @@ def stub_main(args, rank, world, devices):
         if world > 1:
             dist.barrier()
 
+    if rank == args.stub_fail_rank:
+        raise RuntimeError(f'rank {rank}: injected failure before the first barrier (--stub-fail-rank)')
     for _ in range(args.warmup):
         time.sleep(0.002)
     elapsed, _, windows = timed_steps(lambda: time.sleep(0.002), lambda r: None, args.steps, sync_all)
@@ -435,7 +522,9 @@ def stub_main(args, rank, world, devices):
                           'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub',
-                          'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices}))
+                          'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices,
+                          'host_threads': host_thread_plan(args.contexts, world)[1],
+                          'legs': 'skipped (N>1)' if world > 1 else 'skipped (stub)'}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -491,7 +580,8 @@ def main():
     # forward_test returns as soon as the scan's GPU work is enqueued; turning its results into host
     # objects (numpy arrays, RLE mask strings) runs on the model's results thread and overlaps the
     # next scan.  Every one of the K result dicts is fully materialised inside the timed region.
-    model.scan_contexts = max(1, args.contexts)
+    contexts, host_threads = host_thread_plan(max(1, args.contexts), world)
+    model.scan_contexts = contexts
     with torch.no_grad():
         for r in [model(batch) for _ in range(max(args.warmup, 1))]:
             r.resolve()
@@ -530,7 +620,7 @@ def main():
                           'terms <= 2^-24 |ab|) -- measured against the fp32-MFMA kernel and the oracle '
                           'in parity_at_bench; SG_CONV_SPLIT=0 selects the fp32-MFMA kernel',
         },
-        'ranks_seen': world, 'devices': devices,
+        'ranks_seen': world, 'devices': devices, 'host_threads': host_threads,
         # ms/scan of each third of the timed region on rank 0, and their median
         'ms_per_step_windows': [round(w, 3) for w in windows],
         'ms_per_step_window_median': round(sorted(windows)[len(windows) // 2], 3) if windows else None,
@@ -669,18 +759,25 @@ def main():
         rep = parity.parity_report(model, cpu_batch, synthetic.SCANNET_MODEL_CFG)
         cpu_s = rep.pop('oracle_forward_s')
         out['parity_at_bench'] = rep
+        ref_ops = reference_cpu_ops_leg(model, batch)
         out['cpu_baseline'] = {
             'value': round(1.0 / cpu_s, 4), 'unit': 'scans/s', 'cores': os.cpu_count(),
             'kind': 'port',
             'sample': f'1 scan of the same S2 scene ({args.points} pts): C/OpenMP sparse conv on all '
                       f'cores, single-thread brute-force ball query + BFS like the reference CPU ops; '
-                      f'{cpu_s:.1f} s',
+                      f'{cpu_s:.1f} s.  reference_ops: the reference\'s OWN CPU ops (oracle/_ref/sg_ref_ops.so = '
+                      f'softgroup/ops/src compiled unmodified, 1 thread) on the same scan'
+                      + ('' if ref_ops else ' -- library not on this box, not timed'),
+            'reference_ops': ref_ops,
         }
 
     if rank == 0 and world == 1 and not args.no_legs:
         out.setdefault('legs', {}).update(measurement_legs(args, model, batch, xyz, rgb, inst))
 
     if rank == 0:
+        if world > 1:           # nothing is skipped silently: the single-GPU legs do not run with N > 1
+            out['legs'] = 'skipped (N>1)'
+            out.setdefault('cpu_baseline', 'skipped (N>1)')
         print(json.dumps(out))
     if dist_on:
         dist.barrier()          # leave together: rank 0 was still measuring its extras

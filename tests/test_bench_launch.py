@@ -45,3 +45,41 @@ def test_bench_refuses_rank_count_mismatch():
                         '--steps', '2', '--warmup', '0', '--backend', 'gloo', '--stub'],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'launcher started 2 ranks' in (r.stdout + r.stderr)
+
+
+def test_bench_eight_ranks_on_gloo():
+    """the driver's 8-GPU launch shape on CPU: 8 ranks, 8 distinct devices, ONE JSON line, the host
+    thread plan of all ranks within half the cores, the single-GPU legs reported as skipped"""
+    out = _run([sys.executable, 'bench.py', '--gpus', '8', '--steps', '4', '--warmup', '1', '--backend', 'gloo',
+                '--stub'])
+    assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and len(set(out['devices'])) == 8
+    ht = out['host_threads']
+    assert ht['scan_threads'] >= 1 and ht['per_rank'] == ht['scan_threads'] + 2
+    assert ht['all_ranks'] == 8 * ht['per_rank']
+    assert ht['all_ranks'] <= max(ht['host_cores'] // 2, 8 * 3)
+    assert out['legs'] == 'skipped (N>1)'
+
+
+def test_bench_exits_nonzero_when_a_rank_fails_before_the_first_barrier():
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '4', '--steps', '2', '--warmup', '0', '--backend',
+                        'gloo', '--stub', '--stub-fail-rank', '2'], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert 'injected failure before the first barrier' in (r.stdout + r.stderr)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')], 'no result line from a failed job'
+
+
+def test_host_thread_plan_caps_contexts():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cores = os.cpu_count() or 1
+    used, plan = bench.host_thread_plan(4, 1)
+    assert used == min(4, max(3, cores // 2) - 2) and plan['all_ranks'] == used + 2
+    used8, plan8 = bench.host_thread_plan(4, 8)
+    assert 1 <= used8 <= 4 and plan8['all_ranks'] == 8 * (used8 + 2)
+    assert used8 == max(1, min(4, max(3, (cores // 2) // 8) - 2))
