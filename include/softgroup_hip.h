@@ -121,6 +121,23 @@ int sg_exclusive_scan_startlen(int32_t *start_len, int n, int32_t *meta, void *w
 int sg_octree_build_host(const float *points_host, const float *xyzwhl_host, int num_points,
                          int num_levels, float *boxes_host, int32_t *pt_inds_host,
                          int32_t *pt_start_len_host);
+/* The same export built on the DEVICE (no .cpu() of the coordinates, no host thread): root box =
+ * extent of `points` ((max + min) / 2, max - min), 3 levels, identical boxes / pt_inds / pt_start_len
+ * (start, length per leaf) to sg_octree_build_host with that root.  boxes float [585, 6], pt_inds
+ * int32 [n], pt_start_len int32 [512, 2].  Nothing synchronises. */
+size_t sg_octree_build_workspace_bytes(int n);
+int sg_octree_build(const float *points, int n, float *boxes, int32_t *pt_inds, int32_t *pt_start_len,
+                    void *ws, size_t ws_bytes, sg_stream_t stream);
+/* SoftGroup.pyramid_inverse_map (softgroup/model/softgroup.py:500-507): proposals over a class's level
+ * voxels (proposals_idx int32 [num_pairs, 2] = (proposal, voxel), proposals of a class disjoint) ->
+ * proposals over its points through l2p_map int32 [n_points] (voxel of every point): out_idx int32
+ * [<= n_points, 2] = (proposal, point), proposal-major with points ascending (the row order of the
+ * reference's dense nonzero), out_offsets int32 [n_prop + 1], *n_out_dev = rows written. */
+size_t sg_pyramid_inverse_map_workspace_bytes(int n_points, int n_voxels, int n_prop);
+int sg_pyramid_inverse_map(const int32_t *proposals_idx, int64_t num_pairs, int n_prop,
+                           const int32_t *l2p_map, int n_points, int n_voxels, int32_t *out_idx,
+                           int32_t *out_offsets, int32_t *n_out_dev, void *ws, size_t ws_bytes,
+                           sg_stream_t stream);
 int sg_octree_ballquery_count(const float *points, const float *boxes, const int32_t *pt_inds,
                               const int32_t *pt_start_len, int n, float radius,
                               int32_t *start_len, sg_stream_t stream);

@@ -33,6 +33,10 @@ SIGNATURES = {
     'sg_scan_workspace_bytes': (_sz, [_i]),
     'sg_exclusive_scan_startlen': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     'sg_octree_build_host': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'sg_octree_build_workspace_bytes': (_sz, [_i]),
+    'sg_octree_build': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sg_pyramid_inverse_map_workspace_bytes': (_sz, [_i, _i, _i]),
+    'sg_pyramid_inverse_map': (_i, [_vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_octree_ballquery_count': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     'sg_octree_ballquery_fill': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     'sg_bfs_workspace_bytes': (_sz, [_i, _i64]),

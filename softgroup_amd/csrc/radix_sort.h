@@ -21,7 +21,7 @@ inline size_t radix_sort_workspace_bytes(int64_t n) {
          2 * align_up(n * 4) + 256;
 }
 
-__global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__restrict__ keys,
+static __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__restrict__ keys,
                                                           int64_t n, int shift, int nblk, int items,
                                                           int32_t *__restrict__ hist,
                                                           int32_t *totals) {
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t *__res
   if (totals && h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__restrict__ keys,
+static __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__restrict__ keys,
                                                              const int32_t *__restrict__ vals,
                                                              int64_t n, int shift, int nblk, int items,
                                                              const int32_t *__restrict__ hist,

@@ -533,6 +533,9 @@ class SoftGroup(nn.Module):
         table and one stable sort of the points by proposal give the same rows in O(n) memory."""
         dev = proposals_idx.device
         n_prop = proposals_offset.numel() - 1
+        if proposals_idx.is_cuda and l2p_map.is_cuda:
+            # one C call (table, gather, stable sort by proposal, counts): csrc/octree.hip
+            return ops.pyramid_inverse_map(proposals_idx, n_prop, l2p_map, num_points)
         prop_of_voxel = torch.full((num_points, ), -1, dtype=torch.long, device=dev)
         prop_of_voxel[proposals_idx[:, 1].long()] = proposals_idx[:, 0].long()
         prop_of_point = prop_of_voxel[l2p_map.long().to(dev)]              # [n_orig]

@@ -44,6 +44,30 @@ def octree_ball_query(coords, mean_active, radius):
     """functions.py:14-44.  Octree export on the host (as the reference), walk on the GPU."""
     lib = L.lib()
     dev = _dev(coords)
+    if coords.is_cuda and coords.size(0) > 0:
+        # device-resident coordinates: the octree is built where they are (sg_octree_build: same boxes,
+        # leaf order and leaf ranges as the host export, no .cpu(), no host thread)
+        pts = coords.detach().float().contiguous()
+        n = pts.size(0)
+        boxes = torch.empty((1 + 8 + 64 + 512, 6), dtype=torch.float32, device=dev)
+        pt_inds = torch.empty(n, dtype=torch.int32, device=dev)
+        pt_start_len = torch.empty((512, 2), dtype=torch.int32, device=dev)
+        nb = lib.sg_octree_build_workspace_bytes(n)
+        ws = L.workspace(nb, dev)
+        st = L.stream()
+        L.check(lib.sg_octree_build(L.ptr(pts), n, L.ptr(boxes), L.ptr(pt_inds), L.ptr(pt_start_len),
+                                    L.ptr(ws), ws.numel(), st), 'sg_octree_build')
+        start_len = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        L.check(lib.sg_octree_ballquery_count(L.ptr(pts), L.ptr(boxes), L.ptr(pt_inds),
+                                              L.ptr(pt_start_len), n, float(radius), L.ptr(start_len),
+                                              st), 'sg_octree_ballquery_count')
+        n_totals = _scan_start_len(start_len, n, dev)
+        out_inds = torch.empty(n_totals, dtype=torch.int32, device=dev)
+        L.check(lib.sg_octree_ballquery_fill(L.ptr(pts), L.ptr(boxes), L.ptr(pt_inds),
+                                             L.ptr(pt_start_len), n, float(radius), L.ptr(start_len),
+                                             L.ptr(out_inds), st), 'sg_octree_ballquery_fill')
+        out_inds._sg_flags = LISTS_RADIUS
+        return out_inds, start_len
     coords_cpu = coords.detach().cpu().float().contiguous()
     assert coords_cpu.is_contiguous()
     n = coords_cpu.size(0)
@@ -468,3 +492,23 @@ class GetMaskLabel(Function):
 
 
 get_mask_label = GetMaskLabel.apply
+
+
+def pyramid_inverse_map(proposals_idx, n_prop, l2p_map, n_voxels):
+    """SoftGroup.pyramid_inverse_map (reference softgroup.py:500-507) on the device: proposals over
+    level voxels -> proposals over points.  proposals_idx int32 CUDA [S,2] = (proposal, voxel),
+    l2p_map int32 CUDA [n] = voxel of every point.  -> (pidx int32 [S',2], poff int32 [n_prop+1])."""
+    lib = L.lib()
+    dev = proposals_idx.device
+    pairs = proposals_idx.int().contiguous()
+    l2p = l2p_map.int().contiguous()
+    n = l2p.numel()
+    out_idx = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    out_off = torch.empty(n_prop + 1, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    nb = lib.sg_pyramid_inverse_map_workspace_bytes(n, n_voxels, n_prop)
+    ws = L.workspace(nb, dev)
+    L.check(lib.sg_pyramid_inverse_map(L.ptr(pairs), pairs.size(0), n_prop, L.ptr(l2p), n, n_voxels,
+                                       L.ptr(out_idx), L.ptr(out_off), L.ptr(n_out), L.ptr(ws), ws.numel(),
+                                       L.stream()), 'sg_pyramid_inverse_map')
+    return out_idx[:int(n_out.item())], out_off

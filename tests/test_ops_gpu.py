@@ -471,3 +471,61 @@ def test_row_gather_and_bn_relu_glue(C):
         ref = torch.addcmul(shift, feats, scale)          # one fma per element, like the kernel
         ref = ref.clamp_min(0) if relu else ref
         np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('n', [1, 37, 3000, 150000])
+def test_octree_build_on_the_device_equals_the_host_export(n):
+    """sg_octree_build (device) == sg_octree_build_host == the reference's build_and_export_octree
+    (tests/golden/octree.npz pins the host build): boxes, leaf order, leaf ranges identical"""
+    from softgroup_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(n)
+    pts = (rng.standard_normal((n, 3)) * np.array([4.0, 2.0, 0.7])).astype(np.float32)
+    if n > 100:
+        pts[:50] = pts[0]                           # many points in one leaf
+    t = torch.from_numpy(pts)
+    mx, mn = t.max(0)[0], t.min(0)[0]
+    xyzwhl = torch.cat([(mx + mn) / 2, mx - mn]).contiguous()
+    boxes_h = torch.zeros((585, 6), dtype=torch.float32)
+    inds_h = torch.zeros(n, dtype=torch.int32)
+    sl_h = torch.zeros((512, 2), dtype=torch.int32)
+    L.check(lib.sg_octree_build_host(L.ptr(t), L.ptr(xyzwhl), n, 3, L.ptr(boxes_h), L.ptr(inds_h), L.ptr(sl_h)),
+            'sg_octree_build_host')
+    d = t.cuda()
+    boxes = torch.empty((585, 6), dtype=torch.float32, device='cuda')
+    inds = torch.empty(n, dtype=torch.int32, device='cuda')
+    sl = torch.empty((512, 2), dtype=torch.int32, device='cuda')
+    ws = torch.empty(lib.sg_octree_build_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+    L.check(lib.sg_octree_build(L.ptr(d), n, L.ptr(boxes), L.ptr(inds), L.ptr(sl), L.ptr(ws), ws.numel(),
+                                L.stream()), 'sg_octree_build')
+    assert torch.equal(boxes.cpu(), boxes_h)
+    assert torch.equal(sl.cpu(), sl_h)
+    assert torch.equal(inds.cpu(), inds_h)
+
+
+def test_octree_ball_query_device_and_host_inputs_agree():
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy(rng.random((20000, 3)).astype(np.float32) * 3)
+    a_idx, a_sl = ops.octree_ball_query(pts.cuda(), 300, 0.05)      # device build
+    b_idx, b_sl = ops.octree_ball_query(pts, 300, 0.05)             # host build (CPU input), GPU walk
+    assert torch.equal(a_sl, b_sl) and torch.equal(a_idx, b_idx)
+
+
+def test_pyramid_inverse_map_equals_the_dense_reference_formulation():
+    """ops.pyramid_inverse_map == nonzero of the reference's dense [nProposal, n] matrix
+    (softgroup/model/softgroup.py:500-507), rows (proposal, point) ascending"""
+    rng = np.random.default_rng(2)
+    n_vox, n_pts, n_prop = 5000, 40000, 37
+    l2p = torch.from_numpy(rng.integers(0, n_vox, n_pts).astype(np.int32)).cuda()
+    vox_prop = rng.integers(-1, n_prop, n_vox)                      # -1: voxel in no proposal
+    vox_prop[rng.random(n_vox) < 0.3] = -1
+    sel = np.nonzero(vox_prop >= 0)[0]
+    order = np.lexsort((sel, vox_prop[sel]))
+    pidx = torch.from_numpy(np.stack([vox_prop[sel][order], sel[order]], 1).astype(np.int32)).cuda()
+    got_idx, got_off = ops.pyramid_inverse_map(pidx, n_prop, l2p, n_vox)
+    dense = torch.zeros((n_prop, n_vox), dtype=torch.int32, device='cuda')
+    dense[pidx[:, 0].long(), pidx[:, 1].long()] = 1
+    exp = dense[:, l2p.long()].nonzero()
+    assert torch.equal(got_idx.long(), exp)
+    counts = torch.bincount(exp[:, 0], minlength=n_prop)
+    assert torch.equal(got_off.long(), torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]))
