@@ -586,26 +586,32 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
 
 
 // ---------------------------------------------------------------- D'. giant clusters
-// A cluster with tens of thousands of points (a floor, a wall) has BFS levels with 10^4..10^5
-// edges; replayed by ONE workgroup such a level is bound by a single CU's memory pipe (~45 us).
-// Here `big_wgs` workgroups (32: measured best on a 300k-point room, the barrier grows with the count) replay the cluster together, level by level, with a grid barrier
-// (agent-scope release / counter / acquire, cdna_hip_programming.md Guideline 16) between the
-// three phases of a level:
-//   claim   every edge (frontier rank q, list position p) proposes pos = q*1024 + p (p < 1000) to
+// A cluster with tens of thousands of points (a floor, a wall, a LiDAR ground plane) has BFS levels
+// with 10^4..10^5 edges; replayed by ONE workgroup such a level is bound by a single CU's memory
+// pipe (~45 us).  Here `big_wgs` workgroups replay the cluster together, level by level.
+// Round 3 paid three grid barriers per level (claim | count | append) and tested every edge of a
+// level three times; a 68 k-point floor has ~400 levels of ~17 k edges, so the barriers were the
+// level.  Now TWO synchronisations per level and two edge sweeps:
+//   claim   every edge (frontier rank q, list position p) proposes pos = q * 1024 + p (p < 1000) to
 //           its unvisited target with a device-scope atomicMin -- the same total order as the
-//           sequential queue, so the winner of a node is its BFS parent edge;
-//   count   winners per frontier node (each workgroup owns a contiguous range of the frontier),
-//           one total per workgroup;
-//   append  workgroup b starts at tail + (totals of workgroups < b): winners in (node, position)
-//           order go to the queue and become visited.
-// Every spin is bounded: a barrier that does not complete sets `fail` and all workgroups leave
-// (the host then reports an error instead of hanging the GPU).
+//           sequential queue, so the winner of a node is its BFS parent edge.            [grid barrier]
+//   emit    every workgroup owns a contiguous range of the frontier: it counts the winners of its
+//           nodes, takes a region of that size out of the level's staging pool with ONE atomicAdd
+//           (regions land in arbitrary order; the pool holds at most the cluster's points), writes
+//           its winners there in (node, position) order, marks them visited, and publishes (region
+//           offset, length) tagged with the level number.                 [wait for all G records]
+//   The next frontier is the concatenation of the regions in WORKGROUP order -- exactly the order
+//   the sequential queue produces -- so no global prefix over winners is ever needed before the
+//   write; ranks follow from the G lengths every workgroup reads anyway.  The output queue gets
+//   each region as a copy once its position (tail + lengths of the workgroups before) is known.
+// Every spin is bounded: a barrier / wait that does not complete sets `fail` and all workgroups
+// leave (the giant clusters are then replayed by the per-cluster kernel, gated on the device).
 constexpr int kBigWgsMax = 256;
 constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
 
-// Everything the workgroups exchange (queue, claims, per-node counts, per-workgroup totals) is
-// written with device-scope write-through stores / atomics and read with sc1 loads that bypass the
-// CU's L1 (SG_ST / SG_LD / atomicMin), so the barrier needs no L2 write-back or L1 invalidate
+// Everything the workgroups exchange (frontier regions, claims, records) is written with
+// device-scope write-through stores / atomics and read with sc1 loads that bypass the CU's L1
+// (SG_ST / SG_LD / atomicMin), so the barrier needs no L2 write-back or L1 invalidate
 // (Guideline 16, form R1): every wave drains its stores, one lane arrives and polls.
 __device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *fail, int *lds_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -632,58 +638,134 @@ __device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *f
   return *lds_flag != 0;
 }
 
+// sync words: [0] barrier counter, [1] fail, [2..3] staging pool heads (per parity),
+// [64 ..] records: rec[parity][workgroup] = two self-validating 64-bit words (tag << 32 | value):
+// region offset and region length
+constexpr int kBigRecAt = 64;
+
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
-    int32_t *owner_g, int32_t *wcnt, int32_t *cluster_idxs, int32_t *sync /* [0] barrier [1] fail [2..] totals */) {
+    int32_t *owner_g, int32_t *wcnt, int32_t *stage0, int32_t *stage1, int32_t *cluster_idxs, int32_t *sync) {
   __shared__ int lds_scan[kEmitWaves];
-  __shared__ int lds_flag, lds_base, lds_total;
+  __shared__ int lds_flag, lds_off;
   __shared__ int node_off[kEmitThreads];
+  __shared__ int pre[kBigWgsMax + 1], offs[kBigWgsMax];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int G = gridDim.x, b = blockIdx.x;
-  int32_t *bar = sync, *fail = sync + 1, *tot = sync + 64;      // tot[2][G]
-  int epoch = 0, parity = 0;
+  int32_t *bar = sync, *fail = sync + 1, *pool = sync + 2;
+  unsigned long long *rec = reinterpret_cast<unsigned long long *>(sync + kBigRecAt);     // [2][G][2]
+  int epoch = 0;
+  unsigned tag = 0;            // level counter over the whole launch (never 0 in a record)
   for (int c = 0; c < n_cluster; ++c) {
     const int off = cluster_offsets[c];
     const int size = cluster_offsets[c + 1] - off;
     if (size <= kBigMin) continue;                               // uniform over the grid
     const int seed = seeds[c];
     int32_t *Q = cluster_idxs + 2LL * off;
-    if (b == 0 && threadIdx.x == 0) {
-      SG_ST(&Q[0], c);
-      SG_ST(&Q[1], seed);
-      SG_ST(&owner_g[seed], -1);
+    int par = 0;
+    ++tag;
+    // ---- level 0: the seed is workgroup 0's region of parity 0
+    if (threadIdx.x == 0) {
+      if (b == 0) {
+        SG_ST(&stage0[0], seed);
+        SG_ST(&Q[0], c);
+        SG_ST(&Q[1], seed);
+        SG_ST(&owner_g[seed], -1);
+        SG_ST(&pool[0], 1);
+        SG_ST(&pool[1], 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&rec[(0 * G + b) * 2], (static_cast<unsigned long long>(tag) << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rec[(0 * G + b) * 2 + 1], (static_cast<unsigned long long>(tag) << 32) | (b == 0 ? 1u : 0u),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
-    int head = 0, tail = 1;
-    while (head < tail) {
-      const int L = tail - head;
+    int tail = 0;       // queue entries written so far (the seed is counted with its level below)
+    while (true) {
+      // ---- wait for the G records of the current frontier, then ranks: pre[w] = nodes before workgroup w
+      if (wave == 0) {
+        int ok = 1;
+        for (int w0 = 0; w0 < G; w0 += 64) {
+          const int w = w0 + lane;
+          unsigned long long a = 0, l = 0;
+          unsigned spins = 0;
+          while (true) {
+            bool ready = true;
+            if (w < G) {
+              a = __hip_atomic_load(&rec[(par * G + w) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              l = __hip_atomic_load(&rec[(par * G + w) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ready = (a >> 32) == tag && (l >> 32) == tag;
+            }
+            if (__all(ready)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u &&
+                (spins > (1u << 24) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = 0;
+              break;
+            }
+          }
+          if (w < G) {
+            offs[w] = static_cast<int>(a & 0xffffffffu);
+            pre[w + 1] = static_cast<int>(l & 0xffffffffu);      // lengths first, prefix below
+          }
+          if (!ok) break;
+        }
+        if (lane == 0) lds_flag = ok;
+      }
+      __syncthreads();
+      if (!lds_flag) return;
+      if (threadIdx.x == 0) {
+        pre[0] = 0;
+        for (int w = 0; w < G; ++w) pre[w + 1] += pre[w];
+      }
+      __syncthreads();
+      const int L = pre[G];
+      const int my_pos = pre[b], my_len = pre[b + 1] - pre[b];
+      int32_t *cur = par ? stage1 : stage0, *nxt = par ? stage0 : stage1;
+      // ---- this workgroup's region of the current frontier goes to the output queue
+      for (int i = threadIdx.x; i < my_len; i += kEmitThreads) {
+        SG_ST(&Q[2 * (tail + my_pos + i)], c);
+        SG_ST(&Q[2 * (tail + my_pos + i) + 1], SG_LD(&cur[offs[b] + i]));
+      }
+      tail += L;
+      if (L == 0) break;                                           // cluster complete (uniform)
       const int lo = static_cast<int>(static_cast<long long>(L) * b / G);
       const int hi = static_cast<int>(static_cast<long long>(L) * (b + 1) / G);
+      auto node_at = [&](int q) {                                  // frontier rank -> point id
+        int w0 = 0, w1 = G;                                        // last w with pre[w] <= q
+        while (w1 - w0 > 1) {
+          const int mid = (w0 + w1) >> 1;
+          if (pre[mid] <= q) w0 = mid; else w1 = mid;
+        }
+        return SG_LD(&cur[offs[w0] + (q - pre[w0])]);
+      };
       // ---- claim
       for (int q = lo + wave; q < hi; q += kEmitWaves) {
-        const int v = SG_LD(&Q[2 * (head + q) + 1]);
-        const int4 rec = node_rec[v];
-        for (int p = lane; p < rec.w; p += 64) {
-          const int g = rec.z + p;
+        const int v = node_at(q);
+        const int4 r = node_rec[v];
+        for (int p = lane; p < r.w; p += 64) {
+          const int g = r.z + p;
           if ((erec[g].x & 0xffff) == 0xffff) continue;          // target in another cluster
           const int t = idx[g];
           const int pos = (q << 10) | p;
           if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
         }
       }
+      if (b == 0 && threadIdx.x == 0) SG_ST(&pool[par ^ 1], 0);   // next level's pool (idle since two levels)
       if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
-      // ---- count
+      // ---- emit, pass 1: winners per node of this workgroup's range
       int my_total = 0;
       for (int q = lo + wave; q < hi; q += kEmitWaves) {
-        const int v = SG_LD(&Q[2 * (head + q) + 1]);
-        const int4 rec = node_rec[v];
+        const int v = node_at(q);
+        const int4 r = node_rec[v];
         int wins = 0;
-        for (int p0 = 0; p0 < rec.w; p0 += 64) {
+        for (int p0 = 0; p0 < r.w; p0 += 64) {
           const int p = p0 + lane;
           bool win = false;
-          if (p < rec.w) {
-            const int g = rec.z + p;
+          if (p < r.w) {
+            const int g = r.z + p;
             if ((erec[g].x & 0xffff) != 0xffff) win = SG_LD(&owner_g[idx[g]]) == ((q << 10) | p);
           }
           wins += __popcll(__ballot(win));
@@ -692,28 +774,20 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         my_total += wins;                                        // per wave (uniform over its lanes)
       }
       if (lane == 0) lds_scan[wave] = my_total;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
         int t = 0;
         for (int w = 0; w < kEmitWaves; ++w) t += lds_scan[w];
-        SG_ST(&tot[parity * G + b], t);
-      }
-      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
-      // ---- append
-      if (threadIdx.x == 0) {
-        int base = 0, total = 0;
-        for (int w = 0; w < G; ++w) {
-          const int t = SG_LD(&tot[parity * G + w]);
-          if (w < b) base += t;
-          total += t;
-        }
-        lds_base = base;
-        lds_total = total;
+        lds_off = t > 0 ? __hip_atomic_fetch_add(&pool[par ^ 1], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        lds_scan[0] = t;
       }
       __syncthreads();
-      const int total_new = lds_total;
-      int carry = tail + lds_base;
-      for (int c0 = lo; c0 < hi; c0 += kEmitThreads) {            // this workgroup's nodes, 512 at a time
+      const int region = lds_off, region_len = lds_scan[0];
+      __syncthreads();
+      // ---- emit, pass 2: winners in (node, position) order into the region; they become visited
+      int carry = region;
+      for (int c0 = lo; c0 < hi; c0 += kEmitThreads) {
         const int q_mine = c0 + threadIdx.x;
         const int cnt = q_mine < hi ? SG_LD(&wcnt[q_mine]) : 0;
         int chunk_total;
@@ -721,17 +795,17 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         node_off[threadIdx.x] = carry + ex;
         __syncthreads();
         const int n_here = min(kEmitThreads, hi - c0);
-        for (int j = wave; j < n_here; j += kEmitWaves) {
-          const int q = c0 + j;
-          const int v = SG_LD(&Q[2 * (head + q) + 1]);
-          const int4 rec = node_rec[v];
-          int o = node_off[j];
-          for (int p0 = 0; p0 < rec.w; p0 += 64) {
+        for (int jn = wave; jn < n_here; jn += kEmitWaves) {
+          const int q = c0 + jn;
+          const int v = node_at(q);
+          const int4 r = node_rec[v];
+          int o = node_off[jn];
+          for (int p0 = 0; p0 < r.w; p0 += 64) {
             const int p = p0 + lane;
             bool win = false;
             int t = 0;
-            if (p < rec.w) {
-              const int g = rec.z + p;
+            if (p < r.w) {
+              const int g = r.z + p;
               if ((erec[g].x & 0xffff) != 0xffff) {
                 t = idx[g];
                 win = SG_LD(&owner_g[t]) == ((q << 10) | p);
@@ -739,9 +813,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
             }
             const uint64_t bal = __ballot(win);
             if (win) {
-              const int dst = o + mask_prefix(bal);
-              SG_ST(&Q[2 * dst], c);
-              SG_ST(&Q[2 * dst + 1], t);
+              SG_ST(&nxt[o + mask_prefix(bal)], t);
               SG_ST(&owner_g[t], -1);                            // only this edge matches pos
             }
             o += __popcll(bal);
@@ -750,11 +822,21 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         carry += chunk_total;
         __syncthreads();
       }
-      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
-      head = tail;
-      tail += total_new;
-      parity ^= 1;
+      // ---- publish this workgroup's region of the next frontier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      ++tag;
+      par ^= 1;
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&rec[(par * G + b) * 2], (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(region),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec[(par * G + b) * 2 + 1],
+                           (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(region_len),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    // (all workgroups leave a cluster together: the records of its last, empty level were seen by all)
+    if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
   }
 }
 
@@ -875,14 +957,16 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
     static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 32;   // developer knob
     const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
-    int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 2 * kBigWgsMax ints
-    if (static_cast<size_t>(n) >= 64 + 2 * kBigWgsMax) {
-      hipMemsetAsync(sync, 0, (64 + 2 * kBigWgsMax) * 4, stream);
+    int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 8 * kBigWgsMax ints
+    if (static_cast<size_t>(n) >= 64 + 8 * kBigWgsMax) {
+      hipMemsetAsync(sync, 0, (64 + 8 * kBigWgsMax) * 4, stream);
       if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))      // test hook: pretend the barrier gave up
         if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
+      // frontier staging pools (one per level parity, at most a cluster's points each): the union-find
+      // arrays of the labelling, idle by now
       bfs_emit_big_kernel<<<big_wgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
                                                               cluster_offsets, n_cluster, w.owner,
-                                                              w.wcnt, cluster_idxs, sync);
+                                                              w.wcnt, w.parent, w.lab, cluster_idxs, sync);
       // sync[1] != 0: the replay gave up somewhere (see big_barrier) -- redo the giant clusters on
       // the per-cluster kernel (same output, slower); both launches are no-ops otherwise
       bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin,
