@@ -608,6 +608,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
 // leave (the giant clusters are then replayed by the per-cluster kernel, gated on the device).
 constexpr int kBigWgsMax = 256;
 constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
+constexpr int kBigNodes = 1024;         // frontier nodes / edges of a workgroup's range that the cached level holds
+constexpr int kBigEdges = 8192;
 
 // Everything the workgroups exchange (frontier regions, claims, records) is written with
 // device-scope write-through stores / atomics and read with sc1 loads that bypass the CU's L1
@@ -651,6 +653,11 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
   __shared__ int lds_flag, lds_off;
   __shared__ int node_off[kEmitThreads];
   __shared__ int pre[kBigWgsMax + 1], offs[kBigWgsMax];
+  // cached level (this workgroup's range has <= kBigNodes nodes and <= kBigEdges edges, the usual
+  // case): list starts and edge bases of its nodes and the target of every edge stay in LDS from
+  // the claim sweep to the emit sweep, which then costs ONE memory round trip (the claim words)
+  __shared__ int c_st[kBigNodes], c_eb[kBigNodes + 1];
+  __shared__ int c_t[kBigEdges];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int G = gridDim.x, b = blockIdx.x;
   int32_t *bar = sync, *fail = sync + 1, *pool = sync + 2;
@@ -742,19 +749,116 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         return SG_LD(&cur[offs[w0] + (q - pre[w0])]);
       };
       // ---- claim
-      for (int q = lo + wave; q < hi; q += kEmitWaves) {
-        const int v = node_at(q);
-        const int4 r = node_rec[v];
-        for (int p = lane; p < r.w; p += 64) {
-          const int g = r.z + p;
-          if ((erec[g].x & 0xffff) == 0xffff) continue;          // target in another cluster
-          const int t = idx[g];
-          const int pos = (q << 10) | p;
-          if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+      const int nn = hi - lo;
+      int E = -1;                                                  // >= 0: cached level with E edges
+      if (nn <= kBigNodes) {
+        int carry = 0;
+        for (int i0 = 0; i0 < nn; i0 += kEmitThreads) {
+          const int i = i0 + threadIdx.x;
+          int ln = 0;
+          if (i < nn) {
+            const int4 r = node_rec[node_at(lo + i)];
+            c_st[i] = r.z;
+            ln = r.w;
+          }
+          int tot;
+          const int ex = wg_excl_scan(ln, lds_scan, &tot);
+          if (i < nn) c_eb[i] = carry + ex;
+          carry += tot;
+        }
+        if (threadIdx.x == 0) c_eb[nn] = carry;
+        __syncthreads();
+        if (carry <= kBigEdges) E = carry;
+      }
+      auto edge_node = [&](int e) {                                // last j with c_eb[j] <= e (lists may be empty)
+        int j0 = 0, j1 = nn;
+        while (j1 - j0 > 1) {
+          const int mid = (j0 + j1) >> 1;
+          if (c_eb[mid] <= e) j0 = mid; else j1 = mid;
+        }
+        return j0;
+      };
+      if (E >= 0) {
+        for (int e = threadIdx.x; e < E; e += kEmitThreads) {      // flat over the range's edges
+          const int jn = edge_node(e);
+          const int p = e - c_eb[jn], g = c_st[jn] + p;
+          int t = -1;
+          if ((erec[g].x & 0xffff) != 0xffff) {                    // else: target in another cluster
+            t = idx[g];
+            const int pos = ((lo + jn) << 10) | p;
+            if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+          }
+          c_t[e] = t;
+        }
+      } else {
+        for (int q = lo + wave; q < hi; q += kEmitWaves) {
+          const int v = node_at(q);
+          const int4 r = node_rec[v];
+          for (int p = lane; p < r.w; p += 64) {
+            const int g = r.z + p;
+            if ((erec[g].x & 0xffff) == 0xffff) continue;          // target in another cluster
+            const int t = idx[g];
+            const int pos = (q << 10) | p;
+            if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+          }
         }
       }
       if (b == 0 && threadIdx.x == 0) SG_ST(&pool[par ^ 1], 0);   // next level's pool (idle since two levels)
       if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      if (E >= 0) {
+        // ---- emit of a cached level: one sweep over the claim words decides the winners (losers and
+        //      foreign targets become -1 in LDS), one atomicAdd takes the region, one LDS-only sweep
+        //      writes the winners in edge order = (node, position) order
+        int total = 0;
+        for (int e0 = 0; e0 < E; e0 += kEmitThreads) {
+          const int e = e0 + threadIdx.x;
+          bool win = false;
+          if (e < E) {
+            const int t = c_t[e];
+            if (t >= 0) {
+              const int jn = edge_node(e);
+              win = SG_LD(&owner_g[t]) == (((lo + jn) << 10) | (e - c_eb[jn]));
+            }
+            if (!win) c_t[e] = -1;
+          }
+          total += __popcll(__ballot(win));
+        }
+        if (lane == 0) lds_scan[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          int t = 0;
+          for (int w = 0; w < kEmitWaves; ++w) t += lds_scan[w];
+          lds_off = t > 0 ? __hip_atomic_fetch_add(&pool[par ^ 1], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          lds_scan[0] = t;
+        }
+        __syncthreads();
+        const int region = lds_off, region_len = lds_scan[0];
+        __syncthreads();
+        int carry = region;
+        for (int e0 = 0; e0 < E; e0 += kEmitThreads) {
+          const int e = e0 + threadIdx.x;
+          const int t = e < E ? c_t[e] : -1;
+          int tot;
+          const int ex = wg_excl_scan(t >= 0 ? 1 : 0, lds_scan, &tot);
+          if (t >= 0) {
+            SG_ST(&nxt[carry + ex], t);
+            SG_ST(&owner_g[t], -1);                                // only this edge matches pos
+          }
+          carry += tot;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++tag;
+        par ^= 1;
+        if (threadIdx.x == 0) {
+          __hip_atomic_store(&rec[(par * G + b) * 2], (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(region),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&rec[(par * G + b) * 2 + 1],
+                             (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(region_len),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;
+      }
       // ---- emit, pass 1: winners per node of this workgroup's range
       int my_total = 0;
       for (int q = lo + wave; q < hi; q += kEmitWaves) {

@@ -215,40 +215,35 @@ __global__ void __launch_bounds__(256) pim_scatter_kernel(const int32_t *__restr
 }
 __global__ void __launch_bounds__(256) pim_key_kernel(const int32_t *__restrict__ prop_of_voxel,
                                                      const int32_t *__restrict__ l2p, int n, int n_prop,
-                                                     uint32_t *__restrict__ key, int32_t *__restrict__ val,
-                                                     int32_t *__restrict__ cnt) {
+                                                     uint32_t *__restrict__ key, int32_t *__restrict__ val) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int p = prop_of_voxel[l2p[i]];
     key[i] = p >= 0 ? static_cast<uint32_t>(p) : static_cast<uint32_t>(n_prop);
     val[i] = i;
-    if (p >= 0) atomicAdd(&cnt[p], 1);
   }
 }
+// rows in sorted order; the offsets are the positions where the sorted key changes (a proposal's
+// rows start where its key first appears; keys nobody has -- none in practice, every proposal owns
+// a voxel with a point -- get the position of the next larger key), n_out = first unassigned row
 __global__ void __launch_bounds__(256) pim_emit_kernel(const uint32_t *__restrict__ key, const int32_t *__restrict__ val,
-                                                      int n, int n_prop, const int32_t *__restrict__ cnt,
-                                                      int32_t *__restrict__ out_idx, int32_t *__restrict__ out_off,
-                                                      int32_t *__restrict__ n_out) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-    if (key[i] < static_cast<uint32_t>(n_prop)) {
-      out_idx[2LL * i] = static_cast<int32_t>(key[i]);
+                                                      int n, int n_prop, int32_t *__restrict__ out_idx,
+                                                      int32_t *__restrict__ out_off, int32_t *__restrict__ n_out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t k = key[i];
+    if (k < static_cast<uint32_t>(n_prop)) {
+      out_idx[2LL * i] = static_cast<int32_t>(k);
       out_idx[2LL * i + 1] = val[i];
     }
-  if (blockIdx.x == 0) {               // offsets: running sum of the counts (one workgroup)
-    __shared__ int lds4[4];
-    int carry = 0;
-    for (int base = 0; base < n_prop; base += 256) {
-      const int p = base + threadIdx.x;
-      const int c = p < n_prop ? cnt[p] : 0;
-      int tot;
-      const int incl = block_incl_scan_256(c, lds4, &tot);
-      if (p < n_prop) out_off[p + 1] = carry + incl;
-      carry += tot;
-    }
-    if (threadIdx.x == 0) {
-      out_off[0] = 0;
-      *n_out = carry;
+    const int prev = i > 0 ? static_cast<int>(key[i - 1]) : -1;
+    for (int p = prev + 1; p <= static_cast<int>(k) && p <= n_prop; ++p) out_off[p] = i;
+    if (k >= static_cast<uint32_t>(n_prop) && prev < n_prop) *n_out = i;
+    if (i == n - 1 && k < static_cast<uint32_t>(n_prop)) {
+      for (int p = static_cast<int>(k) + 1; p <= n_prop; ++p) out_off[p] = n;
+      *n_out = n;
     }
   }
+  if (n == 0 && blockIdx.x == 0)
+    for (int p = threadIdx.x; p <= n_prop; p += 256) out_off[p] = 0;
 }
 
 }  // namespace sg
@@ -328,24 +323,23 @@ int sg_pyramid_inverse_map(const int32_t *proposals_idx, int64_t num_pairs, int 
   uint32_t *key = a.take<uint32_t>(n_points > 0 ? n_points : 1);
   int32_t *val = a.take<int32_t>(n_points > 0 ? n_points : 1);
   int32_t *pov = a.take<int32_t>(n_voxels > 0 ? n_voxels : 1);
-  int32_t *cnt = a.take<int32_t>(static_cast<size_t>(n_prop) + 2);
   const size_t rs_bytes = radix_sort_workspace_bytes(n_points);
   void *rs_ws = a.take<char>(rs_bytes);
   hipMemsetAsync(pov, 0xff, static_cast<size_t>(n_voxels > 0 ? n_voxels : 1) * 4, stream);
-  hipMemsetAsync(cnt, 0, (static_cast<size_t>(n_prop) + 2) * 4, stream);
   if (num_pairs > 0)
     pim_scatter_kernel<<<grid_for(num_pairs, 256, 2048), 256, 0, stream>>>(proposals_idx, num_pairs, pov);
   uint32_t *ks = key;
   int32_t *vs = val;
   if (n_points > 0) {
-    pim_key_kernel<<<grid_for(n_points, 256, 2048), 256, 0, stream>>>(pov, l2p_map, n_points, n_prop, key, val, cnt);
+    pim_key_kernel<<<grid_for(n_points, 256, 2048), 256, 0, stream>>>(pov, l2p_map, n_points, n_prop, key, val);
     int bits = 1;
     while ((1 << bits) <= n_prop) ++bits;
     const int rc = radix_sort_pairs(key, val, n_points, bits, rs_ws, rs_bytes, stream, &ks, &vs);
     if (rc != SG_OK) return rc;
   }
-  pim_emit_kernel<<<grid_for(n_points > 0 ? n_points : 1, 256, 2048), 256, 0, stream>>>(ks, vs, n_points, n_prop, cnt,
-                                                                                       out_idx, out_offsets, n_out_dev);
+  hipMemsetAsync(n_out_dev, 0, 4, stream);
+  pim_emit_kernel<<<grid_for(n_points > 0 ? n_points : 1, 256, 2048), 256, 0, stream>>>(ks, vs, n_points, n_prop, out_idx,
+                                                                                       out_offsets, n_out_dev);
   return check_launch("sg_pyramid_inverse_map");
 }
 

@@ -453,13 +453,18 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   // row (CK = 32: the half-wave pair reads the row's whole 128-B line in one slice) and the
   // matching HC/8 packed weight blocks of its column
   f4 *tr_lds = reinterpret_cast<f4 *>(ctl + 4) + wave * 256;       // AT: this wave's 32 x 128 B block
+  const unsigned row_pitch = static_cast<unsigned>(p.Cin) * 4u, lane_chunk = static_cast<unsigned>(lane & 7) * 16u;
   auto load = [&](const Ctx &c, int k, int s, Slice &S) {
     if constexpr (AT) {
       // load q: row 8q + lane/8 of the tile, 16-byte chunk lane%8 of the item's 128-byte line
 #pragma unroll
+      // byte offset of the lane's 16-B chunk: row * (Cin * 4) + chunk * 16 as ONE 24-bit multiply-add
+      // (rows < 2^24 - 1, checked by the launch).  An absent neighbour (-1) needs no select: its low 24
+      // bits times the row pitch lie past the end of the buffer, and an out-of-range buffer load
+      // returns 0 (the range check looks at this offset, not at the scalar slice offset added to it).
       for (int q = 0; q < 4; ++q) {
-        const int src = c.meta[(8 * q + (lane >> 3)) * p.K + k];
-        const unsigned v_a = src >= 0 ? static_cast<unsigned>(src * p.Cin + (lane & 7) * 4) * 4u : kOob;
+        const unsigned src = static_cast<unsigned>(c.meta[(8 * q + (lane >> 3)) * p.K + k]);
+        const unsigned v_a = __umul24(src, row_pitch) + lane_chunk;
         S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, 0));
       }
       // weights: sub-slice sl = channel blocks 4s + 2sl + h of the three bf16 planes
@@ -1166,7 +1171,8 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   static const float min_rounds = getenv("SG_CONV_ROUNDS") ? atof(getenv("SG_CONV_ROUNDS")) : 2.5f;
   static const int at_env = getenv("SG_CONV_AT") ? atoi(getenv("SG_CONV_AT")) : 1;             // line-wise gather
   const int NB = (a.Cout + 31) / 32;
-  const int use_at = (at_env != 0 && a.Cin % 32 == 0) ? 1 : 0;
+  // (the line-wise gather forms its addresses with a 24-bit multiply: input rows < 2^24 - 1)
+  const int use_at = (at_env != 0 && a.Cin % 32 == 0 && in_bytes / (4LL * a.Cin) < (1LL << 24) - 1) ? 1 : 0;
   int pick = -1;
   // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
   // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units
