@@ -168,57 +168,113 @@ __global__ void instance_runs_total_kernel(const int32_t *__restrict__ total, in
 // decodes every RLE string to a dense N-vector on the host (and round 3 re-parsed the RLE text):
 // 21 ms per LiDAR sweep with ~1000 instances, profiles/r04_kitti_host_profile.txt.
 constexpr int kFuseThreads = 1024;
+constexpr int kFuseWpt = 8;          // 32-point words a thread owns in the register path (N <= 262 144 points)
 __global__ void __launch_bounds__(kFuseThreads) panoptic_fusion_kernel(
     const uint32_t *__restrict__ bits, int words, int n_inst, const int32_t *__restrict__ order,
     const int32_t *__restrict__ label_id, const int64_t *__restrict__ semantic_preds, int n_points,
     int cls_offset, double skip_iou, int semantic_classes, int thing_class_min, uint32_t *__restrict__ taken,
     uint32_t *__restrict__ ids, int32_t *__restrict__ label_of_id, uint32_t *__restrict__ out) {
-  __shared__ int red[2][kFuseThreads / 64];
-  __shared__ int decide;
+  __shared__ int red[2][2][kFuseThreads / 64];          // [parity][inter | count][wave]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int w = threadIdx.x; w < words; w += kFuseThreads) taken[w] = 0u;
   for (int i = threadIdx.x; i < n_points; i += kFuseThreads) ids[i] = 0u;
   int next_id = 1;
-  for (int r = 0; r < n_inst; ++r) {
-    const int k = order[r];
-    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
-    int inter = 0, cnt = 0;
-    for (int w = threadIdx.x; w < words; w += kFuseThreads) {
-      const uint32_t b = row[w];
-      cnt += __popc(b);
-      inter += __popc(b & taken[w]);
+  if (words <= kFuseWpt * kFuseThreads) {
+    // ---- register path: thread t owns words t, t + 1024, ... of the `taken` row for the whole walk;
+    //      the next instance's row is on its way while this one is decided (the order is known up
+    //      front), so an instance costs one block reduction, not two memory round trips
+    uint32_t tk[kFuseWpt], rw[kFuseWpt], nx[kFuseWpt];
+    auto fetch = [&](int r, uint32_t (&dst)[kFuseWpt]) {
+      const uint32_t *row = bits + static_cast<int64_t>(order[r]) * words;
+#pragma unroll
+      for (int j = 0; j < kFuseWpt; ++j) {
+        const int w = threadIdx.x + j * kFuseThreads;
+        dst[j] = w < words ? row[w] : 0u;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < kFuseWpt; ++j) tk[j] = nx[j] = 0u;
+    if (n_inst > 0) fetch(0, nx);
+    for (int r = 0; r < n_inst; ++r) {
+#pragma unroll
+      for (int j = 0; j < kFuseWpt; ++j) rw[j] = nx[j];
+      if (r + 1 < n_inst) fetch(r + 1, nx);
+      int inter = 0, cnt = 0;
+#pragma unroll
+      for (int j = 0; j < kFuseWpt; ++j) {
+        cnt += __popc(rw[j]);
+        inter += __popc(rw[j] & tk[j]);
+      }
+      inter = wave_sum(inter);
+      cnt = wave_sum(cnt);
+      const int par = r & 1;                           // double-buffered: one barrier per instance
+      if (lane == 0) {
+        red[par][0][wave] = inter;
+        red[par][1][wave] = cnt;
+      }
+      __syncthreads();
+      long long ti = 0, tc = 0;
+#pragma unroll
+      for (int v = 0; v < kFuseThreads / 64; ++v) {
+        ti += red[par][0][v];
+        tc += red[par][1][v];
+      }
+      const bool paste_it = !(static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou);   // every thread, same numbers
+      if (paste_it) {
+        if (threadIdx.x == 0) label_of_id[next_id] = label_id[order[r]] + cls_offset;
+#pragma unroll
+        for (int j = 0; j < kFuseWpt; ++j) {
+          uint32_t paste = rw[j] & ~tk[j];
+          tk[j] |= paste;
+          const int w = threadIdx.x + j * kFuseThreads;
+          while (paste) {
+            const int bb = __ffs(static_cast<int>(paste)) - 1;
+            paste &= paste - 1;
+            ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
+          }
+        }
+        ++next_id;
+      }
     }
-    inter = wave_sum(inter);
-    cnt = wave_sum(cnt);
-    if (lane == 0) {
-      red[0][wave] = inter;
-      red[1][wave] = cnt;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+  } else {
+    for (int w = threadIdx.x; w < words; w += kFuseThreads) taken[w] = 0u;
+    for (int r = 0; r < n_inst; ++r) {
+      const int k = order[r];
+      const uint32_t *row = bits + static_cast<int64_t>(k) * words;
+      int inter = 0, cnt = 0;
+      for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+        const uint32_t bw = row[w];
+        cnt += __popc(bw);
+        inter += __popc(bw & taken[w]);
+      }
+      inter = wave_sum(inter);
+      cnt = wave_sum(cnt);
+      const int par = r & 1;
+      if (lane == 0) {
+        red[par][0][wave] = inter;
+        red[par][1][wave] = cnt;
+      }
+      __syncthreads();
       long long ti = 0, tc = 0;
       for (int v = 0; v < kFuseThreads / 64; ++v) {
-        ti += red[0][v];
-        tc += red[1][v];
+        ti += red[par][0][v];
+        tc += red[par][1][v];
       }
-      decide = (static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou) ? 0 : 1;
-      if (decide) label_of_id[next_id] = label_id[k] + cls_offset;
-    }
-    __syncthreads();
-    if (decide) {          // uniform
-      for (int w = threadIdx.x; w < words; w += kFuseThreads) {
-        uint32_t paste = row[w] & ~taken[w];
-        if (paste == 0u) continue;
-        taken[w] |= paste;
-        while (paste) {
-          const int b = __ffs(static_cast<int>(paste)) - 1;
-          paste &= paste - 1;
-          ids[w * 32 + b] = static_cast<uint32_t>(next_id);
+      const bool paste_it = !(static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou);
+      if (paste_it) {
+        if (threadIdx.x == 0) label_of_id[next_id] = label_id[k] + cls_offset;
+        for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+          uint32_t paste = row[w] & ~taken[w];
+          if (paste == 0u) continue;
+          taken[w] |= paste;
+          while (paste) {
+            const int bb = __ffs(static_cast<int>(paste)) - 1;
+            paste &= paste - 1;
+            ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
+          }
         }
+        ++next_id;
       }
-      ++next_id;
     }
-    __syncthreads();       // `decide` / `red` are rewritten by the next instance
   }
   __threadfence_block();
   __syncthreads();
