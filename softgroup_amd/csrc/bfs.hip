@@ -1059,7 +1059,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
       stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr);
   if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
-    static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 32;   // developer knob
+    static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 16;   // developer knob
     const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
     int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 8 * kBigWgsMax ints
     if (static_cast<size_t>(n) >= 64 + 8 * kBigWgsMax) {
