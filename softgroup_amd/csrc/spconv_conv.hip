@@ -1137,18 +1137,12 @@ struct SplitVariant {
 #define SG_SPLIT_VARIANT(CK, DEPTH, WPE, NBW, WV, AT)                                            \
   {gather_conv_persistent_kernel<CK, DEPTH, 0, WPE, NBW, 1, WV, AT>,                              \
    gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
-constexpr int kSplitVariants = 13;
-constexpr int kWideFirst = 9;         // [kWideFirst, kSplitVariants): units of 3 / 4 column blocks
+constexpr int kSplitVariants = 9;
 static SplitVariant g_split_variants[kSplitVariants] = {
     SG_SPLIT_VARIANT(32, 2, 2, 2, 2, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 2, 1),
     SG_SPLIT_VARIANT(32, 2, 2, 2, 4, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 4, 1), SG_SPLIT_VARIANT(32, 2, 1, 1, 8, 1),
     SG_SPLIT_VARIANT(16, 2, 3, 2, 4, 0),  SG_SPLIT_VARIANT(16, 2, 4, 1, 4, 0), SG_SPLIT_VARIANT(16, 2, 2, 1, 8, 0),
     SG_SPLIT_VARIANT(16, 2, 1, 1, 16, 0),
-    // wide units: ALL column blocks of a 96- / 128-column layer in one unit -- the gathered rows are
-    // fetched, transposed and split into bf16 planes once for 36 / 48 MFMAs instead of once per 12
-    // (the conversions are 72 of the ~150 instructions of a one-block item); one wave per SIMD
-    SG_SPLIT_VARIANT(32, 2, 1, 3, 2, 1),  SG_SPLIT_VARIANT(32, 2, 1, 3, 4, 1),
-    SG_SPLIT_VARIANT(32, 2, 1, 4, 2, 1),  SG_SPLIT_VARIANT(32, 2, 1, 4, 4, 1),
 };
 // (Tried for the offset-split layers, whose waves run alone on their SIMDs at 0.75 us per item: a
 // 3-deep operand ring -- 2.31 instead of 2.28 ms of conv time per scan, not kept; what such a wave
@@ -1179,7 +1173,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   const int NB = (a.Cout + 31) / 32;
   // (the line-wise gather forms its addresses with a 24-bit multiply: input rows < 2^24 - 1)
   const int use_at = (at_env != 0 && a.Cin % 32 == 0 && in_bytes / (4LL * a.Cin) < (1LL << 24) - 1) ? 1 : 0;
-  int pick = -1, last = -1;
+  int pick = -1;
   // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
   // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units
   // (141 rows x 192 columns: 22.6 us against 42.7 us).  They run as 4-wave, one-block units.
@@ -1197,26 +1191,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   // (One wave per unit was measured too: the heaviest tiles -- 27 offsets in a single wave -- then
   // set the span of the big layers, 32->32 x 124 k rows 28.5 -> 32.1 us, 64->64 x 77 k 52 -> 69 us; on
   // the K = 8 strided / inverse convs alone it changes nothing, 2.22 ms per scan either way.)
-  // wide units (NBW = 3 / 4) where the layer's columns are exactly one unit: waves per unit by
-  // rounds of units per slot x items per wave (SG_CONV_WIDE=0 disables, SG_CONV_WIDE_WV forces)
-  static const int wide_env = getenv("SG_CONV_WIDE") ? atoi(getenv("SG_CONV_WIDE")) : 1;
-  static const int wide_wv_env = getenv("SG_CONV_WIDE_WV") ? atoi(getenv("SG_CONV_WIDE_WV")) : 0;
-  if (use_at && a.ksplit == 1 && wide_env != 0 && wv_env == 0 && (a.Cout == 96 || a.Cout == 128)) {
-    const int nbw = a.Cout / 32;
-    const long long items = static_cast<long long>(a.K) * (a.Cin / 32);      // of a full tile (upper bound)
-    long long best = -1;
-    for (int i = kWideFirst; i < kSplitVariants; ++i) {
-      const SplitVariant &v = g_split_variants[i];
-      if (v.nbw != nbw || (wide_wv_env && v.wv != wide_wv_env)) continue;
-      const long long slots = static_cast<long long>(num_cu) * v.occ;
-      const long long cost = ((num_tiles + slots - 1) / slots) * ((items + v.wv - 1) / v.wv + 4);
-      if (best < 0 || cost < best) {
-        best = cost;
-        pick = i;
-      }
-    }
-  }
-  for (int i = 0; i < kWideFirst && pick < 0; ++i) {
+  for (int i = 0; i < kSplitVariants; ++i) {
     const SplitVariant &v = g_split_variants[i];
     if (v.at != use_at) continue;
     if (v.wv == 2 && (!use_w2 || a.ksplit > 1 || v.nbw > w2_nbw)) continue;
@@ -1225,7 +1200,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
       if (v.nbw == 1 && v.wv == 4) { pick = i; break; }
       continue;
     }
-    last = i;                         // (the last candidate of the group stays if none qualifies)
+    pick = i;                         // (the last candidate of the group stays if none qualifies)
     if (v.nbw == 2 && (a.Cout % 64 != 0 || nbw_env < 2)) continue;
     if (wv_env && v.wv != wv_env) continue;
     const long long units = static_cast<long long>(num_tiles) * (NB / v.nbw);
@@ -1234,7 +1209,6 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
       break;
     }
   }
-  if (pick < 0) pick = last;
   const SplitVariant &v = g_split_variants[pick];
   a.col_units = NB / v.nbw;
   a.blocks_per_unit = v.nbw;
