@@ -311,7 +311,10 @@ int sg_spconv_pyramid_build(const int32_t *indices, int num_rows, const int32_t 
  * sg_spconv_gather_conv_f32 builds its weight descriptor over that full size and, on the default
  * split path, reads the planes.  Non-finite weights: h carries the Inf/NaN, m and l are NaN-free
  * only for finite values (x - Inf = NaN); a diverged model shows NaN where the fp32-MFMA kernel
- * (sg_spconv_set_arithmetic(0)) would show Inf. */
+ * (sg_spconv_set_arithmetic(0)) would show Inf.
+ * src_is_kio = 2 / 3 pack the weights of the TRANSPOSED convolution (the input gradient of a layer)
+ * straight from that layer's "OKKKI" tensor, read as src [cin][K][cout] (this call's cin = the
+ * layer's Cout and vice versa); 3 also mirrors the kernel offsets (k -> K-1-k: SubMConv3d). */
 size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout);
 int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
                           sg_stream_t stream);
@@ -341,8 +344,10 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
 /* Arithmetic of the fp32 sparse convolution's products (process-wide, not thread-safe; meant for
  * tests and A/B measurements): 1 = on the bf16 matrix pipe at fp32 accuracy (operands split three
  * ways, six v_mfma_f32_32x32x16_bf16 per 16-channel slice, fp32 accumulation; dropped terms
- * <= 2^-24 |a b|) -- the default; 0 = v_mfma_f32_32x32x2_f32; -1 = back to the environment
- * (SG_CONV_SPLIT).  No counterpart in the reference: spconv 2.1 multiplies in fp32 (or fp16 under
+ * <= 2^-24 |a b|) -- the default; 0 = v_mfma_f32_32x32x2_f32; 2 = bf16 OPERANDS (activations and
+ * weights rounded to nearest-even bf16, one v_mfma_f32_32x32x16_bf16 per slice, fp32 accumulation,
+ * fp32 in and out: the precision of gather_conv_bf16 without rounding the stored activations;
+ * layers with cin % 32 != 0 keep mode 1); -1 = back to the environment (SG_CONV_SPLIT).  No counterpart in the reference: spconv 2.1 multiplies in fp32 (or fp16 under
  * autocast).  Edge behaviour of mode 1: an activation that is Inf, NaN or above the bf16 maximum
  * (3.39e38) yields NaN in every output it touches (x - bf16(x) is Inf - Inf), where fp32 products
  * would give Inf; finite inputs below that are unaffected. */
@@ -427,6 +432,10 @@ typedef struct sg_unet_desc {
                                         multiple of 16 (weights zero-padded along Cin before packing)
                                         makes the executor convolve a zero-padded copy of the features
                                         on the persistent MFMA kernel instead of the general one */
+  int arithmetic;                    /* 0 = the process-wide conv arithmetic (fp32 products); 2 = bf16
+                                        operands for this call's convolutions (sg_spconv_set_arithmetic's
+                                        mode 2, scoped to the call and the calling thread): what a
+                                        frozen backbone runs in under bf16 autocast */
 } sg_unet_desc;
 /* upper bound of the arena sg_unet_forward needs for num_rows input voxels */
 size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);
@@ -436,6 +445,67 @@ size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);
 int sg_unet_forward(const sg_unet_desc *desc, const float *feats, const int32_t *indices,
                     int num_rows, const int32_t *spatial_shape_host, float *out, void *arena,
                     size_t arena_bytes, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Native TRAINING executor of the same U-Net (the DDP training step, tools/train.py:44-62 ->
+ * SoftGroup.forward_train, softgroup.py:113-150: tiny U-Net of the refinement head always, the
+ * backbone when it is not in `fixed_modules`).  The reference trains these modules through spconv's
+ * autograd functions and torch.nn.BatchNorm1d in train() mode, one interpreter round trip and
+ * several launches per layer; here
+ *   sg_unet_train_forward   runs the whole forward -- BatchNorm1d with BATCH statistics (biased
+ *                           variance for the normalisation, running_mean / running_var updated with
+ *                           `momentum`, unbiased variance, as torch does), ReLU, the convolutions --
+ *                           and records what the backward needs (activations, statistics, tables) in
+ *                           the caller's arena and in a host-side tape;
+ *   sg_unet_train_backward  consumes the tape: input gradients by the forward kernel on the
+ *                           transposed rulebooks, weight gradients by sg_spconv_wgrad, BatchNorm1d
+ *                           gradients from fp64 column sums.  Deterministic: no floating-point atomics.
+ * Weights and their gradients are the module's own tensors in the checkpoint layout [Cout][K][Cin]
+ * (packing happens inside); a NULL gradient pointer skips that gradient (frozen parameter).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sg_train_bn {          /* BatchNorm1d(c) in train() mode; weight == NULL: absent */
+  const float *weight, *bias;         /* [c] */
+  float *running_mean, *running_var;  /* [c], updated in place by the forward */
+  float momentum, eps;
+  float *g_weight, *g_bias;           /* [c] written by the backward, or NULL */
+} sg_train_bn;
+typedef struct sg_train_conv {        /* bias-free sparse conv; w == NULL: absent */
+  const float *w;                     /* [Cout][K][Cin] */
+  float *g_w;                         /* same layout, written by the backward, or NULL */
+} sg_train_conv;
+typedef struct sg_unet_train_block {  /* ResidualBlock, blocks.py:44-79 */
+  int cin, cout;
+  sg_train_bn bn1, bn2;
+  sg_train_conv c1, c2, ci;           /* ci: 1x1 conv of the identity branch (cin != cout) */
+} sg_unet_train_block;
+typedef struct sg_unet_train_level {  /* UBlock, blocks.py:82-143 */
+  int planes, n_blocks;
+  const sg_unet_train_block *blocks, *tail;      /* [n_blocks]; tail NULL on the deepest level */
+  sg_train_bn down_bn, up_bn;
+  sg_train_conv down, up;
+} sg_unet_train_level;
+typedef struct sg_unet_train_desc {
+  int n_levels;
+  const sg_unet_train_level *levels;  /* host array, outermost first */
+  int input_cin;
+  sg_train_conv input;                /* SubMConv3d(input_cin, planes[0]) before the UBlock, or absent */
+  sg_train_bn out_bn;                 /* BatchNorm1d + ReLU after the UBlock, or absent */
+  int arithmetic;                     /* as sg_unet_desc.arithmetic (0 | 2), forward and input gradients */
+} sg_unet_train_desc;
+/* Arena: index tables + every activation of the forward + the gradients of the backward, bump
+ * allocated and alive until the backward has run.  *arena_needed (if not NULL) receives the exact
+ * size for this input once the level row counts are known; SG_ERR_WORKSPACE = call again with at
+ * least that much.  sg_unet_train_arena_hint: a first guess from the row count alone. */
+size_t sg_unet_train_arena_hint(const sg_unet_train_desc *desc, int num_rows);
+int sg_unet_train_forward(const sg_unet_train_desc *desc, const float *feats, const int32_t *indices,
+                          int num_rows, const int32_t *spatial_shape_host, float *out, void *arena,
+                          size_t arena_bytes, size_t *arena_needed, void **tape, sg_stream_t stream);
+/* g_out [num_rows, planes[0]]; g_feats [num_rows, input_cin or planes[0]] or NULL.  Parameter
+ * gradients go to the pointers of the descriptor the forward was given (they must still be valid).
+ * Frees the tape, whatever it returns. */
+int sg_unet_train_backward(void *tape, const float *g_out, float *g_feats, sg_stream_t stream);
+/* a forward whose backward will never run */
+void sg_unet_train_release(void *tape);
 
 /* Fused eval-mode BatchNorm1d + ReLU over [M, C] rows (output_layer, softgroup.py:65):
  * out = relu(x*scale + shift) (relu optional). */

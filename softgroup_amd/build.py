@@ -25,6 +25,7 @@ SOURCES = [
     ('spconv_conv.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form', '-mllvm', '-amdgpu-atomic-optimizer-strategy=None'] + os.environ.get('SG_CONV_EXTRA_FLAGS', '').split()),
     ('spconv_train.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form']),
     ('unet_exec.hip', ['-ffp-contract=off']),
+    ('unet_train.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
     ('scan_exec.hip', ['-ffp-contract=off']),
     ('eval_ops.hip', ['-ffp-contract=off']),

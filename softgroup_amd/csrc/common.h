@@ -94,4 +94,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
+// conv arithmetic requested by the calling thread (spconv_conv.hip); -1 = none
+extern thread_local int t_conv_arith;
+
 }  // namespace sg

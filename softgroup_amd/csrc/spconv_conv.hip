@@ -67,6 +67,17 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
     l[2 * j] = ll[0]; l[2 * j + 1] = ll[1];
   }
 }
+// h alone: the operand of the "bf16 operands" arithmetic (round to nearest even, as torch's .bfloat16())
+__device__ __forceinline__ bf16x8 round_bf16(const float (&x)[8]) {
+  bf16x8 h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f2 v = {x[2 * j], x[2 * j + 1]};
+    const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+    h[2 * j] = hh[0]; h[2 * j + 1] = hh[1];
+  }
+  return h;
+}
 __device__ __forceinline__ uint16_t bf16_rne(float x) {
   const uint32_t u = __builtin_bit_cast(uint32_t, x);
   return static_cast<uint16_t>((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
@@ -429,8 +440,11 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   };
   (void)num_tiles;
 
-  // SPLIT: b[n][pl] = the 8 bf16 weights of plane pl (h, m, l) for this lane's channel block
-  constexpr int NB_ = AT ? 6 : SPLIT ? 3 : NQ;   // AT: two 16-channel sub-slices x three planes
+  // SPLIT: b[n][pl] = the 8 bf16 weights of plane pl (h, m, l) for this lane's channel block.
+  // SPLIT == 2 ("bf16 operands", the autocast arithmetic): only the h plane = bf16(w) is read and the
+  // gathered rows are rounded to bf16 once -- ONE MFMA per product instead of six, fp32 sums.
+  constexpr int NPL = SPLIT == 2 ? 1 : 3;
+  constexpr int NB_ = AT ? 2 * NPL : SPLIT ? NPL : NQ;   // AT: two 16-channel sub-slices x the planes
   struct Slice { f4 a[NQ]; f4 b[NBW][NB_]; };
   const int plane_bytes = p.K * c8 * p.Cout * 16;          // one bf16 plane of the packed weights
   const int planes_at = 2 * plane_bytes;                   // they follow the fp32 copy
@@ -474,8 +488,8 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            S.b[n][sl * 3 + pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+          for (int pl = 0; pl < NPL; ++pl)
+            S.b[n][sl * NPL + pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                                              rs_w, c.v_w + n * 512,
                                                              s_w + sl * (2 * p.Cout * 16) + pl * plane_bytes, 0));
       return;
@@ -492,7 +506,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           S.b[n][pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   rs_w, c.v_w + n * 512, s_w + pl * plane_bytes, 0));
     } else {
@@ -605,6 +619,14 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
       for (int sl = 0; sl < 2; ++sl) {
         const float af[8] = {fr[sl][0][0], fr[sl][0][1], fr[sl][0][2], fr[sl][0][3],
                              fr[sl][1][0], fr[sl][1][1], fr[sl][1][2], fr[sl][1][3]};
+        if constexpr (SPLIT == 2) {
+          const bf16x8 ah = round_bf16(af);
+#pragma unroll
+          for (int n = 0; n < NBW; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, S.b[n][sl]), acc[n],
+                                                             0, 0, 0);
+          continue;
+        }
         bf16x8 ah, am, al;
         split3(af, ah, am, al);
 #pragma unroll
@@ -624,6 +646,14 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     }
     if constexpr (SPLIT) {
       const float af[8] = {S.a[0][0], S.a[0][1], S.a[0][2], S.a[0][3], S.a[1][0], S.a[1][1], S.a[1][2], S.a[1][3]};
+      if constexpr (SPLIT == 2) {
+        const bf16x8 ah = round_bf16(af);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, S.b[n][0]), acc[n], 0,
+                                                           0, 0);
+        return;
+      }
       bf16x8 ah, am, al;
       split3(af, ah, am, al);
 #pragma unroll
@@ -993,7 +1023,9 @@ __global__ void __launch_bounds__(256) gather_conv_scalar_kernel(
 }
 
 // weight packing: src [Cout][K][Cin] (spconv "OKKKI", src_kio == 0) or [K][Cin][Cout]
-// (src_kio == 1) -> [K][ceil(Cin/8)][Cout][8], zero padded
+// (src_kio == 1) -> [K][ceil(Cin/8)][Cout][8], zero padded.  src_kio == 2 / 3: the weights of the
+// TRANSPOSED convolution (input gradient) straight from the forward layer's "OKKKI" tensor
+// w[Cin][K][Cout] (this conv's Cin = that layer's Cout), 3 = kernel offsets mirrored (SubM)
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restrict__ w, int cout, int K,
                                                          int cin, int src_kio,
                                                          float *__restrict__ out) {
@@ -1007,9 +1039,11 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restric
     const int blk = static_cast<int>(r % c8), k = static_cast<int>(r / c8);
     const int ci = blk * 8 + j;
     float v = 0.f;
-    if (ci < cin)
-      v = src_kio ? w[(static_cast<int64_t>(k) * cin + ci) * cout + co]
-                  : w[(static_cast<int64_t>(co) * K + k) * cin + ci];
+    if (ci < cin) {
+      if (src_kio == 0) v = w[(static_cast<int64_t>(co) * K + k) * cin + ci];
+      else if (src_kio == 1) v = w[(static_cast<int64_t>(k) * cin + ci) * cout + co];
+      else v = w[(static_cast<int64_t>(ci) * K + (src_kio == 3 ? K - 1 - k : k)) * cout + co];   // transposed conv
+    }
     out[t] = v;
     // the same element as three bf16 planes behind the fp32 copy (split-precision MFMA path)
     uint16_t *planes = reinterpret_cast<uint16_t *>(out + total);
@@ -1051,6 +1085,9 @@ static ConvProf g_conv_prof;
 // arithmetic of the persistent kernel: -1 = from the environment (SG_CONV_SPLIT, default 1), 0 = fp32
 // MFMA, 1 = split-precision bf16 MFMA (sg_spconv_set_arithmetic; tests compare the two in one process)
 static std::atomic<int> g_arith_override{-1};
+// arithmetic requested by the calling thread for the convs it launches (sg_unet_forward with
+// sg_unet_desc.arithmetic set; common.h); -1 = none, the process-wide choice applies
+thread_local int t_conv_arith = -1;
 static std::atomic<int> g_combine_override{-1};   // in-launch combine of offset-split layers: -1 = SG_CONV_COMBINE (default 1)
 
 // Ticket counters of the persistent kernel's unit hand-out: every launch gets its own zeroed block
@@ -1130,13 +1167,21 @@ static unsigned *take_tickets(hipStream_t stream) {
 typedef void (*PersistentFn)(ConvArgs, unsigned, unsigned);
 struct SplitVariant {
   PersistentFn fn, fn_trace;
+  PersistentFn fn_b16;      // the same decomposition with bf16 operands (one MFMA per product)
   int nbw, wv, ck, at;
   size_t lds;
-  int occ;      // resident workgroups per CU (0 = not asked yet)
+  int occ, occ_b16;      // resident workgroups per CU
 };
+#ifndef SG_B16_DEPTH
+#define SG_B16_DEPTH 2
+#endif
+#ifndef SG_B16_WPE_PLUS
+#define SG_B16_WPE_PLUS 0
+#endif
 #define SG_SPLIT_VARIANT(CK, DEPTH, WPE, NBW, WV, AT)                                            \
   {gather_conv_persistent_kernel<CK, DEPTH, 0, WPE, NBW, 1, WV, AT>,                              \
-   gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>, NBW, WV, CK, AT, 0, 0}
+   gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>,                              \
+   gather_conv_persistent_kernel<CK, SG_B16_DEPTH, 0, WPE + SG_B16_WPE_PLUS, NBW, 2, WV, AT>, NBW, WV, CK, AT, 0, 0, 0}
 constexpr int kSplitVariants = 9;
 static SplitVariant g_split_variants[kSplitVariants] = {
     SG_SPLIT_VARIANT(32, 2, 2, 2, 2, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 2, 1),
@@ -1149,7 +1194,7 @@ static SplitVariant g_split_variants[kSplitVariants] = {
 // waits for is its own chain of dependent MFMAs and conversions, not its loads.)
 
 static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes, long long w_bytes,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, bool b16) {
   static int num_cu = 0;
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1163,6 +1208,9 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
       int o = 0;
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn, 64 * v.wv, v.lds);
       v.occ = o < 1 ? 1 : o;
+      o = 0;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn_b16, 64 * v.wv, v.lds);
+      v.occ_b16 = o < 1 ? 1 : o;
     };
     for (SplitVariant &v : g_split_variants) prepare(v);
   });
@@ -1204,7 +1252,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
     if (v.nbw == 2 && (a.Cout % 64 != 0 || nbw_env < 2)) continue;
     if (wv_env && v.wv != wv_env) continue;
     const long long units = static_cast<long long>(num_tiles) * (NB / v.nbw);
-    if (wv_env || units >= static_cast<long long>((v.wv == 2 ? w2_rounds : min_rounds) * num_cu * v.occ)) {
+    if (wv_env || units >= static_cast<long long>((v.wv == 2 ? w2_rounds : min_rounds) * num_cu * (b16 ? v.occ_b16 : v.occ))) {
       pick = i;
       break;
     }
@@ -1220,10 +1268,14 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   a.magic_nsl = magic(static_cast<unsigned>(a.Cin / v.ck));
   static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
   a.queue = dyn_env ? take_tickets(stream) : nullptr;
-  long long g = static_cast<long long>(num_cu) * v.occ;
+  long long g = static_cast<long long>(num_cu) * (b16 ? v.occ_b16 : v.occ);
   if (g > units) g = units;
   if (g >= 8) g -= g % 8;
   const unsigned ib = static_cast<unsigned>(in_bytes), wb = static_cast<unsigned>(w_bytes);
+  if (b16) {
+    v.fn_b16<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
+    return check_launch("sg_spconv_gather_conv_f32(bf16 operands)");
+  }
   static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
   if (trace_env) {
     const size_t nb = static_cast<size_t>(units) * kWavesPerWg * 8 * sizeof(unsigned long long);
@@ -1256,7 +1308,7 @@ using namespace sg;
 extern "C" {
 
 int sg_spconv_set_arithmetic(int mode) {
-  SG_REQUIRE(mode >= -1 && mode <= 1, "sg_spconv_set_arithmetic: mode must be -1, 0 or 1");
+  SG_REQUIRE(mode >= -1 && mode <= 2, "sg_spconv_set_arithmetic: mode must be -1, 0, 1 or 2");
   g_arith_override = mode;
   return SG_OK;
 }
@@ -1300,7 +1352,8 @@ size_t sg_spconv_packed_weight_elems(int kvol, int cin, int cout) {
 
 int sg_spconv_pack_weight(const float *w, int cout, int kvol, int cin, int src_is_kio, float *w_k8,
                           sg_stream_t stream) {
-  SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0, "sg_spconv_pack_weight: bad arguments");
+  SG_REQUIRE(cout > 0 && kvol > 0 && cin > 0 && src_is_kio >= 0 && src_is_kio <= 3,
+             "sg_spconv_pack_weight: bad arguments");
   const int64_t total = static_cast<int64_t>(packed_k8_elems(kvol, cin, cout));
   pack_weight_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>(w, cout, kvol, cin,
                                                                          src_is_kio, w_k8);
@@ -1360,7 +1413,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   // kernel, kept for A/B)
   static const int split_env = getenv("SG_CONV_SPLIT") ? atoi(getenv("SG_CONV_SPLIT")) : 1;
   static const int split_min_cin = getenv("SG_CONV_SPLIT_MIN_CIN") ? atoi(getenv("SG_CONV_SPLIT_MIN_CIN")) : 16;
-  const int arith_ov = g_arith_override.load(std::memory_order_relaxed);
+  const int arith_ov = t_conv_arith >= 0 ? t_conv_arith : g_arith_override.load(std::memory_order_relaxed);
   const int split_on = arith_ov >= 0 ? arith_ov : split_env;
   const bool split = persistent && split_on != 0 && Cin >= split_min_cin;
   // ---- decomposition: aim at >= ~2048 waves; the general kernel widens its column block while
@@ -1413,7 +1466,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.magic_nsl = 0;
 
   if (split) {
-    const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream);
+    const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream, split_on == 2);
     if (rc != SG_OK) return rc;
   } else if (persistent) {
     // fp32-MFMA kernel (SG_CONV_SPLIT=0 / sg_spconv_set_arithmetic(0), and layers below

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "unet_common.h"
 
 namespace sg {
 
@@ -46,6 +47,9 @@ __global__ void __launch_bounds__(256) concat2_kernel(const float4 *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// index build shared with the training executor (unet_common.h)
+// ---------------------------------------------------------------------------------------------
 // Trivial plans of the 1x1 convs on the identity branches (kernel volume 1, neighbour = the row
 // itself): order[l][i] = i for i < rows, -1 up to whole 32-row tiles -- with K = 1 the same buffer is
 // the gather table, the plan's row order and its per-tile gather blocks; mask[l][t] = 1 is every
@@ -65,6 +69,147 @@ __global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s) {
     s.mask[l][i] = i < tiles ? 1u : (i == tiles + 1 ? static_cast<uint32_t>(tiles) : 0u);
 }
 
+int unet_build_index(const char *who, int L, const int32_t *indices, int num_rows,
+                     const int32_t *spatial_shape_host, void *arena, size_t arena_bytes, sg_stream_t stream,
+                     LevelIdx *li, size_t *used, std::unique_lock<std::mutex> *lock) {
+  // ---- runtime state per (device, caller's stream): callers that run scans concurrently on
+  //      several streams (one host thread each) get an index stream of their own and never wait for
+  //      each other; calls on the same stream are serialised by the state's mutex
+  struct StreamState {
+    std::mutex mu;
+    int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
+    int32_t *dev_rows = nullptr;      // device
+    hipStream_t istream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_index = nullptr;
+    bool ready = false;
+  };
+  static std::mutex table_mu;
+  static std::map<std::pair<int, hipStream_t>, StreamState *> table;
+  int dev = 0;
+  SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "%s: no current device", who);
+  StreamState *stp = nullptr;
+  {
+    std::lock_guard<std::mutex> g(table_mu);
+    StreamState *&slot = table[std::make_pair(dev, as_stream(stream))];
+    if (slot == nullptr) slot = new StreamState();     // lives as long as the process
+    stp = slot;
+  }
+  StreamState &st = *stp;
+  std::unique_lock<std::mutex> guard(st.mu);
+  if (!st.ready) {
+    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
+               "%s: pinned allocation failed", who);
+    SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
+               "%s: device allocation failed", who);
+    SG_REQUIRE(hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
+               "%s: stream creation failed", who);
+    SG_REQUIRE(hipEventCreateWithFlags(&st.ev_start, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&st.ev_index, hipEventDisableTiming) == hipSuccess,
+               "%s: event creation failed", who);
+    st.ready = true;
+  }
+  hipStream_t istream = st.istream;
+  sg_stream_t is = reinterpret_cast<sg_stream_t>(istream);
+  // the index stream starts where the caller's stream is now: the coordinates are ready, and the
+  // previous forward's convolutions no longer read the tables about to be overwritten
+  if (hipEventRecord(st.ev_start, as_stream(stream)) != hipSuccess ||
+      hipStreamWaitEvent(istream, st.ev_start, 0) != hipSuccess) {
+    set_error("%s: event record/wait failed", who);
+    return SG_ERR_LAUNCH;
+  }
+  // ---- index part of the arena (bump, never recycled inside a forward)
+  Arena ix(arena, arena_bytes);
+#define SG_IALLOC(var, T, count)                                                       \
+  T *var = ix.take<T>(count);                                                          \
+  if (var == nullptr) {                                                                \
+    set_error("%s: arena too small (%zu bytes) for the index tables", who, arena_bytes); \
+    return SG_ERR_WORKSPACE;                                                           \
+  }
+  // ---- rows of every level: one pass + one read-back (the only host sync of the forward; it
+  //      waits for the index stream only -- whatever the caller's stream has queued keeps running)
+  const size_t pws_bytes = sg_spconv_pyramid_workspace_bytes(num_rows, L);
+  SG_IALLOC(pws, char, pws_bytes);
+  SG_TRY(sg_spconv_pyramid_rows(indices, num_rows, spatial_shape_host, L, st.dev_rows, pws, pws_bytes, is));
+  if (hipMemcpyAsync(st.host_rows, st.dev_rows, sizeof(int32_t) * L, hipMemcpyDeviceToHost, istream) != hipSuccess ||
+      hipStreamSynchronize(istream) != hipSuccess) {
+    set_error("%s: reading the level row counts failed", who);
+    return SG_ERR_LAUNCH;
+  }
+  SG_REQUIRE(st.host_rows[0] == num_rows, "%s: duplicate voxel coordinates in the input "
+             "(%d distinct of %d rows)", who, st.host_rows[0], num_rows);
+  // ---- tables and plans of all levels
+  sg_pyramid_level pl[SG_PYRAMID_MAX_LEVELS];
+  for (int l = 0; l < L; ++l) {
+    const int rows = st.host_rows[l];
+    const int rows2 = l + 1 < L ? st.host_rows[l + 1] : 0;
+    const size_t r = static_cast<size_t>(rows ? rows : 1), r2 = static_cast<size_t>(rows2 ? rows2 : 1);
+    const size_t t = (r + 31) / 32, t2 = (r2 + 31) / 32;
+    sg_pyramid_level &P = pl[l];
+    P = sg_pyramid_level();
+    P.rows = rows;
+    SG_IALLOC(indices_l, int32_t, r * 4);
+    SG_IALLOC(nbr, int32_t, r * 27);
+    SG_IALLOC(so, int32_t, t * 32);
+    SG_IALLOC(sm, uint32_t, t + SG_PLAN_HIST_WORDS);
+    SG_IALLOC(sn, int32_t, t * 32 * 27);
+    P.indices = indices_l; P.nbr = nbr;
+    P.subm = sg_plan_ptrs{so, sm, sn};
+    LevelIdx &I = li[l];
+    I.rows = rows;
+    for (int a = 0; a < 3; ++a) I.shape[a] = spatial_shape_host[a] >> l;
+    I.subm.nbr = nbr; I.subm.order = so; I.subm.tile_mask = sm; I.subm.nbr_tiles = sn;
+    I.subm.rows = rows; I.subm.kvol = 27;
+    if (l + 1 < L) {
+      SG_IALLOC(in2out, int32_t, r);
+      SG_IALLOC(child, int32_t, r2 * 8);
+      SG_IALLOC(inv, int32_t, r * 8);
+      SG_IALLOC(dord, int32_t, t2 * 32);
+      SG_IALLOC(dm, uint32_t, t2 + SG_PLAN_HIST_WORDS);
+      SG_IALLOC(dn, int32_t, t2 * 32 * 8);
+      SG_IALLOC(uo, int32_t, t * 32);
+      SG_IALLOC(um, uint32_t, t + SG_PLAN_HIST_WORDS);
+      SG_IALLOC(un, int32_t, t * 32 * 8);
+      P.in2out = in2out; P.child = child; P.inv = inv;
+      P.down = sg_plan_ptrs{dord, dm, dn};
+      P.up = sg_plan_ptrs{uo, um, un};
+      I.down.nbr = child; I.down.order = dord; I.down.tile_mask = dm; I.down.nbr_tiles = dn;
+      I.down.rows = rows2; I.down.kvol = 8;
+      I.up.nbr = inv; I.up.order = uo; I.up.tile_mask = um; I.up.nbr_tiles = un;
+      I.up.rows = rows; I.up.kvol = 8;
+    }
+  }
+  {
+    const size_t nb = sg_spconv_pyramid_build_workspace_bytes(pl, L);
+    SG_IALLOC(ws2, char, nb);
+    SG_TRY(sg_spconv_pyramid_build(indices, num_rows, spatial_shape_host, L, pl, pws, pws_bytes, ws2, nb, is));
+  }
+  if (L > 1) {      // trivial plans of the 1x1 convs on the tail's identity branches
+    IdentSegs segs;
+    segs.n = L - 1;
+    for (int l = 0; l + 1 < L; ++l) {
+      const size_t tiles = (static_cast<size_t>(li[l].rows) + 31) / 32;
+      SG_IALLOC(ord, int32_t, tiles ? tiles * 32 : 32);
+      SG_IALLOC(tm, uint32_t, tiles + SG_PLAN_HIST_WORDS);
+      segs.order[l] = ord;
+      segs.mask[l] = tm;
+      segs.rows[l] = li[l].rows;
+      Plan &P = li[l].ident;
+      P.nbr = ord; P.order = ord; P.nbr_tiles = ord; P.tile_mask = tm;
+      P.rows = li[l].rows; P.kvol = 1;
+    }
+    ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs);
+  }
+#undef SG_IALLOC
+  if (hipEventRecord(st.ev_index, istream) != hipSuccess ||
+      hipStreamWaitEvent(as_stream(stream), st.ev_index, 0) != hipSuccess) {
+    set_error("%s: event record/wait failed", who);
+    return SG_ERR_LAUNCH;
+  }
+  *used = ix.off;
+  *lock = std::move(guard);
+  return SG_OK;
+}
+
 // feature rows zero-padded to `cpad` channels (the input conv on the persistent kernel: Cin % 16 == 0)
 __global__ void __launch_bounds__(256) pad_channels_kernel(const float *__restrict__ in, int64_t rows, int cin,
                                                           int cpad, float *__restrict__ out) {
@@ -76,49 +221,12 @@ __global__ void __launch_bounds__(256) pad_channels_kernel(const float *__restri
   }
 }
 
-// bump allocator with stack discipline
-struct Arena {
-  char *base;
-  size_t cap, off, peak;
-  Arena(void *p, size_t n) : base(static_cast<char *>(p)), cap(n), off(0), peak(0) {}
-  template <typename T>
-  T *take(size_t count) {
-    const size_t bytes = align_up(count * sizeof(T));
-    if (off + bytes > cap) return nullptr;
-    T *r = reinterpret_cast<T *>(base + off);
-    off += bytes;
-    if (off > peak) peak = off;
-    return r;
-  }
-  size_t mark() const { return off; }
-  void release(size_t m) { off = m; }
-};
-
-struct Plan {
-  const int32_t *nbr = nullptr;
-  int32_t *order = nullptr;
-  uint32_t *tile_mask = nullptr;
-  int32_t *nbr_tiles = nullptr;
-  int rows = 0, kvol = 0;
-};
-
-#define SG_TRY(expr)              \
-  do {                            \
-    const int rc_ = (expr);       \
-    if (rc_ != SG_OK) return rc_; \
-  } while (0)
 #define SG_ALLOC(var, T, count)                                                        \
   T *var = ar.take<T>(count);                                                          \
   if (var == nullptr) {                                                                \
     set_error("sg_unet_forward: arena too small (%zu bytes, need more than %zu)", ar.cap, ar.off); \
     return SG_ERR_WORKSPACE;                                                           \
   }
-
-struct LevelIdx {
-  int rows = 0;
-  int32_t shape[3] = {0, 0, 0};
-  Plan subm, down, up, ident;
-};
 
 struct Exec {
   const sg_unet_desc *d;
@@ -283,12 +391,6 @@ struct Exec {
   }
 };
 
-}  // namespace sg
-
-using namespace sg;
-
-extern "C" {
-
 // index part of the arena (the pyramid's hash workspace, every level's tables and plans, the plan
 // build scratch): priced with all `num_rows` voxels on every level (levels can only shrink)
 static size_t level_index_bytes(size_t rows, size_t rows_next, bool deeper) {
@@ -301,9 +403,8 @@ static size_t level_index_bytes(size_t rows, size_t rows_next, bool deeper) {
          align_up(t * 32 * 4) + align_up((t + SG_PLAN_HIST_WORDS) * 4) + align_up(t * 32 * 8 * 4);       // up plan
   return b + 4096;
 }
-static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
+size_t unet_index_bytes(int L, int num_rows) {
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
-  const int L = d->n_levels;
   size_t total = (1 << 20) + sg_spconv_pyramid_workspace_bytes(num_rows, L) +
                  (L + 1) * (align_up(rows * 4) + align_up(rows / 8 + 256) + 4096);   // trivial plans of the 1x1 convs
   sg_pyramid_level bound[SG_PYRAMID_MAX_LEVELS];
@@ -315,9 +416,15 @@ static size_t unet_index_bytes(const sg_unet_desc *d, int num_rows) {
   return align_up(total, 4096);
 }
 
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
 size_t sg_unet_arena_bytes(const sg_unet_desc *d, int num_rows) {
   // feature part: at most ~12 live buffers of 2*planes floats per level (stack discipline)
-  size_t total = unet_index_bytes(d, num_rows) + (1 << 20);
+  size_t total = unet_index_bytes(d->n_levels, num_rows) + (1 << 20);
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
   for (int l = 0; l < d->n_levels; ++l)
     total += rows * 12 * 2 * static_cast<size_t>(d->levels[l].planes) * 4 + (64 << 10);
@@ -333,144 +440,22 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   for (int l = 0; l < d->n_levels; ++l)
     SG_REQUIRE(d->levels[l].planes % 4 == 0 && d->levels[l].n_blocks >= 1,
                "sg_unet_forward: level %d: planes must be a multiple of 4", l);
+  SG_REQUIRE(d->arithmetic == 0 || d->arithmetic == 2, "sg_unet_forward: arithmetic must be 0 or 2");
   if (num_rows == 0) return SG_OK;
   const int L = d->n_levels;
-  // ---- runtime state per (device, caller's stream): callers that run scans concurrently on
-  //      several streams (one host thread each) get an index stream of their own and never wait for
-  //      each other; calls on the same stream are serialised by the state's mutex
-  struct StreamState {
-    std::mutex mu;
-    int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
-    int32_t *dev_rows = nullptr;      // device
-    hipStream_t istream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_index = nullptr;
-    bool ready = false;
-  };
-  static std::mutex table_mu;
-  static std::map<std::pair<int, hipStream_t>, StreamState *> table;
-  int dev = 0;
-  SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "sg_unet_forward: no current device");
-  StreamState *stp = nullptr;
-  {
-    std::lock_guard<std::mutex> g(table_mu);
-    StreamState *&slot = table[std::make_pair(dev, as_stream(stream))];
-    if (slot == nullptr) slot = new StreamState();     // lives as long as the process
-    stp = slot;
-  }
-  StreamState &st = *stp;
-  std::lock_guard<std::mutex> guard(st.mu);
-  if (!st.ready) {
-    SG_REQUIRE(hipHostMalloc(reinterpret_cast<void **>(&st.host_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
-               "sg_unet_forward: pinned allocation failed");
-    SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
-               "sg_unet_forward: device allocation failed");
-    SG_REQUIRE(hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
-               "sg_unet_forward: stream creation failed");
-    SG_REQUIRE(hipEventCreateWithFlags(&st.ev_start, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&st.ev_index, hipEventDisableTiming) == hipSuccess,
-               "sg_unet_forward: event creation failed");
-    st.ready = true;
-  }
-  hipStream_t istream = st.istream;
-  sg_stream_t is = reinterpret_cast<sg_stream_t>(istream);
-  // the index stream starts where the caller's stream is now: the coordinates are ready, and the
-  // previous forward's convolutions no longer read the tables about to be overwritten
-  if (hipEventRecord(st.ev_start, as_stream(stream)) != hipSuccess ||
-      hipStreamWaitEvent(istream, st.ev_start, 0) != hipSuccess) {
-    set_error("sg_unet_forward: event record/wait failed");
-    return SG_ERR_LAUNCH;
-  }
-  // ---- index part of the arena (bump, never recycled inside a forward)
-  Arena ix(arena, arena_bytes);
-#define SG_IALLOC(var, T, count)                                                       \
-  T *var = ix.take<T>(count);                                                          \
-  if (var == nullptr) {                                                                \
-    set_error("sg_unet_forward: arena too small (%zu bytes) for the index tables", arena_bytes); \
-    return SG_ERR_WORKSPACE;                                                           \
-  }
-  // ---- rows of every level: one pass + one read-back (the only host sync of the forward; it
-  //      waits for the index stream only -- whatever the caller's stream has queued keeps running)
-  const size_t pws_bytes = sg_spconv_pyramid_workspace_bytes(num_rows, L);
-  SG_IALLOC(pws, char, pws_bytes);
-  SG_TRY(sg_spconv_pyramid_rows(indices, num_rows, spatial_shape_host, L, st.dev_rows, pws, pws_bytes, is));
-  if (hipMemcpyAsync(st.host_rows, st.dev_rows, sizeof(int32_t) * L, hipMemcpyDeviceToHost, istream) != hipSuccess ||
-      hipStreamSynchronize(istream) != hipSuccess) {
-    set_error("sg_unet_forward: reading the level row counts failed");
-    return SG_ERR_LAUNCH;
-  }
-  SG_REQUIRE(st.host_rows[0] == num_rows, "sg_unet_forward: duplicate voxel coordinates in the input "
-             "(%d distinct of %d rows)", st.host_rows[0], num_rows);
-  // ---- tables and plans of all levels
-  sg_pyramid_level pl[SG_PYRAMID_MAX_LEVELS];
+  struct ArithScope {      // this call's convolutions, on this thread only
+    int keep;
+    explicit ArithScope(int a) : keep(t_conv_arith) { if (a > 0) t_conv_arith = a; }
+    ~ArithScope() { t_conv_arith = keep; }
+  } arith_scope(d->arithmetic);
+  // ---- gather tables and tile plans of all levels (index stream; this stream waits for them once)
   LevelIdx li[SG_PYRAMID_MAX_LEVELS];
-  for (int l = 0; l < L; ++l) {
-    const int rows = st.host_rows[l];
-    const int rows2 = l + 1 < L ? st.host_rows[l + 1] : 0;
-    const size_t r = static_cast<size_t>(rows ? rows : 1), r2 = static_cast<size_t>(rows2 ? rows2 : 1);
-    const size_t t = (r + 31) / 32, t2 = (r2 + 31) / 32;
-    sg_pyramid_level &P = pl[l];
-    P = sg_pyramid_level();
-    P.rows = rows;
-    SG_IALLOC(indices_l, int32_t, r * 4);
-    SG_IALLOC(nbr, int32_t, r * 27);
-    SG_IALLOC(so, int32_t, t * 32);
-    SG_IALLOC(sm, uint32_t, t + SG_PLAN_HIST_WORDS);
-    SG_IALLOC(sn, int32_t, t * 32 * 27);
-    P.indices = indices_l; P.nbr = nbr;
-    P.subm = sg_plan_ptrs{so, sm, sn};
-    LevelIdx &I = li[l];
-    I.rows = rows;
-    for (int a = 0; a < 3; ++a) I.shape[a] = spatial_shape_host[a] >> l;
-    I.subm.nbr = nbr; I.subm.order = so; I.subm.tile_mask = sm; I.subm.nbr_tiles = sn;
-    I.subm.rows = rows; I.subm.kvol = 27;
-    if (l + 1 < L) {
-      SG_IALLOC(in2out, int32_t, r);
-      SG_IALLOC(child, int32_t, r2 * 8);
-      SG_IALLOC(inv, int32_t, r * 8);
-      SG_IALLOC(dord, int32_t, t2 * 32);
-      SG_IALLOC(dm, uint32_t, t2 + SG_PLAN_HIST_WORDS);
-      SG_IALLOC(dn, int32_t, t2 * 32 * 8);
-      SG_IALLOC(uo, int32_t, t * 32);
-      SG_IALLOC(um, uint32_t, t + SG_PLAN_HIST_WORDS);
-      SG_IALLOC(un, int32_t, t * 32 * 8);
-      P.in2out = in2out; P.child = child; P.inv = inv;
-      P.down = sg_plan_ptrs{dord, dm, dn};
-      P.up = sg_plan_ptrs{uo, um, un};
-      I.down.nbr = child; I.down.order = dord; I.down.tile_mask = dm; I.down.nbr_tiles = dn;
-      I.down.rows = rows2; I.down.kvol = 8;
-      I.up.nbr = inv; I.up.order = uo; I.up.tile_mask = um; I.up.nbr_tiles = un;
-      I.up.rows = rows; I.up.kvol = 8;
-    }
-  }
-  {
-    const size_t nb = sg_spconv_pyramid_build_workspace_bytes(pl, L);
-    SG_IALLOC(ws2, char, nb);
-    SG_TRY(sg_spconv_pyramid_build(indices, num_rows, spatial_shape_host, L, pl, pws, pws_bytes, ws2, nb, is));
-  }
-  if (L > 1) {      // trivial plans of the 1x1 convs on the tail's identity branches
-    IdentSegs segs;
-    segs.n = L - 1;
-    for (int l = 0; l + 1 < L; ++l) {
-      const size_t tiles = (static_cast<size_t>(li[l].rows) + 31) / 32;
-      SG_IALLOC(ord, int32_t, tiles ? tiles * 32 : 32);
-      SG_IALLOC(tm, uint32_t, tiles + SG_PLAN_HIST_WORDS);
-      segs.order[l] = ord;
-      segs.mask[l] = tm;
-      segs.rows[l] = li[l].rows;
-      Plan &P = li[l].ident;
-      P.nbr = ord; P.order = ord; P.nbr_tiles = ord; P.tile_mask = tm;
-      P.rows = li[l].rows; P.kvol = 1;
-    }
-    ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs);
-  }
-#undef SG_IALLOC
-  if (hipEventRecord(st.ev_index, istream) != hipSuccess ||
-      hipStreamWaitEvent(as_stream(stream), st.ev_index, 0) != hipSuccess) {
-    set_error("sg_unet_forward: event record/wait failed");
-    return SG_ERR_LAUNCH;
-  }
+  std::unique_lock<std::mutex> guard;
+  size_t index_bytes = 0;
+  SG_TRY(unet_build_index("sg_unet_forward", L, indices, num_rows, spatial_shape_host, arena, arena_bytes, stream,
+                          li, &index_bytes, &guard));
   // ---- the convolutions: feature part of the arena
-  const size_t used = align_up(ix.off, 4096);
+  const size_t used = align_up(index_bytes, 4096);
   if (arena_bytes <= used) {
     set_error("sg_unet_forward: arena too small (%zu bytes)", arena_bytes);
     return SG_ERR_WORKSPACE;

@@ -29,6 +29,7 @@ from ..spconv import pytorch as spconv
 from ..util import cuda_cast, force_fp32, to_host, rle_decode, rle_encode_many, rle_encode_runs, rle_text_to_dicts
 from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
+from ..spconv.unet_train import UNetTrainExecutor
 from .blocks import MLP, ResidualBlock, UBlock
 
 
@@ -80,6 +81,8 @@ class SoftGroup(nn.Module):
         self.test_cfg = test_cfg
         self.fixed_modules = fixed_modules
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
+        # train() mode U-Nets as one autograd node each (csrc/unet_train.hip); SG_TRAIN_EXEC=0: the modules
+        self.use_train_executor = os.environ.get('SG_TRAIN_EXEC', '1') != '0'
         self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
@@ -131,7 +134,8 @@ class SoftGroup(nn.Module):
 
     # ---- derived state (packed weights, BatchNorm affines, native-executor descriptors, the
     #      results stream) is rebuilt on demand and never copied / pickled with the module
-    _DERIVED = ('_backbone_exec', '_tiny_exec', '_results_stream', '_grouping_const', '_scan_pool')
+    _DERIVED = ('_backbone_exec', '_tiny_exec', '_backbone_train_exec', '_tiny_train_exec', '_results_stream',
+                '_grouping_const', '_scan_pool')
 
     def invalidate_caches(self):
         """Call after writing parameters/buffers through ``tensor.data`` (EMA copies, custom
@@ -388,7 +392,16 @@ class SoftGroup(nn.Module):
                                                                  self.output_layer)
         if self.use_executor and ex.usable(x.features):
             return ex(x)
+        if self.use_train_executor and self._train_exec('_backbone_train_exec', self.unet, self.input_conv,
+                                                        self.output_layer).usable(x.features):
+            return self.__dict__['_backbone_train_exec'](x)      # backbone not frozen, train() mode
         return self.output_layer(self.unet(self.input_conv(x))).features
+
+    def _train_exec(self, slot, unet, input_conv, output_layer):
+        ex = self.__dict__.get(slot)
+        if ex is None:
+            ex = self.__dict__[slot] = UNetTrainExecutor(unet, input_conv, output_layer)
+        return ex
 
     def forward_backbone(self, input, input_map, x4_split=False, lvl_fusion=False):
         if x4_split:
@@ -455,7 +468,7 @@ class SoftGroup(nn.Module):
         # (constants of the configuration live on the device once, not re-uploaded per scan)
         cls_t, seg_thr, dummy_offsets, _ = self._grouping_constants(dev)
         sel = scores[:, cls_t].t() > _cfg(g, 'score_thr')                  # [n_seg, N]
-        sel &= (sel.sum(1, keepdim=True) >= min_npoint)                    # small classes are skipped
+        sel &= (sel.sum(1, keepdim=True, dtype=torch.int32) >= min_npoint)   # small classes are skipped
         seg, obj = sel.nonzero(as_tuple=True)                              # class-major, point-ascending
         if obj.numel() == 0:
             return (torch.zeros((0, 2), dtype=torch.int32, device=dev),
@@ -617,6 +630,10 @@ class SoftGroup(nn.Module):
                                                              self.tiny_unet_outputlayer)
         if self.use_executor and ex.usable(inst_feats.features):
             feats = inst_feats.replace_feature(ex(inst_feats))
+        elif self.use_train_executor and self._train_exec('_tiny_train_exec', self.tiny_unet, None,
+                                                          self.tiny_unet_outputlayer).usable(inst_feats.features):
+            # train() mode: forward and backward of the tiny U-Net are one C call each
+            feats = inst_feats.replace_feature(self.__dict__['_tiny_train_exec'](inst_feats))
         else:
             feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
         inst_map = inst_map.long()
@@ -832,7 +849,7 @@ class SoftGroup(nn.Module):
             with torch.no_grad():
                 proposals_idx, proposals_offset = self.forward_grouping(
                     semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float,
-                    self.grouping_cfg)
+                    self.grouping_cfg, batch_size=batch_size)
             max_prop = _cfg(self.train_cfg, 'max_proposal_num')
             if proposals_offset.shape[0] > max_prop:
                 proposals_offset = proposals_offset[:max_prop + 1]
@@ -853,14 +870,17 @@ class SoftGroup(nn.Module):
         weight = None
         if self.semantic_weight:
             weight = torch.tensor(self.semantic_weight, dtype=torch.float, device=semantic_scores.device)
-        losses = dict(semantic_loss=F.cross_entropy(semantic_scores, semantic_labels, weight=weight,
-                                                    ignore_index=self.ignore_label))
-        pos = instance_labels != self.ignore_label
-        if pos.sum() == 0:
-            losses['offset_loss'] = 0 * pt_offsets.sum()
-        else:
-            losses['offset_loss'] = F.l1_loss(pt_offsets[pos], pt_offset_labels[pos],
-                                              reduction='sum') / pos.sum()
+        losses = dict(semantic_loss=_cross_entropy(semantic_scores, semantic_labels, weight,
+                                                   self.ignore_label))
+        # offset loss over the points of instances (reference softgroup.py:163-169: boolean indexing,
+        # a host read of pos.sum() to branch on "no instance point").  Here without the read-back and
+        # without the compaction: masked sum / count, 0 * sum when the count is 0 -- the same value
+        # (summation order aside) and the same gradient.
+        pos = (instance_labels != self.ignore_label)
+        n_pos = pos.sum(dtype=torch.int32)
+        diff = (pt_offsets - pt_offset_labels).abs()
+        diff = torch.where(pos.unsqueeze(1), diff, torch.zeros((), dtype=diff.dtype, device=diff.device))
+        losses['offset_loss'] = diff.sum() / n_pos.clamp(min=1)
         return losses
 
     @force_fp32(apply_to=('cls_scores', 'mask_scores', 'iou_scores'))
@@ -949,6 +969,20 @@ class SoftGroup(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+def _cross_entropy(scores, labels, weight, ignore_index):
+    """F.cross_entropy(scores, labels, weight=weight, ignore_index=ignore_index) (reference
+    softgroup.py:159-160) as log_softmax + gather + masked mean: torch's nll_loss reduces [N] with a
+    single workgroup (285 us for the 600 k points of a config-3 step), this form is three
+    vectorised kernels.  Same value up to the order of the fp32 additions; same gradient."""
+    logp = F.log_softmax(scores.float(), dim=1)
+    valid = labels != ignore_index
+    tgt = labels.clamp(min=0).unsqueeze(1)
+    nll = -logp.gather(1, tgt).squeeze(1)
+    w = valid.float() if weight is None else weight[tgt.squeeze(1)] * valid
+    nll = torch.where(valid, nll, torch.zeros((), dtype=nll.dtype, device=nll.device))
+    return (nll * w).sum() / w.sum()
+
+
 def _take_rows(feats, index):
     """feats[index] through the HIP row-gather (devoxelize, softgroup.py:374,677-678); keeps
     autograd by falling back to torch indexing only when a gradient is required."""

@@ -33,7 +33,7 @@ class _Desc(C.Structure):
     _fields_ = [('n_levels', C.c_int), ('levels', C.POINTER(_Level)),
                 ('input_cin', C.c_int), ('input_w', C.c_void_p),
                 ('out_bn_scale', C.c_void_p), ('out_bn_shift', C.c_void_p),
-                ('input_cin_packed', C.c_int)]
+                ('input_cin_packed', C.c_int), ('arithmetic', C.c_int)]
 
 
 _desc_lock = threading.Lock()
@@ -214,6 +214,13 @@ class UNetExecutor:
         """x: SparseConvTensor -> features [M, planes[0]] of the U-Net output (after output_layer)"""
         lib = L.lib()
         d = self._descriptor()
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+            # bf16 autocast (a frozen backbone inside a training step, BASELINE config 3): the
+            # convolutions take bf16 operands like the module path's gather_conv_bf16 does -- one
+            # MFMA per product instead of the six of the fp32-accurate split; sums and stored
+            # activations stay fp32.  (a per-call copy: the cached descriptor is shared by threads)
+            d = _Desc.from_buffer_copy(d)
+            d.arithmetic = 2
         feats = x.features.contiguous()
         idx = x.indices.contiguous()
         M = feats.shape[0]

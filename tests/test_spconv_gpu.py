@@ -358,6 +358,42 @@ def test_split_precision_products_equal_fp32_mfma(cin, cout, n):
     assert rel <= 1e-5, rel
 
 
+@pytest.mark.parametrize('cin,cout,n', [(64, 64, 200000), (96, 96, 60000), (128, 128, 9000), (192, 192, 400),
+                                        (32, 64, 200000), (16, 32, 120000)])
+def test_bf16_operand_arithmetic_equals_fp32_kernel_on_rounded_operands(cin, cout, n):
+    """sg_spconv_set_arithmetic(2) / sg_unet_desc.arithmetic = 2 (what a frozen backbone runs in under
+    bf16 autocast): activations and weights rounded to nearest-even bf16, ONE MFMA per product, fp32
+    sums.  The products of two bf16 numbers are exact in fp32, so the result must equal the fp32-MFMA
+    kernel run on operands that were rounded beforehand, up to the order of the fp32 additions."""
+    from softgroup_amd import _lib as L
+    rng = np.random.default_rng(cin + n + 1)
+    shape = [320, 270, 150] if n > 20000 else [64, 64, 32]
+    idx = _scene(rng, n, shape)
+    M = len(idx)
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key='k').to(DEV)
+    conv_r = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key='k').to(DEV)
+    with torch.no_grad():
+        conv_r.weight.copy_(conv.weight.bfloat16().float())
+    x = (torch.randn(M, cin, device=DEV) * torch.exp(torch.empty(M, 1, device=DEV).uniform_(-4, 4))).contiguous()
+    lib = L.lib()
+    try:
+        with torch.no_grad():
+            L.check(lib.sg_spconv_set_arithmetic(2), 'sg_spconv_set_arithmetic')
+            got = conv(spconv.SparseConvTensor(x, t(idx), shape, 1)).features.double()
+            L.check(lib.sg_spconv_set_arithmetic(0), 'sg_spconv_set_arithmetic')
+            want = conv_r(spconv.SparseConvTensor(x.bfloat16().float(), t(idx), shape, 1)).features.double()
+            exact = conv(spconv.SparseConvTensor(x, t(idx), shape, 1)).features.double()
+    finally:
+        lib.sg_spconv_set_arithmetic(-1)
+    scale = want.abs().max(1, keepdim=True)[0].clamp(min=1e-30)
+    rel = ((got - want).abs() / scale).max().item()
+    gap = ((got - exact).abs() / scale).max().item()
+    print(f'{cin}->{cout} x {M} rows: max |bf16 operands - fp32 on rounded| / row scale = {rel:.2e}; '
+          f'distance to the fp32 result {gap:.2e}')
+    assert rel <= 1e-5, rel
+    assert 1e-5 < gap < 5e-2, gap        # it IS the reduced-precision arithmetic, and only that
+
+
 @pytest.mark.parametrize('cin,cout', [(48, 48), (16, 112), (64, 96)])
 def test_large_layer_with_a_partial_last_column_block(cin, cout):
     """>= 70 k output rows with Cout % 64 != 0 (the STPLS3D channels = 16 pyramid has 48 and 112):
