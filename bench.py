@@ -279,6 +279,42 @@ def config_legs(args):
         ts, fw = sorted(ts[2:]), sorted(fw[2:])
         rec[name] = {'ms_per_step': round(ts[len(ts) // 2], 2), 'forward_ms': round(fw[len(fw) // 2], 2),
                      'loss': round(float(loss.detach()), 4)}
+    # where a step goes (bf16 autocast; a device synchronisation on either side of every stage, so
+    # the sum exceeds the unsynchronised step above)
+    acc, names = {}, ('forward_backbone', 'point_wise_loss', '_native_proposals', 'clusters_voxelization',
+                      'forward_instance', 'instance_loss', 'parse_losses')
+
+    def timed(fn, label):
+        def wrap(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            acc[label] = acc.get(label, 0.0) + (time.perf_counter() - t0) * 1e3
+            return r
+        return wrap
+    for nm in names:
+        setattr(model, nm, timed(getattr(model, nm), nm))
+    reps = 5
+    for it in range(reps):
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss, _ = model(batch, return_loss=True)
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize()
+        acc['backward'] = acc.get('backward', 0.0) + (t1 - t0) * 1e3
+        acc['optimizer'] = acc.get('optimizer', 0.0) + (time.perf_counter() - t1) * 1e3
+    for nm in names:
+        delattr(model, nm)
+    rec['stages_ms_bf16_autocast'] = {k: round(v / reps, 3) for k, v in acc.items()}
+    rec['executors'] = {'backbone': 'sg_unet_forward (frozen: inference executor, bf16 operands under autocast)',
+                        'tiny_unet': 'sg_unet_train_forward / sg_unet_train_backward',
+                        'grouping': 'sg_scan_grouping (proposals only)'}
     legs['train_step_s3dis'] = rec
     return legs
 

@@ -610,7 +610,8 @@ typedef struct sg_grouping_cfg {
   float radius;              /* grouping_cfg.radius */
   int batch_size;
   float voxel_scale;         /* instance_voxel_cfg.scale */
-  int voxel_shape;           /* instance_voxel_cfg.spatial_shape */
+  int voxel_shape;           /* instance_voxel_cfg.spatial_shape; 0 = stop after the proposals (the
+                                training step voxelises them itself, with rand_quantize) */
   int feat_channels;         /* C of point_feats */
 } sg_grouping_cfg;
 typedef struct sg_grouping_result {   /* host */

@@ -373,7 +373,7 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
   static const char *kWhat = "sg_scan_grouping";
   SG_REQUIRE(cfg != nullptr && res != nullptr, "sg_scan_grouping: null descriptor");
   SG_REQUIRE(cfg->n_points >= 0 && cfg->n_sem_classes >= 1 && cfg->n_seg >= 0 && cfg->n_seg <= kMaxSeg &&
-                 cfg->batch_size >= 1 && cfg->feat_channels >= 1 && cfg->voxel_shape >= 1,
+                 cfg->batch_size >= 1 && cfg->feat_channels >= 1 && cfg->voxel_shape >= 0,
              "sg_scan_grouping: bad configuration (n_seg must be <= %d)", kMaxSeg);
   memset(res, 0, sizeof(*res));
   hipStream_t stream = as_stream(stream_);
@@ -438,6 +438,10 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
   proposal_map_kernel<<<grid_for(S, 256), 256, 0, stream>>>(pairs, S, obj);
   res->proposals_idx = ar.at(pairs);
   res->proposals_offset = ar.at(poff);
+  if (cfg->voxel_shape == 0) {      // proposals only (the training step voxelises with rand_quantize)
+    res->arena_used = ar.off;
+    return check_launch(kWhat);
+  }
 
   // ---- 4. proposal voxelisation (softgroup.py:655-709, rand_quantize = False)
   SG_TAKE(cscale, float, n_prop);

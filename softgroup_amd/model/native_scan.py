@@ -80,6 +80,10 @@ def grouping(cfg, scores, pt_offsets, coords_float, batch_idxs, point_feats):
     if res.sum_npoint == 0:
         return None
     S, nP, M = res.sum_npoint, res.n_proposals, res.n_voxels
+    if cfg.voxel_shape == 0:
+        return dict(proposals_idx=_view(arena, res.proposals_idx, torch.int32, S, 2).clone(),
+                    proposals_offset=_view(arena, res.proposals_offset, torch.int32, nP + 1).clone(),
+                    n_proposals=nP)
     return dict(
         proposals_idx=_view(arena, res.proposals_idx, torch.int32, S, 2).clone(),
         proposals_offset=_view(arena, res.proposals_offset, torch.int32, nP + 1).clone(),

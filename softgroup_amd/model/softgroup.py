@@ -348,6 +348,26 @@ class SoftGroup(nn.Module):
             torch.cuda.current_stream().synchronize()      # once: other streams may use them next
         return const[ck]
 
+    def _native_proposals(self, semantic_scores, pt_offsets, batch_idxs, coords_float, batch_size):
+        """forward_grouping's result from the native driver stopped after the clustering (the training
+        step voxelises the proposals itself, with rand_quantize): same values, one C call"""
+        from . import native_scan as NS
+        g = self.grouping_cfg
+        dev = semantic_scores.device
+        _, seg_thr, _, cls32 = self._grouping_constants(dev)
+        scores = semantic_scores.float().softmax(dim=-1)
+        cfg = NS.GroupingCfg(
+            n_points=scores.size(0), n_sem_classes=scores.size(1), n_seg=cls32.numel(),
+            seg_class=cls32.data_ptr(), seg_thr=seg_thr.data_ptr(), score_thr=_cfg(g, 'score_thr'),
+            min_npoint=_cfg(self.test_cfg, 'min_npoint'), radius=_cfg(g, 'radius'), batch_size=int(batch_size),
+            voxel_scale=1.0, voxel_shape=0, feat_channels=1)
+        r = NS.grouping(cfg, scores, pt_offsets.float().contiguous(), coords_float.contiguous(),
+                        batch_idxs.int().contiguous(), None)
+        if r is None:
+            return (torch.zeros((0, 2), dtype=torch.int32, device=dev),
+                    torch.zeros((0, ), dtype=torch.int32, device=dev))
+        return r['proposals_idx'], r['proposals_offset']
+
     def _native_grouping_and_refinement(self, semantic_scores, pt_offsets, batch_idxs, coords_float,
                                         output_feats, batch_size):
         """forward_grouping + clusters_voxelization + forward_instance with the grouping head and the
@@ -847,9 +867,15 @@ class SoftGroup(nn.Module):
                                            instance_labels, pt_offset_labels))
         if not self.semantic_only:
             with torch.no_grad():
-                proposals_idx, proposals_offset = self.forward_grouping(
-                    semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float,
-                    self.grouping_cfg, batch_size=batch_size)
+                g = self.grouping_cfg
+                if (self.use_native_scan and semantic_scores.is_cuda and not _cfg(g, 'with_pyramid', False)
+                        and not _cfg(g, 'with_octree', False)):
+                    proposals_idx, proposals_offset = self._native_proposals(
+                        semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float, batch_size)
+                else:
+                    proposals_idx, proposals_offset = self.forward_grouping(
+                        semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float,
+                        self.grouping_cfg, batch_size=batch_size)
             max_prop = _cfg(self.train_cfg, 'max_proposal_num')
             if proposals_offset.shape[0] > max_prop:
                 proposals_offset = proposals_offset[:max_prop + 1]

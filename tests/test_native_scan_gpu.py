@@ -92,6 +92,30 @@ def test_native_grouping_pieces_equal_operator_path():
     assert int(r['voxel_offsets'][0]) == 0
 
 
+def test_native_proposals_on_a_two_scene_batch_equal_forward_grouping():
+    """the training step's use of the driver (voxel_shape = 0: stop after the clustering) on a batch
+    of two scenes: points of different scenes never share a proposal, values and order equal
+    forward_grouping's (reference softgroup.py:411-480 with batch_idxs from collate_fn)"""
+    from softgroup_amd.data import collate_device, make_item
+    items = []
+    for i in range(2):
+        xyz, rgb, inst = synthetic.scene_s2(seed=11 + i, n=50000, room_scale=0.55)
+        sem = np.where(inst >= 0, 2 + inst % 16, 0).astype(np.int64)
+        items.append(make_item(xyz, rgb, 50, sem, inst, f's{i}'))
+    b = collate_device(items)
+    model = synthetic.build_model(seed=0)
+    with torch.no_grad():
+        sem, off, _ = _backbone(model, b)
+        pidx, poff = model.forward_grouping(sem, off, b['batch_idxs'], b['coords_float'], model.grouping_cfg,
+                                            batch_size=2)
+        n_idx, n_off = model._native_proposals(sem, off, b['batch_idxs'], b['coords_float'], 2)
+    assert pidx.shape[0] > 1000 and poff.numel() > 3
+    assert torch.equal(n_idx, pidx) and torch.equal(n_off, poff.int())
+    scene_of = b['batch_idxs'][pidx[:, 1].long()]
+    first = scene_of[poff[:-1].long()]
+    assert torch.equal(scene_of, first.repeat_interleave((poff[1:] - poff[:-1]).long()))
+
+
 def test_native_grouping_without_proposals_falls_back_to_the_dummy_tensor():
     """no class passes the score threshold -> the driver reports nothing and forward_test takes the
     reference's dummy 2-voxel path (softgroup.py:664-673)"""

@@ -360,6 +360,8 @@ def test_bf16_autocast_losses_explained():
           points both runs agree on."""
     model, batch, ref, seed = _train_case('scannet_frozen')
     model.train()
+    model.use_native_scan = False      # the proposals are intercepted at forward_grouping (the native
+    #                                    driver returns the same ones, tests/test_native_scan_gpu.py)
     torch.manual_seed(seed)
     _, fp32 = model(batch, return_loss=True)
     keep = {}
