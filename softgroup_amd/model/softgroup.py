@@ -923,25 +923,29 @@ class SoftGroup(nn.Module):
         instance_pointnum = instance_pointnum.int().contiguous()
         ious_on_cluster = ops.get_mask_iou_on_cluster(pidx, poff, instance_labels, instance_pointnum)
 
-        fg = instance_cls != self.ignore_label                 # drop background GT columns
-        fg_cls = instance_cls[fg]
-        fg_ious = ious_on_cluster[:, fg]
-        n_prop, n_gt = fg_ious.shape
-        assigned = fg_ious.new_full((n_prop, ), -1, dtype=torch.long)
+        # Proposal -> ground-truth assignment (reference softgroup.py:196-222).  The reference drops the
+        # background GT columns by boolean indexing and writes the matches through boolean masks -- five
+        # host read-backs of a count.  Here the background columns stay and are masked to IoU -1 (they
+        # can never win a maximum; column order, hence every argmax tie-break, is unchanged) and the
+        # masked writes are torch.where: same assignment, no read-back.
+        fg = instance_cls != self.ignore_label
+        n_prop, n_gt = ious_on_cluster.shape
+        fg_ious = torch.where(fg.unsqueeze(0), ious_on_cluster, ious_on_cluster.new_full((), -1.0))
         max_iou, argmax_iou = fg_ious.max(1)
-        pos = max_iou >= _cfg(tc, 'pos_iou_thr')
-        assigned[pos] = argmax_iou[pos]
+        assigned = torch.where(max_iou >= _cfg(tc, 'pos_iou_thr'), argmax_iou, argmax_iou.new_full((), -1))
         if _cfg(tc, 'match_low_quality', False):               # best proposal of each GT is positive
+            # (the reference loops over the GTs in order, a later GT overwrites an earlier one on the
+            # same proposal: the largest qualifying GT index per proposal)
             gt_max, gt_arg = fg_ious.max(0)
-            min_pos = _cfg(tc, 'min_pos_thr', 0)
-            for g in range(n_gt):
-                if gt_max[g] >= min_pos:
-                    assigned[gt_arg[g]] = g
+            cand = torch.where(gt_max >= _cfg(tc, 'min_pos_thr', 0), torch.arange(n_gt, device=dev),
+                               gt_arg.new_full((), -1))
+            lowq = cand.new_full((n_prop, ), -1).scatter_reduce(0, gt_arg, cand, 'amax', include_self=True)
+            assigned = torch.where(lowq >= 0, lowq, assigned)
 
         # classification: 0..K-1 foreground, K background
-        labels = fg_cls.new_full((n_prop, ), self.instance_classes)
         pos = assigned >= 0
-        labels[pos] = fg_cls[assigned[pos]]
+        labels = torch.where(pos, instance_cls[assigned.clamp(min=0)],
+                             instance_cls.new_full((), self.instance_classes))
         losses = dict(cls_loss=F.cross_entropy(cls_scores, labels))
 
         # mask loss on the score slice of the assigned class
@@ -951,14 +955,14 @@ class SoftGroup(nn.Module):
         mask_label = ops.get_mask_label(pidx, poff, instance_labels, instance_cls, instance_pointnum,
                                         ious_on_cluster, _cfg(tc, 'pos_iou_thr'))
         weight = (mask_label != -1).float()
-        mask_label[mask_label == -1.] = 0.5                    # ignored points: value irrelevant
+        mask_label = torch.where(mask_label == -1., mask_label.new_full((), 0.5), mask_label)   # ignored points
         mask_loss = F.binary_cross_entropy(mask_sig, mask_label, weight=weight, reduction='sum')
         losses['mask_loss'] = mask_loss / (weight.sum() + 1)
 
         # IoU-score regression against the IoU of the predicted mask
         ious = ops.get_mask_iou_on_pred(pidx, poff, instance_labels, instance_pointnum,
                                         mask_sig.detach().contiguous())
-        gt_ious, _ = ious[:, fg].max(1)
+        gt_ious, _ = torch.where(fg.unsqueeze(0), ious, ious.new_full((), -1.0)).max(1)
         rows = torch.arange(labels.size(0), device=dev)
         w = (labels < self.instance_classes).float()
         iou_loss = F.mse_loss(iou_scores[rows, labels], gt_ious, reduction='none')
