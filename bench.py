@@ -55,6 +55,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--points', type=int, default=150000)
     ap.add_argument('--contexts', type=int, default=4, help='scans in flight in the timed region')
+    ap.add_argument('--switch-interval-us', type=int, default=0,
+                    help='sys.setswitchinterval for the process (0 = leave CPython\'s 5 ms)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-legs', action='store_true')
@@ -568,6 +570,8 @@ def stub_main(args, rank, world, devices):
 
 def main():
     args = parse()
+    if args.switch_interval_us > 0:
+        sys.setswitchinterval(args.switch_interval_us * 1e-6)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
