@@ -95,6 +95,8 @@ int sg_voxelize_bp(const float *d_out, const int32_t *rules, int num_voxels, int
  *   count : start_len[i,1] = min(cnt,1000); meta[0] = total (int32, saturates at INT32_MAX)
  *   (caller exclusive-scans start_len[:,1] into start_len[:,0] -- sg_exclusive_scan_startlen)
  *   fill  : idx[start .. start+len) = neighbours.
+ * All three calls of one query share ONE workspace: the grid lives there, and the count pass parks
+ * the finished (sorted) lists of up to 64 entries there, which the fill pass only copies.
  * The reference's `nActive > n*meanActive` retry protocol (functions.py:258-266) is kept in
  * the Python facade; the kernels never truncate.
  * ---------------------------------------------------------------------------------------- */

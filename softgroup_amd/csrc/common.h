@@ -94,6 +94,49 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
+// Several buffers filled by ONE launch (each hipMemsetAsync is a graph node of its own: ~5 us of GPU
+// time and a launch gap; an index build used to issue ten of them).  Regions are 4-byte aligned, sizes
+// multiples of 4; `byte` is replicated like memset's value.
+constexpr int kFillMax = 12;
+struct FillList {
+  uint32_t *p[kFillMax];
+  size_t words[kFillMax];
+  uint32_t pattern[kFillMax];
+  int n = 0;
+  void add(void *ptr, size_t bytes, int byte) {
+    if (bytes == 0 || ptr == nullptr) return;
+    p[n] = static_cast<uint32_t *>(ptr);
+    words[n] = bytes / 4;
+    pattern[n] = 0x01010101u * static_cast<uint32_t>(byte & 0xff);
+    ++n;
+  }
+};
+static __global__ void __launch_bounds__(256) fill_many_kernel(FillList f) {
+  const int r = blockIdx.y;
+  uint32_t *p = f.p[r];
+  const size_t w = f.words[r];
+  const uint32_t v = f.pattern[r];
+  // 16-byte stores over the aligned middle, scalar head / tail
+  const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) / 4 % 4;
+  const size_t h = head < w ? head : w;
+  const size_t quads = (w - h) / 4;
+  uint4 *q = reinterpret_cast<uint4 *>(p + h);
+  const uint4 vv = make_uint4(v, v, v, v);
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < quads; i += gridDim.x * 256ull) q[i] = vv;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < h) p[threadIdx.x] = v;
+    const size_t t0 = h + quads * 4;
+    if (threadIdx.x < w - t0) p[t0 + threadIdx.x] = v;
+  }
+}
+inline void fill_many(const FillList &f, hipStream_t stream) {
+  if (f.n == 0) return;
+  size_t mx = 0;
+  for (int i = 0; i < f.n; ++i) mx = f.words[i] > mx ? f.words[i] : mx;
+  const int gx = grid_for(static_cast<int64_t>(mx / 4 + 1), 256, 1024);
+  fill_many_kernel<<<dim3(gx, f.n), 256, 0, stream>>>(f);
+}
+
 // conv arithmetic requested by the calling thread (spconv_conv.hip); -1 = none
 extern thread_local int t_conv_arith;
 

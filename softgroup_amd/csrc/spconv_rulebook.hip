@@ -729,8 +729,12 @@ int sg_spconv_pyramid_rows(const int32_t *indices, int M0, const int32_t *shape_
     return SG_ERR_WORKSPACE;
   }
   const int L = n_levels;
-  hipMemsetAsync(w.keys, 0xff, static_cast<size_t>(L) * w.cap * 8, stream);
-  hipMemsetAsync(w.vals, 0x7f, static_cast<size_t>(L) * w.cap * 4, stream);
+  {
+    FillList f;
+    f.add(w.keys, static_cast<size_t>(L) * w.cap * 8, 0xff);
+    f.add(w.vals, static_cast<size_t>(L) * w.cap * 4, 0x7f);
+    fill_many(f, stream);
+  }
   const Shape3 shape{shape_host[0], shape_host[1], shape_host[2]};
   pyr_insert_kernel<<<(M0 + 255) / 256, 256, 0, stream>>>(indices, M0, shape, L, w.keys, w.vals, w.cap,
                                                          w.slot);
@@ -814,17 +818,6 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
       SG_REQUIRE(levels[l].in2out && levels[l].child && levels[l].inv && levels[l].down.order &&
                      levels[l].up.order, "sg_spconv_pyramid_build: level %d: missing output pointers", l);
   }
-  // ---- coordinates, strided pairs, SubM tables of all levels
-  const int g_all = grid_for(static_cast<int64_t>(L) * M0, 256, 4096);
-  pyr_emit_kernel<<<g_all, 256, 0, stream>>>(indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
-  if (L > 1) {
-    for (int l = 0; l + 1 < L; ++l)
-      if (levels[l + 1].rows > 0)
-        hipMemsetAsync(levels[l].child, 0xff, static_cast<size_t>(levels[l + 1].rows) * 8 * 4, stream);
-    pyr_link_kernel<<<grid_for(static_cast<int64_t>(L - 1) * M0, 256, 4096), 256, 0, stream>>>(
-        indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
-  }
-  pyr_subm_kernel<<<grid_for(o.pre27[L], 256, 8192), 256, 0, stream>>>(L, w.keys, w.rowtab, w.cap, o);
   // ---- tile plans of all gather tables as one segmented problem
   for (int l = 0; l < L; ++l) {
     if (levels[l].rows > 0) add_seg(levels[l].nbr, levels[l].rows, 27, levels[l].subm);
@@ -850,10 +843,24 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
     set_error("sg_spconv_pyramid_build: build workspace too small");
     return SG_ERR_WORKSPACE;
   }
+  {      // one launch: the strided tables' "no child" marks and the offset histogram of the plans
+    FillList f;
+    for (int l = 0; l + 1 < L; ++l)
+      if (levels[l + 1].rows > 0) f.add(levels[l].child, static_cast<size_t>(levels[l + 1].rows) * 8 * 4, 0xff);
+    f.add(freq, kPyrMaxSegs * 32 * 4, 0);
+    fill_many(f, stream);
+  }
+  // ---- coordinates, strided pairs, SubM tables of all levels
+  const int g_all = grid_for(static_cast<int64_t>(L) * M0, 256, 4096);
+  pyr_emit_kernel<<<g_all, 256, 0, stream>>>(indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
+  if (L > 1) {
+    pyr_link_kernel<<<grid_for(static_cast<int64_t>(L - 1) * M0, 256, 4096), 256, 0, stream>>>(
+        indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
+  }
+  pyr_subm_kernel<<<grid_for(o.pre27[L], 256, 8192), 256, 0, stream>>>(L, w.keys, w.rowtab, w.cap, o);
   int max_rows = 0;
   for (int i = 0; i < P.n; ++i) max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
   const dim3 grid((max_rows + 255) / 256, P.n);
-  hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);
   plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
   plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
   plan_key_all_kernel<<<grid, 256, 0, stream>>>(P, bitpos, mask);

@@ -181,9 +181,13 @@ int sg_voxelize_idx_build(const int64_t *coords, int n, int ncol, int mode, int3
   hipMemcpyAsync(meta, init_meta, sizeof(init_meta), hipMemcpyHostToDevice, stream);
   if (n == 0) return SG_OK;
   const int grid = (n + 255) / 256;
-  hipMemsetAsync(w.table, 0x7f, static_cast<size_t>(w.cap) * 4, stream);
-  hipMemsetAsync(w.count, 0, static_cast<size_t>(n) * 4, stream);
-  hipMemsetAsync(w.last, 0, static_cast<size_t>(n) * 4, stream);
+  {
+    FillList f;
+    f.add(w.table, static_cast<size_t>(w.cap) * 4, 0x7f);
+    f.add(w.count, static_cast<size_t>(n) * 4, 0);
+    f.add(w.last, static_cast<size_t>(n) * 4, 0);
+    fill_many(f, stream);
+  }
   vox_insert_kernel<<<grid, 256, 0, stream>>>(coords, n, ncol, w.table, w.cap - 1, w.slot_of);
   vox_owner_kernel<<<grid, 256, 0, stream>>>(w.table, w.slot_of, n, w.owner);
   const int32_t *owner = w.owner;
@@ -209,8 +213,12 @@ int sg_voxelize_idx_fill(const int64_t *coords, int n, int ncol, int mode, const
     return SG_ERR_WORKSPACE;
   }
   if (n == 0 || num_voxels == 0) return SG_OK;
-  hipMemsetAsync(out_map, 0, static_cast<size_t>(num_voxels) * (max_active + 1) * 4, stream);
-  hipMemsetAsync(w.cursor, 0, static_cast<size_t>(num_voxels) * 4, stream);
+  {
+    FillList f;
+    f.add(out_map, static_cast<size_t>(num_voxels) * (max_active + 1) * 4, 0);
+    f.add(w.cursor, static_cast<size_t>(num_voxels) * 4, 0);
+    fill_many(f, stream);
+  }
   const int32_t *count = w.count;
   int32_t *csr = w.csr_off;
   auto in = [count] __device__(int64_t v) { return count[v]; };
