@@ -314,6 +314,42 @@ def config_legs(args):
     for nm in names:
         delattr(model, nm)
     rec['stages_ms_bf16_autocast'] = {k: round(v / reps, 3) for k, v in acc.items()}
+    # conv launches of a training step (forward + input gradient; fp32 arithmetic): algorithmic bytes /
+    # flops from one step on the module path (one Python call per launch, SURVEY 8(d) formulas),
+    # time from the in-library HIP events over 3 steps on the executors
+    from softgroup_amd import _lib
+    from softgroup_amd.spconv import core as spcore
+    try:
+        prof = spcore.ConvProfiler()
+        spcore.PROFILER = prof
+        model.use_executor = model.use_train_executor = False
+        loss, _ = model(batch, return_loss=True)
+        opt.zero_grad()
+        loss.backward()
+        s = prof.summary()
+    finally:
+        spcore.PROFILER = None
+        model.use_executor = model.use_train_executor = True
+    lib = _lib.lib()
+    _lib.check(lib.sg_spconv_profile(1), 'sg_spconv_profile')
+    for it in range(3):
+        loss, _ = model(batch, return_loss=True)
+        opt.zero_grad()
+        loss.backward()
+    torch.cuda.synchronize()
+    ms, nl = _lib.C.c_double(0), _lib.C.c_int(0)
+    _lib.check(lib.sg_spconv_profile_read(_lib.C.byref(ms), _lib.C.byref(nl)), 'sg_spconv_profile_read')
+    _lib.check(lib.sg_spconv_profile(0), 'sg_spconv_profile')
+    conv_ms = ms.value / 3
+    rec['conv_forward_and_input_gradient_fp32'] = {
+        'kernel': 'gather_conv_persistent_kernel: frozen backbone forward + tiny U-Net forward and input gradients',
+        'launches_per_step': nl.value // 3, 'launches_on_the_module_path': s['launches'],
+        'ms_per_step': round(conv_ms, 3), 'algorithmic_bytes_per_step': int(s['bytes']),
+        'flops_per_step': int(s['flops']), 'bound': 'hbm',
+        'achieved': round(s['bytes'] / (conv_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+        'frac': round(s['bytes'] / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        'note': 'weight gradients (sg_spconv_wgrad) are not in this entry: tools/train_conv_bench.py, '
+                'profiles/r04_train_conv.txt'}
     rec['executors'] = {'backbone': 'sg_unet_forward (frozen: inference executor, bf16 operands under autocast)',
                         'tiny_unet': 'sg_unet_train_forward / sg_unet_train_backward',
                         'grouping': 'sg_scan_grouping (proposals only)'}

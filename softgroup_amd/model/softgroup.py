@@ -923,29 +923,10 @@ class SoftGroup(nn.Module):
         instance_pointnum = instance_pointnum.int().contiguous()
         ious_on_cluster = ops.get_mask_iou_on_cluster(pidx, poff, instance_labels, instance_pointnum)
 
-        # Proposal -> ground-truth assignment (reference softgroup.py:196-222).  The reference drops the
-        # background GT columns by boolean indexing and writes the matches through boolean masks -- five
-        # host read-backs of a count.  Here the background columns stay and are masked to IoU -1 (they
-        # can never win a maximum; column order, hence every argmax tie-break, is unchanged) and the
-        # masked writes are torch.where: same assignment, no read-back.
         fg = instance_cls != self.ignore_label
-        n_prop, n_gt = ious_on_cluster.shape
-        fg_ious = torch.where(fg.unsqueeze(0), ious_on_cluster, ious_on_cluster.new_full((), -1.0))
-        max_iou, argmax_iou = fg_ious.max(1)
-        assigned = torch.where(max_iou >= _cfg(tc, 'pos_iou_thr'), argmax_iou, argmax_iou.new_full((), -1))
-        if _cfg(tc, 'match_low_quality', False):               # best proposal of each GT is positive
-            # (the reference loops over the GTs in order, a later GT overwrites an earlier one on the
-            # same proposal: the largest qualifying GT index per proposal)
-            gt_max, gt_arg = fg_ious.max(0)
-            cand = torch.where(gt_max >= _cfg(tc, 'min_pos_thr', 0), torch.arange(n_gt, device=dev),
-                               gt_arg.new_full((), -1))
-            lowq = cand.new_full((n_prop, ), -1).scatter_reduce(0, gt_arg, cand, 'amax', include_self=True)
-            assigned = torch.where(lowq >= 0, lowq, assigned)
-
-        # classification: 0..K-1 foreground, K background
-        pos = assigned >= 0
-        labels = torch.where(pos, instance_cls[assigned.clamp(min=0)],
-                             instance_cls.new_full((), self.instance_classes))
+        labels = _assign_proposals(ious_on_cluster, instance_cls, fg, _cfg(tc, 'pos_iou_thr'),
+                                   _cfg(tc, 'match_low_quality', False), _cfg(tc, 'min_pos_thr', 0),
+                                   self.instance_classes)
         losses = dict(cls_loss=F.cross_entropy(cls_scores, labels))
 
         # mask loss on the score slice of the assigned class
@@ -999,6 +980,31 @@ class SoftGroup(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+def _assign_proposals(ious_on_cluster, instance_cls, fg, pos_iou_thr, match_low_quality, min_pos_thr,
+                      background_label):
+    """Proposal -> class label through the ground-truth assignment of the reference
+    (softgroup.py:196-222): a proposal is positive for the GT of its largest IoU if that IoU reaches
+    `pos_iou_thr`; with `match_low_quality` every GT whose best IoU reaches `min_pos_thr` also claims
+    its best proposal (GTs in order, a later one overwrites an earlier one).  The reference drops the
+    background GT columns by boolean indexing and writes the matches through boolean masks -- five
+    host read-backs of a count.  Here the background columns stay and are masked to IoU -1 (they can
+    never win a maximum; column order, hence every argmax tie-break, is unchanged) and the masked
+    writes are torch.where: same labels, no read-back."""
+    n_prop, n_gt = ious_on_cluster.shape
+    dev = ious_on_cluster.device
+    fg_ious = torch.where(fg.unsqueeze(0), ious_on_cluster, ious_on_cluster.new_full((), -1.0))
+    max_iou, argmax_iou = fg_ious.max(1)
+    assigned = torch.where(max_iou >= pos_iou_thr, argmax_iou, argmax_iou.new_full((), -1))
+    if match_low_quality:
+        gt_max, gt_arg = fg_ious.max(0)
+        cand = torch.where(gt_max >= min_pos_thr, torch.arange(n_gt, device=dev), gt_arg.new_full((), -1))
+        lowq = cand.new_full((n_prop, ), -1).scatter_reduce(0, gt_arg, cand, 'amax', include_self=True)
+        assigned = torch.where(lowq >= 0, lowq, assigned)
+    # classification: 0..K-1 foreground, K background
+    return torch.where(assigned >= 0, instance_cls[assigned.clamp(min=0)],
+                       instance_cls.new_full((), background_label))
+
+
 def _cross_entropy(scores, labels, weight, ignore_index):
     """F.cross_entropy(scores, labels, weight=weight, ignore_index=ignore_index) (reference
     softgroup.py:159-160) as log_softmax + gather + masked mean: torch's nll_loss reduces [N] with a
