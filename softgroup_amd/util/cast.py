@@ -71,13 +71,11 @@ def _pad_block(dev):
     return t
 
 
-def to_host(tensors):
-    """dict of tensors -> dict of numpy arrays.  All CUDA tensors travel through ONE pinned staging
-    block (torch's caching host allocator recycles it) with asynchronous copies and a single stream
-    synchronisation, instead of one pageable, synchronous ``.cpu()`` per tensor (the reference's
-    result dicts are built that way, softgroup.py:323-360; round 3 counted 31 copy nodes per scan).
-    The arrays are views of the staging block, which they keep alive."""
-    import numpy as np  # noqa: F401
+def to_host_begin(tensors, stream=None):
+    """First half of ``to_host``: pack the CUDA tensors with one cat kernel and start their ONE
+    device-to-host copy -- on `stream` if given (it first waits for the current stream: a side stream
+    lets the copy overlap whatever the caller enqueues next), else on the current stream.  Returns a
+    handle for ``to_host_end``; the source tensors must stay referenced until then."""
     out, plan, total = {}, [], 0
     for k, t in tensors.items():
         if not t.is_cuda:
@@ -87,21 +85,47 @@ def to_host(tensors):
         nb = t.numel() * t.element_size()
         plan.append((k, t, total, nb))
         total += (nb + 255) // 256 * 256
+    stage = done = None
     if plan:
-        # packed on the device by ONE cat kernel, then ONE device-to-host copy (every copy node costs
-        # ~10 us of blit set-up whatever its size; a scan returns eight dense arrays)
         dev = plan[0][1].device
-        pad = _pad_block(dev)
-        pieces, at = [], 0
-        for k, t, off, nb in plan:
-            if off > at:
-                pieces.append(pad[:off - at])
-            pieces.append(t.reshape(-1).view(torch.uint8))
-            at = off + nb
-        packed = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
-        stage = torch.empty(max(at, 1), dtype=torch.uint8, pin_memory=True)
-        stage.copy_(packed, non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()
+        cur = torch.cuda.current_stream(dev)
+        run = cur
+        if stream is not None and stream != cur:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            stream.wait_event(ready)
+            run = stream
+        with torch.cuda.stream(run):
+            pad = _pad_block(dev)
+            pieces, at = [], 0
+            for k, t, off, nb in plan:
+                if off > at:
+                    pieces.append(pad[:off - at])
+                pieces.append(t.reshape(-1).view(torch.uint8))
+                at = off + nb
+            packed = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+            stage = torch.empty(max(at, 1), dtype=torch.uint8, pin_memory=True)
+            stage.copy_(packed, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(run)
+    return list(tensors), out, plan, stage, done, (packed if plan else None)
+
+
+def to_host_end(handle):
+    keys, out, plan, stage, done, _packed = handle
+    if plan:
+        done.synchronize()
         for k, t, off, nb in plan:
             out[k] = stage[off:off + nb].view(t.dtype).view(t.shape).numpy()
-    return {k: out[k] for k in tensors}
+    return {k: out[k] for k in keys}
+
+
+def to_host(tensors):
+    """dict of tensors -> dict of numpy arrays.  All CUDA tensors are packed on the device by ONE cat
+    kernel and travel in ONE device-to-host copy into a pinned staging block (torch's caching host
+    allocator recycles it; every copy node costs ~10 us of blit set-up whatever its size, and a scan
+    returns eight dense arrays), with a single wait -- instead of one pageable, synchronous ``.cpu()``
+    per tensor (the reference's result dicts are built that way, softgroup.py:323-360; round 3
+    counted 31 copy nodes per scan).  The arrays are views of the staging block, which they keep
+    alive: release results you no longer need, or every scan page-locks a fresh block."""
+    return to_host_end(to_host_begin(tensors))
