@@ -54,7 +54,10 @@ def parse():
     ap.add_argument('--steps', type=int, default=160)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--points', type=int, default=150000)
-    ap.add_argument('--contexts', type=int, default=4, help='scans in flight in the timed region')
+    ap.add_argument('--contexts', type=int, default=0,
+                    help='scans in flight in the timed region; 0 = 3 for regions of up to 40 steps, 5 beyond '
+                         '(a short region is one pipeline fill and one drain, which cost more with more scans '
+                         'in flight: profiles/README.md, round 4)')
     ap.add_argument('--switch-interval-us', type=int, default=0,
                     help='sys.setswitchinterval for the process (0 = leave CPython\'s 5 ms)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -610,6 +613,8 @@ def stub_main(args, rank, world, devices):
 
 def main():
     args = parse()
+    if args.contexts <= 0:
+        args.contexts = 3 if args.steps <= 40 else 5
     if args.switch_interval_us > 0:
         sys.setswitchinterval(args.switch_interval_us * 1e-6)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
