@@ -115,12 +115,13 @@ def device_identity(stub, rank):
 
 def stage_times(model, batch, reps=5, warm=1):
     """HIP-event timing of the forward's stages on the current stream (orientation only); `warm`
-    untimed passes first (allocator, plan caches), then the mean of `reps`."""
+    untimed passes first (allocator, plan caches), then the MEDIAN of `reps` per stage (a shared box
+    throws an occasional 50-100 ms hiccup into one repetition)."""
     from softgroup_amd import ops
     import softgroup_amd.spconv.pytorch as spconv
     names = ['voxelize+backbone+heads', 'grouping', 'proposal_voxelization', 'tiny_unet+heads',
              'instances+rle']
-    acc = [0.0] * len(names)
+    acc = [[] for _ in names]
     b = batch
     for it in range(warm + reps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
@@ -144,11 +145,11 @@ def stage_times(model, batch, reps=5, warm=1):
         if it < warm:
             continue
         for i in range(len(names)):
-            acc[i] += ev[i].elapsed_time(ev[i + 1]) / reps
+            acc[i].append(ev[i].elapsed_time(ev[i + 1]))
     info = dict(points=int(b['coords_float'].shape[0]), voxels=int(b['voxel_coords'].shape[0]),
                 grouped_points=None, proposals=int(max(poff.numel() - 1, 0)),
                 proposal_points=int(pidx.shape[0]), instances=len(preds))
-    return {n: round(t, 3) for n, t in zip(names, acc)}, info
+    return {n: round(sorted(t)[len(t) // 2], 3) for n, t in zip(names, acc)}, info
 
 
 
@@ -192,14 +193,17 @@ def config_legs(args):
         with torch.no_grad():
             for _ in range(2):
                 model(batch)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
+            ts = []
+            for _ in range(7):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 model(batch)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 5 * 1e3
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ts.sort()
             stages, info = stage_times(model, batch, reps=5)
-        return {'ms_per_scan_unpipelined': round(ms, 3), 'stages_ms': stages, 'scene': info}
+        return {'ms_per_scan_unpipelined': round(ts[len(ts) // 2], 3), 'ms_per_scan_min_max': [round(ts[0], 3), round(ts[-1], 3)],
+                'stages_ms': stages, 'scene': info}
 
     # ---- config 2 again, but with a stand-in for a TRAINED checkpoint (synthetic.fit_model_to_scenes:
     #      colour pass-through backbone, calibrated BatchNorms, heads fitted to the synthetic labels of
@@ -719,6 +723,11 @@ def main():
         # one scan at a time: (a) with the result formatting of scan i overlapping scan i+1 on the
         # results thread, (b) with everything in line -- the latency of a single scan
         with torch.no_grad():
+            # (this thread's stream has not run a scan yet -- the timed region ran on the workers'
+            # streams: arenas, per-stream executor state and the copy stream are created by two
+            # untimed scans first)
+            for _ in range(2):
+                model(batch).resolve()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             rets = [model(batch) for _ in range(min(args.steps, 10))]
@@ -729,12 +738,16 @@ def main():
             del rets
         model.async_results = False
         with torch.no_grad():
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            model(batch)
+            ts = []
             for _ in range(min(args.steps, 10)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
                 model(batch)
-            torch.cuda.synchronize()
-            out['ms_per_step_unpipelined'] = round((time.perf_counter() - t1) / min(args.steps, 10) * 1e3, 3)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            out['ms_per_step_unpipelined'] = round(sum(ts) / len(ts), 3)
+            out['latency_ms_min_median_max'] = [round(min(ts), 3), round(sorted(ts)[len(ts) // 2], 3), round(max(ts), 3)]
         out['latency_ms'] = out['ms_per_step_unpipelined']        # one scan, everything in line
         out['vs_baseline'] = round(REF_MS_PER_SCAN / out['latency_ms'], 3)
         model.async_results = True
