@@ -272,7 +272,7 @@ def config_legs(args):
     for name, ctx in (('fp32', lambda: torch.autocast('cuda', enabled=False)),
                       ('bf16_autocast', lambda: torch.autocast('cuda', dtype=torch.bfloat16))):
         ts, fw = [], []
-        for it in range(7):
+        for it in range(17):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with ctx():
