@@ -1,6 +1,6 @@
 """Developer tool: kernel durations of a rocprofv3 kernel trace grouped by (kernel, grid size) --
 tells the small-level conv launches (few workgroups) from the big ones.
-Usage: python tools/conv_by_grid.py <kernel_trace.csv> <n_scans> [name substring]"""
+Usage: python tools/conv_by_grid.py <kernel_trace.csv> <n_scans|auto> [name substring]"""
 import csv
 import sys
 from collections import defaultdict
@@ -8,7 +8,10 @@ from collections import defaultdict
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    n = float(sys.argv[2])
+    if sys.argv[2] == 'auto':      # scans in the trace = launches of a once-per-scan kernel
+        n = float(sum(1 for r in rows if 'bfs_union_kernel' in r['Kernel_Name'])) or 1.0
+    else:
+        n = float(sys.argv[2])
     sub = sys.argv[3] if len(sys.argv) > 3 else 'gather_conv'
     agg = defaultdict(lambda: [0, 0.0])
     for r in rows:

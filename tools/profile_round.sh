@@ -15,12 +15,12 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # kernel trace + stats of the same command, one scan at a time (--contexts 1: kernel durations are
 # not stretched by overlapping scans, so the conv kernel's average agrees with roofline.avg_launch_us);
-# forwards in the trace: 8 warm-up + 10 timed + 10 + 10 + 5 stage + 1 + 5 roofline = 49
+# forwards in the trace: counted by the tools from a once-per-scan kernel (bfs_union_kernel)
 rm -rf /tmp/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --contexts 1 --steps 10 --warmup 8 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof.err
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv 49 60 > $OUT/${TAG}_kernel_top.txt 2>&1
-python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) 49 > $OUT/${TAG}_conv_by_grid.txt 2>&1
+python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv auto 60 > $OUT/${TAG}_kernel_top.txt 2>&1
+python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) auto > $OUT/${TAG}_conv_by_grid.txt 2>&1
 if [ -z "$QUICK" ]; then      # QUICK=1: bench line + kernel trace only
 python $R/tools/conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
 python $R/tools/train_conv_bench.py > $OUT/${TAG}_train_conv.txt 2>/dev/null < /dev/null
