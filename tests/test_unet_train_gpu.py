@@ -246,3 +246,73 @@ def test_forward_train_with_and_without_the_executor(case):
         # gradient: rounding noise on both sides, nothing to compare)
         if float(g_b[k].norm()) >= 1e-4 * big:
             _close_l2(g_a[k], g_b[k], f'gradient of {k}', 5e-2)
+
+
+def test_train_executor_lifetimes():
+    """tapes and arenas: two forwards before their backwards (each keeps its own arena), a forward
+    whose backward never runs (tape released with the graph, arena returned), and a second backward
+    through the same forward (refused: the tape is consumed)"""
+    rng = np.random.default_rng(6)
+    shape, batch = [20, 20, 20], 12
+    idx = _voxels(rng, 5000, shape, batch)
+    M = idx.shape[0]
+    torch.manual_seed(4)
+    ref = Net([32, 64]).to(DEV).train()
+    net = copy.deepcopy(ref)
+    ex = UNetTrainExecutor(net.unet, None, net.output_layer)
+    xa, xb = torch.randn(M, 32, device=DEV), torch.randn(M, 32, device=DEV)
+    ga, gb = torch.randn(M, 32, device=DEV), torch.randn(M, 32, device=DEV)
+    # reference: the same two forwards and backwards on the modules (BatchNorm statistics update twice)
+    ra = ref(spconv.SparseConvTensor(xa, idx, shape, batch))
+    rb = ref(spconv.SparseConvTensor(xb, idx, shape, batch))
+    rb.backward(gb)
+    ra.backward(ga)
+    oa = ex(spconv.SparseConvTensor(xa, idx, shape, batch))
+    ob = ex(spconv.SparseConvTensor(xb, idx, shape, batch))      # first tape still alive: a second arena
+    ob.backward(gb)
+    oa.backward(ga)
+    assert len(ex._free_arenas) == 2
+    _close(oa.detach(), ra.detach(), 'first output')
+    _close(ob.detach(), rb.detach(), 'second output')
+    for (k, pe), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+        _close_l2(pe.grad, pr.grad, f'accumulated gradient of {k}')
+    # a forward that is never differentiated
+    o = ex(spconv.SparseConvTensor(xa, idx, shape, batch))
+    del o
+    import gc
+    gc.collect()
+    assert len(ex._free_arenas) == 2
+    # the tape is single-use
+    o = ex(spconv.SparseConvTensor(xa, idx, shape, batch))
+    o.backward(ga, retain_graph=True)
+    with pytest.raises(RuntimeError, match='twice'):
+        o.backward(ga)
+
+
+def test_fp16_autocast_with_grad_scaler_steps():
+    """the reference's `fp16: True` switch (tools/train.py:47,55-62: torch.cuda.amp.autocast +
+    GradScaler): dense layers run in fp16, the sparse path stays fp32 (its kernels take fp32 or bf16),
+    the scaled loss back-propagates through the native executor, the scaler unscales and steps"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_train_gpu import _train_case
+    model, batch, ref, seed = _train_case('s3dis_fold5')
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    scaler = torch.amp.GradScaler('cuda')
+    torch.manual_seed(seed)
+    with torch.autocast('cuda', dtype=torch.float16):
+        loss, log_vars = model(batch, return_loss=True)
+    assert model.__dict__.get('_tiny_train_exec') is not None
+    opt.zero_grad()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    assert np.isfinite(float(loss)) and abs(log_vars['loss'] - ref['loss']) <= 2e-2 * abs(ref['loss'])
+    assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
+    assert scaler.get_scale() >= 1.0
+    moved = sum(float((p.detach() - b).abs().sum()) for p, b in zip(params, before))
+    assert moved > 0, 'the optimizer step was skipped (non-finite gradients)'
