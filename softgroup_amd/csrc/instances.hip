@@ -24,30 +24,63 @@
 
 namespace sg {
 
-// grid = (pair chunks, classes); pairs of one proposal are consecutive, so a wave's lanes form a
-// few runs of equal proposal id: the head lane of each run adds the run's popcount
+// Every wave walks a CONTIGUOUS range of the (proposal, point) pairs, 64 at a time; pairs of one
+// proposal are consecutive, so a chunk is usually one proposal: its per-class counts (popcount of
+// the wave's ballot) are kept by lane = class and flushed with one atomic per class when the
+// proposal changes -- a 149 k-point proposal costs nc atomics per wave instead of nc per 64 points
+// (all of them on the same nc words).  A chunk that holds a boundary falls back to one atomic per
+// run.  Every lane reads ITS pair's row of class scores once.
 __global__ void __launch_bounds__(256) instance_npoint_kernel(const int32_t *__restrict__ pairs,
                                                              const float *__restrict__ mask_scores,
                                                              int64_t S, int stride, float thr, int nc,
                                                              int32_t *__restrict__ npoint) {
-  const int i = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  for (int64_t e0 = (blockIdx.x * 256LL + threadIdx.x) - lane; e0 < S; e0 += gridDim.x * 256LL) {
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * 4;
+  const int64_t per = (((S + n_waves - 1) / n_waves) + 63) & ~63LL;
+  const int64_t begin = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * per;
+  const int64_t end = begin + per < S ? begin + per : S;
+  int cur = -1, acc = 0;      // lane i < nc: points of proposal `cur` above the threshold in class i
+  auto flush = [&]() {
+    if (cur >= 0 && lane < nc && acc) atomicAdd(&npoint[static_cast<int64_t>(cur) * nc + lane], acc);
+    acc = 0;
+  };
+  for (int64_t e0 = begin; e0 < end; e0 += 64) {
     const int64_t e = e0 + lane;
-    const bool valid = e < S;
+    const bool valid = e < end;
     const int p = valid ? pairs[2 * e] : -1;
-    const bool on = valid && mask_scores[e * stride + i] > thr;
+    const int p0 = __shfl(p, 0, 64);
+    const float *row = mask_scores + (valid ? e : 0) * stride;
+    if (nc <= 64 && __ballot(valid && p != p0) == 0ull) {          // one proposal in this chunk
+      if (p0 != cur) {
+        flush();
+        cur = p0;
+      }
+      for (int i = 0; i < nc; ++i) {
+        const int cnt = __popcll(__ballot(valid && row[i] > thr));
+        if (lane == i) acc += cnt;
+      }
+      continue;
+    }
+    flush();
+    cur = -1;
     const int p_prev = __shfl_up(p, 1, 64);
     const bool head = valid && (lane == 0 || p != p_prev);
-    const uint64_t heads = __ballot(head), ons = __ballot(on);
+    const uint64_t heads = __ballot(head);
+    uint64_t span = 0;
     if (head) {
       const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-      const int end = above ? __ffsll(static_cast<long long>(above)) - 1 : 64;
-      const uint64_t span = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
-      const int cnt = __popcll(ons & span);
-      if (cnt) atomicAdd(&npoint[static_cast<int64_t>(p) * nc + i], cnt);
+      const int stop = above ? __ffsll(static_cast<long long>(above)) - 1 : 64;
+      span = (stop == 64 ? ~0ull : ((1ull << stop) - 1ull)) & ~((1ull << lane) - 1ull);
+    }
+    for (int i = 0; i < nc; ++i) {
+      const uint64_t ons = __ballot(valid && row[i] > thr);
+      if (head) {
+        const int cnt = __popcll(ons & span);
+        if (cnt) atomicAdd(&npoint[static_cast<int64_t>(p) * nc + i], cnt);
+      }
     }
   }
+  flush();
 }
 
 __global__ void __launch_bounds__(256) instance_bitmap_kernel(const int32_t *__restrict__ pairs,
@@ -56,13 +89,15 @@ __global__ void __launch_bounds__(256) instance_bitmap_kernel(const int32_t *__r
                                                              const int32_t *__restrict__ inst_of,
                                                              int n_prop, int words,
                                                              uint32_t *__restrict__ bits) {
-  const int i = blockIdx.y;
   for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < S; e += gridDim.x * 256LL) {
-    if (!(mask_scores[e * stride + i] > thr)) continue;
     const int2 pq = reinterpret_cast<const int2 *>(pairs)[e];
-    const int k = inst_of[static_cast<int64_t>(i) * n_prop + pq.x];
-    if (k < 0) continue;
-    atomicOr(&bits[static_cast<int64_t>(k) * words + (pq.y >> 5)], 1u << (pq.y & 31));
+    const float *row = mask_scores + e * stride;      // (the pair's class scores: read once, not per class)
+    for (int i = 0; i < nc; ++i) {
+      if (!(row[i] > thr)) continue;
+      const int k = inst_of[static_cast<int64_t>(i) * n_prop + pq.x];
+      if (k < 0) continue;
+      atomicOr(&bits[static_cast<int64_t>(k) * words + (pq.y >> 5)], 1u << (pq.y & 31));
+    }
   }
 }
 
@@ -302,7 +337,7 @@ int sg_instance_npoint(const int32_t *proposals_idx, const float *mask_scores, i
   hipStream_t stream = as_stream(stream_);
   hipMemsetAsync(npoint, 0, static_cast<size_t>(n_prop) * n_classes * 4, stream);
   if (S == 0 || n_prop == 0) return check_launch("sg_instance_npoint");
-  dim3 grid(grid_for(S, 256, 1024), n_classes);
+  const int grid = grid_for((S + 1023) / 1024, 4, 1024);      // >= 1024 pairs per wave
   instance_npoint_kernel<<<grid, 256, 0, stream>>>(proposals_idx, mask_scores, S, stride, mask_thr,
                                                   n_classes, npoint);
   return check_launch("sg_instance_npoint");
@@ -338,7 +373,7 @@ int sg_instance_runs(const int32_t *proposals_idx, const float *mask_scores, int
   int32_t *total = a.take<int32_t>(64);
   hipMemsetAsync(bits, 0, static_cast<size_t>(tw) * 4, stream);
   if (S > 0 && n_prop > 0) {
-    dim3 grid(grid_for(S, 256, 1024), n_classes);
+    const int grid = grid_for(S, 256, 4096);
     instance_bitmap_kernel<<<grid, 256, 0, stream>>>(proposals_idx, mask_scores, S, stride, mask_thr,
                                                     n_classes, inst_of, n_prop, words, bits);
   }

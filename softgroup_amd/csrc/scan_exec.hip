@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(256) proposal_box_kernel(const int32_t *__rest
   for (int p = blockIdx.x; p < n_prop; p += gridDim.x) {
     const int s = offsets[p], e = offsets[p + 1];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = s + threadIdx.x; i < e; i += 256) {
+#pragma unroll 4
+    for (int i = s + threadIdx.x; i < e; i += 256) {      // (a giant proposal: 200+ trips of two dependent loads)
       const int pt = pairs[2LL * i + 1];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -245,8 +246,22 @@ __global__ void __launch_bounds__(256) proposal_voxel_feats_kernel(const float *
     const int32_t *r = rules + static_cast<int64_t>(row) * (max_active + 1);
     const int cnt = r[0];
     const float m = cnt > 0 ? __fdiv_rn(1.0f, static_cast<float>(cnt)) : 1.0f;
+    // (rule -> pair -> feature row is three dependent loads per point: four points' chains are in
+    //  flight at a time, the sum keeps the reference's order)
     float acc = 0.0f;
-    for (int i = 1; i <= cnt; ++i)
+    int i = 1;
+    for (; i + 3 <= cnt; i += 4) {
+      const int a0 = r[i], a1 = r[i + 1], a2 = r[i + 2], a3 = r[i + 3];
+      const int p0 = pairs[2LL * a0 + 1], p1 = pairs[2LL * a1 + 1], p2 = pairs[2LL * a2 + 1],
+                p3 = pairs[2LL * a3 + 1];
+      const float f0 = feats[static_cast<int64_t>(p0) * C + c], f1 = feats[static_cast<int64_t>(p1) * C + c],
+                  f2 = feats[static_cast<int64_t>(p2) * C + c], f3 = feats[static_cast<int64_t>(p3) * C + c];
+      acc = __fadd_rn(acc, __fmul_rn(m, f0));
+      acc = __fadd_rn(acc, __fmul_rn(m, f1));
+      acc = __fadd_rn(acc, __fmul_rn(m, f2));
+      acc = __fadd_rn(acc, __fmul_rn(m, f3));
+    }
+    for (; i <= cnt; ++i)
       acc = __fadd_rn(acc, __fmul_rn(m, feats[static_cast<int64_t>(pairs[2LL * r[i] + 1]) * C + c]));
     out[t] = acc;
   }

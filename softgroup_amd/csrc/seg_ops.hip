@@ -26,8 +26,19 @@ __global__ void __launch_bounds__(256) voxelize_fp_kernel(const float *__restric
     const int32_t *r = rules + static_cast<int64_t>(row) * (max_active + 1);
     const int cnt = r[0];
     const float m = (average && cnt > 0) ? __fdiv_rn(1.0f, static_cast<float>(cnt)) : 1.0f;
+    // (rule -> feature row are dependent loads: four points' chains in flight, the sum in order)
     float acc = 0.0f;
-    for (int i = 1; i <= cnt; ++i)
+    int i = 1;
+    for (; i + 3 <= cnt; i += 4) {
+      const int a0 = r[i], a1 = r[i + 1], a2 = r[i + 2], a3 = r[i + 3];
+      const float f0 = feats[static_cast<int64_t>(a0) * C + p], f1 = feats[static_cast<int64_t>(a1) * C + p],
+                  f2 = feats[static_cast<int64_t>(a2) * C + p], f3 = feats[static_cast<int64_t>(a3) * C + p];
+      acc = __fadd_rn(acc, __fmul_rn(m, f0));
+      acc = __fadd_rn(acc, __fmul_rn(m, f1));
+      acc = __fadd_rn(acc, __fmul_rn(m, f2));
+      acc = __fadd_rn(acc, __fmul_rn(m, f3));
+    }
+    for (; i <= cnt; ++i)
       acc = __fadd_rn(acc, __fmul_rn(m, feats[static_cast<int64_t>(r[i]) * C + p]));
     out[t] = acc;
   }
@@ -100,7 +111,8 @@ __global__ void __launch_bounds__(256) seg_minmax_kernel(const float *__restrict
       float v = init;
       if (threadIdx.x < rows_per_iter * cw) {
         const int c = c0 + threadIdx.x % cw;
-        for (int i = s + threadIdx.x / cw; i < e; i += rows_per_iter) {
+#pragma unroll 8
+        for (int i = s + threadIdx.x / cw; i < e; i += rows_per_iter) {      // (a giant segment: ~2 k trips)
           float x = inp[static_cast<int64_t>(i) * C + c];
           // strict compare keeps the reference's NaN behaviour (NaN never replaces the running value)
           if (IS_MAX ? (x > v) : (x < v)) v = x;
