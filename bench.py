@@ -221,13 +221,15 @@ def config_legs(args):
     fmodel.async_results = False
     with torch.no_grad():
         res = [fmodel(b) for b in eval_batches]        # held-out scenes
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        fts = []
         for _ in range(3):
             for b in eval_batches:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 fmodel(b)
-        torch.cuda.synchronize()
-        fitted_ms = (time.perf_counter() - t0) / (3 * len(eval_batches)) * 1e3
+                torch.cuda.synchronize()
+                fts.append((time.perf_counter() - t0) * 1e3)
+        fitted_ms = sorted(fts)[len(fts) // 2]
         fstages, finfo = stage_times(fmodel, eval_batches[0], reps=5)
     classes = ['c%d' % i for i in range(18)]
     avgs = ScanNetEval(classes).evaluate([r['pred_instances'] for r in res], [r['gt_instances'] for r in res],
@@ -409,15 +411,19 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
     with torch.no_grad():
         for _ in range(2):
             model(dbatch)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        ts = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             model(dbatch)
-        torch.cuda.synchronize()
-        dense_ms = (time.perf_counter() - t0) / 5 * 1e3
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        dense_ms = ts[len(ts) // 2]          # median, like the config legs
         dstages, dinfo = stage_times(model, dbatch, reps=5)
     model.async_results = True
-    legs['dense_scene'] = {'ms_per_scan_unpipelined': round(dense_ms, 3), 'stages_ms': dstages,
+    legs['dense_scene'] = {'ms_per_scan_unpipelined': round(dense_ms, 3),
+                           'ms_per_scan_min_max': [round(ts[0], 3), round(ts[-1], 3)], 'stages_ms': dstages,
                            'scene': dinfo}
 
     # ---- host-to-device inclusive rate of the bench scan: raw points arrive in pinned host memory,
