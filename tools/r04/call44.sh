@@ -2,8 +2,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu > $OUT/r04_c44_full.txt 2>&1
-grep -E "passed|failed" $OUT/r04_c44_full.txt | tail -2 > $OUT/r04_c44_tests.txt
+
+
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/r04_bench.json 2> $OUT/r04_bench.err
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r04_bench_driver_shape.json 2> $OUT/r04_bench_driver_shape.err
