@@ -97,14 +97,14 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // Several buffers filled by ONE launch (each hipMemsetAsync is a graph node of its own: ~5 us of GPU
 // time and a launch gap; an index build used to issue ten of them).  Regions are 4-byte aligned, sizes
 // multiples of 4; `byte` is replicated like memset's value.
-constexpr int kFillMax = 12;
+constexpr int kFillMax = 16;
 struct FillList {
   uint32_t *p[kFillMax];
   size_t words[kFillMax];
   uint32_t pattern[kFillMax];
   int n = 0;
   void add(void *ptr, size_t bytes, int byte) {
-    if (bytes == 0 || ptr == nullptr) return;
+    if (bytes == 0 || ptr == nullptr || n >= kFillMax) return;      // (callers static_assert their region count)
     p[n] = static_cast<uint32_t *>(ptr);
     words[n] = bytes / 4;
     pattern[n] = 0x01010101u * static_cast<uint32_t>(byte & 0xff);

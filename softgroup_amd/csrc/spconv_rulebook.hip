@@ -844,6 +844,7 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
     return SG_ERR_WORKSPACE;
   }
   {      // one launch: the strided tables' "no child" marks and the offset histogram of the plans
+    static_assert(kPyrMaxLevels + 1 <= kFillMax, "one fill region per level + the histogram");
     FillList f;
     for (int l = 0; l + 1 < L; ++l)
       if (levels[l + 1].rows > 0) f.add(levels[l].child, static_cast<size_t>(levels[l + 1].rows) * 8 * 4, 0xff);

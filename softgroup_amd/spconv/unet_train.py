@@ -59,12 +59,15 @@ class _Tape:
         self.keep = None
 
     def __del__(self):
-        if self.handle is not None:
-            L.lib().sg_unet_train_release(C.c_void_p(self.handle))
-            self.handle = None
-        if self.arena is not None and self.owner is not None:
-            self.owner._free_arenas.append(self.arena)
-            self.arena = None
+        try:
+            if self.handle is not None:
+                L.lib().sg_unet_train_release(C.c_void_p(self.handle))
+                self.handle = None
+            if self.arena is not None and self.owner is not None:
+                self.owner._free_arenas.append(self.arena)
+                self.arena = None
+        except Exception:       # interpreter shutdown: the library or the owner may be gone already
+            pass
 
 
 class UNetTrainExecutor:
