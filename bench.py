@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=160)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--points', type=int, default=150000)
+    ap.add_argument('--scenes', type=int, default=4,
+                    help='distinct pre-built scenes the timed region cycles through')
     ap.add_argument('--contexts', type=int, default=0,
                     help='scans in flight in the timed region; 0 = 3 for regions of up to 40 steps, 5 beyond '
                          '(a short region is one pipeline fill and one drain, which cost more with more scans '
@@ -660,10 +662,20 @@ def main():
     from softgroup_amd.spconv import core as spcore
     assert os.path.exists(_lib.LIB_PATH), 'libsoftgroup_hip.so missing: run __graft_entry__.build()'
 
-    # one scene per rank (different seed per rank), weights identical on all ranks
-    xyz, rgb, inst = synthetic.scene_s2(seed=1 + rank, n=args.points)
-    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst, scan_id=f'synthetic_{rank:04d}')
-    batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    # every rank gets its own scenes (different seeds per rank), weights identical on all ranks.  The
+    # timed region cycles through `--scenes` DISTINCT pre-built scenes resident in HBM, as a dataloader
+    # would hand them over (reference loop: tools/test.py:145-150); scene 0 is also the scene of the
+    # cpu_baseline / parity_at_bench legs
+    from softgroup_amd.util.digest import result_digest
+    n_scenes = max(1, args.scenes)
+    batches = []
+    for i in range(n_scenes):
+        xyz_i, rgb_i, inst_i = synthetic.scene_s2(seed=1 + rank + 97 * i, n=args.points)
+        if i == 0:
+            xyz, rgb, inst = xyz_i, rgb_i, inst_i
+        b = synthetic.make_batch(xyz_i, rgb_i, instance_labels=inst_i, scan_id=f'synthetic_{rank:04d}_{i}')
+        batches.append({k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    batch = batches[0]
     model = synthetic.build_model(seed=0)
 
     def sync_all():
@@ -676,16 +688,34 @@ def main():
     # objects (numpy arrays, RLE mask strings) runs on the model's results thread and overlaps the
     # next scan.  Every one of the K result dicts is fully materialised inside the timed region.
     contexts, host_threads = host_thread_plan(max(1, args.contexts), world)
-    model.scan_contexts = contexts
     with torch.no_grad():
-        for r in [model(batch) for _ in range(max(args.warmup, 1))]:
+        # what every scene returns when it runs ALONE (one scan at a time, the reference's loop): the
+        # digest covers semantic_preds, offset_preds and every instance's label / confidence / RLE string
+        model.scan_contexts = 1
+        alone = []
+        for b in batches:
+            r = dict(model(b))
+            assert len(r['semantic_preds']) == args.points and 'pred_instances' in r
+            alone.append(result_digest(r))
+            del r
+        model.scan_contexts = contexts
+        for r in [model(batches[i % n_scenes]) for i in range(max(args.warmup, 1))]:
             r.resolve()
-        def consume(r):
-            r.resolve()
-            return 'pred_instances' in r and 'semantic_preds' in r and len(r['semantic_preds']) == args.points
+        issued = iter(range(args.steps))
+        checked = iter(range(args.steps))
 
-        elapsed, rets, windows = timed_steps(lambda: model(batch), consume, args.steps, sync_all)
-    assert all(rets) and len(rets) == args.steps
+        def step():
+            return model(batches[next(issued) % n_scenes])
+
+        def consume(r):
+            # (inside the timed region) the result is fully materialised and compared with the scene's
+            # one-at-a-time digest: a scan in flight next to others must return the same bits
+            r.resolve()
+            return result_digest(r) == alone[next(checked) % n_scenes]
+
+        elapsed, rets, windows = timed_steps(step, consume, args.steps, sync_all)
+    identical = all(rets) and len(rets) == args.steps
+    assert identical, f'results of the timed region differ from the one-at-a-time results: {rets}'
     del rets
     if dist_on:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
@@ -719,6 +749,9 @@ def main():
                           'in parity_at_bench; SG_CONV_SPLIT=0 selects the fp32-MFMA kernel',
         },
         'ranks_seen': world, 'devices': devices, 'host_threads': host_threads,
+        # every result of the timed region was compared (inside the region) with the digest of the same
+        # scene run one scan at a time: semantic_preds, offset_preds, all instances' label/conf/RLE
+        'timed_results_identical': bool(identical), 'distinct_scenes_in_timed_region': n_scenes,
         # ms/scan of each third of the timed region on rank 0, and their median
         'ms_per_step_windows': [round(w, 3) for w in windows],
         'ms_per_step_window_median': round(sorted(windows)[len(windows) // 2], 3) if windows else None,
@@ -863,7 +896,7 @@ def main():
         # one oracle forward of the SAME scene: timed as the CPU baseline, and its outputs are the
         # full-size parity check of the GPU path (stage-wise: floats <= 1e-4, proposals / instance
         # labels / RLE strings identical; end to end: instance drift)
-        rep = parity.parity_report(model, cpu_batch, synthetic.SCANNET_MODEL_CFG)
+        rep = parity.parity_report(model, cpu_batch, synthetic.SCANNET_MODEL_CFG, timed_path=True)
         cpu_s = rep.pop('oracle_forward_s')
         out['parity_at_bench'] = rep
         ref_ops = reference_cpu_ops_leg(model, batch)

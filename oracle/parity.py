@@ -76,10 +76,17 @@ def _mean_best_iou(got, ref):
     return tot / len(ref)
 
 
-def parity_report(model, batch, cfg, end_to_end=True):
-    """-> dict of parity figures for one scene (all python scalars / bools, JSON-ready)."""
+def parity_report(model, batch, cfg, end_to_end=True, timed_path=False):
+    """-> dict of parity figures for one scene (all python scalars / bools, JSON-ready).
+    ``timed_path``: additionally run ``model(batch)`` -- the call bench.py times: native scan driver +
+    U-Net executor -- and compare ITS results (not only the operator path's) with the oracle."""
     n = lambda t: t.detach().cpu().numpy()  # noqa: E731
     g = gpu_stages(model, batch)
+    native = None
+    if timed_path:
+        with torch.no_grad():
+            b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            native = dict(model(b))
     ora = OracleSoftGroup(model.state_dict(), cfg)
     rep = {'points': int(batch['coords_float'].shape[0]), 'tolerance': ATOL}
 
@@ -123,6 +130,8 @@ def parity_report(model, batch, cfg, end_to_end=True):
                                 n(g['mask']))
         rep['instances'] = len(ref)
         rep['instances_equal'] = _instances_equal(g['preds'], ref)
+        if native is not None:
+            rep['timed_path_instances_equal_oracle'] = _instances_equal(native['pred_instances'], ref)
     rep['float_stages_within_tol'] = bool(ok_f and ok_s and ok_o and ok_v and ok_h)
 
     # end-to-end drift of a pure GPU run against a pure oracle run
@@ -133,4 +142,21 @@ def parity_report(model, batch, cfg, end_to_end=True):
         rep['e2e_instances_oracle'] = len(e2e['pred_instances'])
         rep['e2e_mean_best_mask_iou'] = round(_mean_best_iou(g['preds'], e2e['pred_instances']), 6)
     rep['ok'] = bool(rep['float_stages_within_tol'] and rep['proposals_equal'] and rep['instances_equal'])
+    if native is not None:
+        # the timed call against (a) the operator path it is claimed equal to, (b) the oracle
+        rep['checked_call'] = 'model(batch): native scan driver + U-Net executor (the timed region\'s call)'
+        rep['timed_path_instances_equal_operator_path'] = bool(
+            len(native['pred_instances']) == len(g['preds']) and
+            all(a['label_id'] == c['label_id'] and a['conf'] == c['conf'] and a['pred_mask'] == c['pred_mask']
+                for a, c in zip(native['pred_instances'], g['preds'])))
+        rep['timed_path_semantic_preds_equal_operator_path'] = bool(
+            np.array_equal(native['semantic_preds'], n(g['sem']).argmax(1)))
+        ok_no, rep['timed_path_max_abs_offsets_vs_oracle'] = _close(native['offset_preds'], off)
+        rep['timed_path_semantic_preds_vs_oracle_mismatches'] = int(
+            np.count_nonzero(native['semantic_preds'] != np.asarray(sem).argmax(1)))
+        if e2e is not None:
+            rep['timed_path_e2e_instances_equal_oracle'] = _instances_equal(native['pred_instances'],
+                                                                             e2e['pred_instances'])
+        rep['ok'] = bool(rep['ok'] and ok_no and rep['timed_path_instances_equal_operator_path'] and
+                         rep.get('timed_path_instances_equal_oracle', True))
     return rep

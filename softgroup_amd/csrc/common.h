@@ -139,5 +139,8 @@ inline void fill_many(const FillList &f, hipStream_t stream) {
 
 // conv arithmetic requested by the calling thread (spconv_conv.hip); -1 = none
 extern thread_local int t_conv_arith;
+// per-(device, stream) runtime state of the conv launches / the executors' index builds (sg_stream_release)
+void conv_release_stream(int dev, hipStream_t stream);
+void unet_release_stream(int dev, hipStream_t stream);
 
 }  // namespace sg

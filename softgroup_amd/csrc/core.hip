@@ -70,6 +70,17 @@ int sg_device_info(char *name_host, int name_cap, int *num_cu_host, int *clock_k
   return SG_OK;
 }
 
+int sg_stream_release(sg_stream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    sg::set_error("sg_stream_release: no HIP device");
+    return SG_ERR_LAUNCH;
+  }
+  sg::conv_release_stream(dev, sg::as_stream(stream));
+  sg::unet_release_stream(dev, sg::as_stream(stream));
+  return SG_OK;
+}
+
 size_t sg_scan_workspace_bytes(int n) { return sg::scan_workspace_bytes(n); }
 
 // start_len[i,0] = exclusive prefix of start_len[:,1]

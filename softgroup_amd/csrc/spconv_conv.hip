@@ -1138,6 +1138,21 @@ static unsigned *take_done(hipStream_t stream, size_t count) {
   return r;
 }
 
+// sg_stream_release: the caller's stream is idle and about to be destroyed
+void conv_release_stream(int dev, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_ticket_mu);
+  auto d = g_done_pools.find({dev, stream});
+  if (d != g_done_pools.end()) {
+    if (d->second.dev) hipFree(d->second.dev);
+    g_done_pools.erase(d);
+  }
+  auto t = g_ticket_pools.find({dev, stream});
+  if (t != g_ticket_pools.end()) {
+    if (t->second.dev) hipFree(t->second.dev);
+    g_ticket_pools.erase(t);
+  }
+}
+
 static unsigned *take_tickets(hipStream_t stream) {
   int dev = 0;
   hipGetDevice(&dev);
@@ -1220,7 +1235,12 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   static const int at_env = getenv("SG_CONV_AT") ? atoi(getenv("SG_CONV_AT")) : 1;             // line-wise gather
   const int NB = (a.Cout + 31) / 32;
   // (the line-wise gather forms its addresses with a 24-bit multiply: input rows < 2^24 - 1)
-  const int use_at = (at_env != 0 && a.Cin % 32 == 0 && in_bytes / (4LL * a.Cin) < (1LL << 24) - 1) ? 1 : 0;
+  // and an absent neighbour (-1 -> 0xffffff * row pitch, wrapped to 32 bits) must land past the end
+  // of the buffer: row pitches that are not multiples of 256 B (Cin = 96, 160, 224) wrap to just
+  // below 2^31, which is inside an input of a few million rows -- those take the fragment-shaped gather
+  const unsigned absent_at = static_cast<unsigned>((0xFFFFFFull * (4ull * a.Cin)) & 0xFFFFFFFFull);
+  const int use_at = (at_env != 0 && a.Cin % 32 == 0 && in_bytes / (4LL * a.Cin) < (1LL << 24) - 1 &&
+                      static_cast<long long>(absent_at) >= in_bytes) ? 1 : 0;
   int pick = -1;
   // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
   // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units

@@ -69,29 +69,54 @@ __global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s) {
     s.mask[l][i] = i < tiles ? 1u : (i == tiles + 1 ? static_cast<uint32_t>(tiles) : 0u);
 }
 
+// ---- runtime state per (device, caller's stream): callers that run scans concurrently on
+//      several streams (one host thread each) get an index stream of their own and never wait for
+//      each other; calls on the same stream are serialised by the state's mutex
+struct StreamState {
+  std::mutex mu;
+  int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
+  int32_t *dev_rows = nullptr;      // device
+  hipStream_t istream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_index = nullptr;
+  bool ready = false;
+};
+static std::mutex table_mu;
+static std::map<std::pair<int, hipStream_t>, StreamState *> table;
+
+// sg_stream_release: the caller's stream is idle and about to be destroyed
+void unet_release_stream(int dev, hipStream_t stream) {
+  StreamState *st = nullptr;
+  {
+    std::lock_guard<std::mutex> g(table_mu);
+    auto it = table.find(std::make_pair(dev, stream));
+    if (it == table.end()) return;
+    st = it->second;
+    table.erase(it);
+  }
+  {
+    std::lock_guard<std::mutex> g(st->mu);      // (no forward of that stream is inside the build)
+    if (st->ready) {
+      hipStreamSynchronize(st->istream);
+      hipStreamDestroy(st->istream);
+      hipEventDestroy(st->ev_start);
+      hipEventDestroy(st->ev_index);
+      hipHostFree(st->host_rows);
+      hipFree(st->dev_rows);
+    }
+  }
+  delete st;
+}
+
 int unet_build_index(const char *who, int L, const int32_t *indices, int num_rows,
                      const int32_t *spatial_shape_host, void *arena, size_t arena_bytes, sg_stream_t stream,
                      LevelIdx *li, size_t *used, std::unique_lock<std::mutex> *lock) {
-  // ---- runtime state per (device, caller's stream): callers that run scans concurrently on
-  //      several streams (one host thread each) get an index stream of their own and never wait for
-  //      each other; calls on the same stream are serialised by the state's mutex
-  struct StreamState {
-    std::mutex mu;
-    int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
-    int32_t *dev_rows = nullptr;      // device
-    hipStream_t istream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_index = nullptr;
-    bool ready = false;
-  };
-  static std::mutex table_mu;
-  static std::map<std::pair<int, hipStream_t>, StreamState *> table;
   int dev = 0;
   SG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, "%s: no current device", who);
   StreamState *stp = nullptr;
   {
     std::lock_guard<std::mutex> g(table_mu);
     StreamState *&slot = table[std::make_pair(dev, as_stream(stream))];
-    if (slot == nullptr) slot = new StreamState();     // lives as long as the process
+    if (slot == nullptr) slot = new StreamState();     // until sg_stream_release (else: the process)
     stp = slot;
   }
   StreamState &st = *stp;

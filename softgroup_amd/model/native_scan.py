@@ -55,6 +55,12 @@ def _arena(tag, nbytes, device):
     return t
 
 
+def release_stream(raw_stream):
+    """drop the arenas of a stream that is being retired (its scans have finished)"""
+    for key in [k for k in _arenas if k[2] == raw_stream]:
+        del _arenas[key]
+
+
 def _view(arena, off, dtype, *shape):
     n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     return arena[off:off + n].view(dtype).view(*shape)

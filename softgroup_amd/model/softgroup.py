@@ -38,6 +38,28 @@ _EARLY_COPY = os.environ.get('SG_EARLY_COPY', '1') != '0'      # (developer A/B 
 _POOL_LOCK = threading.Lock()        # creation / retirement of a model's scan pool
 
 
+def _retire_pool(pool, wait=True):
+    """shut a scan pool down and give back what its worker streams held: this module's and the
+    executor's per-stream arenas (>= 130 MB per worker) and the library's per-stream runtime state
+    (sg_stream_release).  wait=False -- called from one of the pool's own threads -- only stops the
+    pool: its streams may still be running that very scan, their state stays until the process ends."""
+    pool.shutdown(wait=wait)
+    if not wait:
+        return
+    from . import native_scan as NS
+    from ..spconv import unet_exec as UE
+    from .. import _lib as L
+    for dev, st in getattr(pool, '_sg_streams', ()):
+        with torch.cuda.device(dev):
+            st.synchronize()
+            raw = st.cuda_stream
+            NS.release_stream(raw)
+            UE.release_stream(raw)
+            L.check(L.lib().sg_stream_release(raw), 'sg_stream_release')
+    pool._sg_streams = []
+
+
+
 def _cfg(cfg, key, default=None):
     """config sections arrive as Munch / dict / namespace depending on the caller"""
     if cfg is None:
@@ -151,7 +173,7 @@ class SoftGroup(nn.Module):
             pool = self.__dict__.pop('_scan_pool', None)
         if pool is not None:
             own = threading.current_thread() in getattr(pool, '_threads', ())
-            pool.shutdown(wait=not own)
+            _retire_pool(pool, wait=not own)
         spconv.invalidate_caches()
         for k in self._DERIVED:
             self.__dict__.pop(k, None)
@@ -199,6 +221,7 @@ class SoftGroup(nn.Module):
                 st = getattr(local, 'stream', None)
                 if st is None:
                     st = local.stream = torch.cuda.Stream()
+                    my_pool._sg_streams.append((dev, st))      # released when the pool is retired
                 with torch.cuda.stream(st), torch.no_grad():
                     st.wait_event(ready)
                     out = self.forward_test(**batch, _inline_results=True)
@@ -209,8 +232,13 @@ class SoftGroup(nn.Module):
             pool = self.__dict__.get('_scan_pool')
             if pool is None or pool._max_workers != self.scan_contexts:
                 from concurrent.futures import ThreadPoolExecutor
+                old = pool
                 pool = self.__dict__['_scan_pool'] = ThreadPoolExecutor(
                     max_workers=self.scan_contexts, thread_name_prefix='softgroup-scan')
+                pool._sg_streams = []
+                if old is not None:      # scan_contexts changed: the old workers finish their scans and go
+                    threading.Thread(target=_retire_pool, args=(old, True), daemon=True).start()
+            my_pool = pool
             fut = pool.submit(job)       # (under the lock: the pool cannot be retired in between)
         ret = LazyResults(scan_id=batch['scan_ids'][0])
         ret.defer(fut)
@@ -885,8 +913,10 @@ class SoftGroup(nn.Module):
         if not self.semantic_only:
             with torch.no_grad():
                 g = self.grouping_cfg
+                n_seg = self.semantic_classes - len(set(_cfg(g, 'ignore_classes')))
+                # (same bound as _native_scan_usable: the driver holds at most 32 grouped classes)
                 if (self.use_native_scan and semantic_scores.is_cuda and not _cfg(g, 'with_pyramid', False)
-                        and not _cfg(g, 'with_octree', False)):
+                        and not _cfg(g, 'with_octree', False) and 0 < n_seg <= 32):
                     proposals_idx, proposals_offset = self._native_proposals(
                         semantic_scores.detach(), pt_offsets.detach(), batch_idxs, coords_float, batch_size)
                 else:

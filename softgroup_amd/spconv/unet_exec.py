@@ -50,6 +50,12 @@ def _get_arena(nbytes, device):
     return t
 
 
+def release_stream(raw_stream):
+    """drop the arena of a stream that is being retired (its forwards have finished)"""
+    for key in [k for k in _arena if k[1] == raw_stream]:
+        del _arena[key]
+
+
 class UNetExecutor:
     """descriptor + cached device tensors for one (input_conv, unet, output_layer) triple"""
 

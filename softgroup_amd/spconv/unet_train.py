@@ -140,6 +140,10 @@ class UNetTrainExecutor:
         module path"""
         if not (feats.is_cuda and feats.dtype == torch.float32 and torch.is_grad_enabled()):
             return False
+        if feats.shape[0] < 2:
+            # a single row: torch.nn.BatchNorm1d in train() mode raises ("Expected more than 1 value
+            # per channel"); the module path does, so it is the path that must see this input
+            return False
         ok = self.__dict__.get('_ok')
         if ok is None:
             try:

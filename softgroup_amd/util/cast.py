@@ -4,8 +4,12 @@
 only knows torch.half)."""
 import functools
 import inspect
+import os
+import threading
+import weakref
 from collections import abc
 
+import numpy as np
 import torch
 
 from ..spconv import SparseConvTensor
@@ -62,6 +66,9 @@ def force_fp32(apply_to=None):
 
 
 _PAD = {}
+_NP_DTYPE = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16,
+             torch.int64: np.int64, torch.int32: np.int32, torch.int16: np.int16, torch.int8: np.int8,
+             torch.uint8: np.uint8, torch.bool: np.bool_}
 
 
 def _pad_block(dev):
@@ -111,12 +118,44 @@ def to_host_begin(tensors, stream=None):
     return list(tensors), out, plan, stage, done, (packed if plan else None)
 
 
+# Page-locked staging blocks still referenced by result arrays.  A consumer that releases each scan's
+# results before long (a pipelined evaluation, bench.py) gets zero-copy views of the pinned block; a
+# loop that ACCUMULATES results (the reference's tools/test.py keeps every scan's arrays until the
+# evaluation) would otherwise hold one ~12 MB block -- 16 MB after the host allocator's power-of-two
+# rounding -- page-locked per scan: past `_PINNED_CAP` bytes of live blocks a scan's arrays are copied
+# out to ordinary pageable memory (one memcpy) and its block goes back to the allocator at once.
+_PINNED_CAP = int(os.environ.get('SG_PINNED_RESULTS_MB', '256')) << 20
+_pinned_lock = threading.Lock()
+_pinned_live = [0]
+
+
+def pinned_result_bytes():
+    """bytes of pinned staging blocks currently kept alive by result arrays (tests, diagnostics)"""
+    with _pinned_lock:
+        return _pinned_live[0]
+
+
+def _unpin(nbytes):
+    with _pinned_lock:
+        _pinned_live[0] -= nbytes
+
+
 def to_host_end(handle):
     keys, out, plan, stage, done, _packed = handle
     if plan:
         done.synchronize()
+        nbytes = stage.numel()
+        with _pinned_lock:
+            keep_pinned = _pinned_live[0] + nbytes <= _PINNED_CAP
+            if keep_pinned:
+                _pinned_live[0] += nbytes
+        block = stage.numpy()           # every result array is a view of `block` (numpy keeps it as their base)
+        if keep_pinned:
+            weakref.finalize(block, _unpin, nbytes)
+        else:
+            block = block.copy()        # pageable; the pinned block is released when `stage` goes
         for k, t, off, nb in plan:
-            out[k] = stage[off:off + nb].view(t.dtype).view(t.shape).numpy()
+            out[k] = block[off:off + nb].view(_NP_DTYPE[t.dtype]).reshape(tuple(t.shape))
     return {k: out[k] for k in keys}
 
 
@@ -126,6 +165,7 @@ def to_host(tensors):
     allocator recycles it; every copy node costs ~10 us of blit set-up whatever its size, and a scan
     returns eight dense arrays), with a single wait -- instead of one pageable, synchronous ``.cpu()``
     per tensor (the reference's result dicts are built that way, softgroup.py:323-360; round 3
-    counted 31 copy nodes per scan).  The arrays are views of the staging block, which they keep
-    alive: release results you no longer need, or every scan page-locks a fresh block."""
+    counted 31 copy nodes per scan).  The arrays are views of the staging block while less than
+    SG_PINNED_RESULTS_MB (default 256) of such blocks are alive, pageable copies beyond that (see
+    `_PINNED_CAP`): accumulating the results of a whole dataset does not accumulate page-locked memory."""
     return to_host_end(to_host_begin(tensors))
