@@ -263,7 +263,10 @@ int sg_spconv_inverse_rulebook(const int32_t *indices_fine, const int32_t *in2ou
  *                       and the position of any (tile, offset) of the list without a search
  *   nbr_tiles[T*32*K] : the tile's gather-table rows copied contiguously (-1 for padding rows)
  * Row order behind the API is untouched: a tile computes rows order[32t .. 32t+31] and stores
- * them back at their own row index. */
+ * them back at their own row index.  kvol <= 27.
+ * (Developer A/B knob SG_PLAN_ORDER=1|2, read once: rows mask-sorted inside super-blocks of consecutive
+ * rows and the tiles dealt to the 8 XCDs in contiguous ranges -- the spatially local plans measured and
+ * rejected in round 5; the default 0 is the order described above.) */
 #define SG_PLAN_HIST_WORDS 40
 size_t sg_spconv_plan_workspace_bytes(int num_out_rows);
 int sg_spconv_plan(const int32_t *nbr, int num_out_rows, int kvol, int32_t *order,
@@ -376,6 +379,10 @@ int sg_spconv_set_combine(int mode);
  * calls since the last sg_spconv_profile(1). */
 int sg_spconv_profile(int enable);
 int sg_spconv_profile_read(double *total_ms, int *launches);
+/* Per call since the last sg_spconv_profile(1), in call order: ms[i] and dims[5*i .. 5*i+4] = num_out_rows,
+ * kvol, cin, cout, num_in_rows; at most `cap` entries are written, *calls = number recorded (the profiler is
+ * a single-threaded developer hook: one stream at a time). */
+int sg_spconv_profile_detail(float *ms, int32_t *dims, int cap, int *calls);
 
 /* ---- training side of the sparse convolution (csrc/spconv_train.hip; spconv's autograd reached from
  * tools/train.py:47-58 under autocast) ---------------------------------------------------------

@@ -66,6 +66,7 @@ SIGNATURES = {
     'sg_spconv_set_combine': (_i, [_i]),
     'sg_spconv_profile': (_i, [_i]),
     'sg_spconv_profile_read': (_i, [_vp, _vp]),
+    'sg_spconv_profile_detail': (_i, [_vp, _vp, _i, _vp]),
     'sg_unet_arena_bytes': (_sz, [_vp, _i]),
     'sg_unet_forward': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     'sg_unet_train_arena_hint': (_sz, [_vp, _i]),

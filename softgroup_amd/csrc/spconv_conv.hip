@@ -731,9 +731,12 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     int un_w0 = -1;
     if (wave == 0) {
       if (round == 0 || !draws) {      // (no queue: the static snake all the way, A/B knob)
+        // (a reversed round mirrors the GROUP of 8 only: unit u stays on XCD u % 8 = blockIdx.x % 8,
+        // which is what the tile plan's per-XCD ranges rely on; G is a multiple of 8 when > 8)
         const int r = round + 1;
-        un_w0 = r * G + ((__builtin_popcount(r) & 1) ? G - 1 - static_cast<int>(blockIdx.x)
-                                                     : static_cast<int>(blockIdx.x));
+        const int b = static_cast<int>(blockIdx.x);
+        const int rev = (G & 7) == 0 ? G - 8 - (b & ~7) + (b & 7) : G - 1 - b;
+        un_w0 = r * G + ((__builtin_popcount(r) & 1) ? rev : b);
       } else if (drawing) {
         const unsigned t = __builtin_amdgcn_readfirstlane(ticket);     // drawn one unit ago
         un_w0 = dyn0 + static_cast<int>(t) * 8 + xcd;
@@ -1070,6 +1073,7 @@ static void launch_tile(const ConvArgs &a, int grid, size_t lds, bool vec, hipSt
 struct ConvProf {
   bool enabled = false;
   std::vector<hipEvent_t> pool;     // start/stop pairs, reused across sessions
+  std::vector<int> dims;            // per call: M_out, K, Cin, Cout, num_in_rows
   size_t used = 0;
   hipEvent_t take() {
     if (used == pool.size()) {
@@ -1341,7 +1345,27 @@ int sg_spconv_set_combine(int mode) {
 
 int sg_spconv_profile(int enable) {
   g_conv_prof.enabled = enable != 0;
-  if (enable) g_conv_prof.used = 0;
+  if (enable) {
+    g_conv_prof.used = 0;
+    g_conv_prof.dims.clear();
+  }
+  return SG_OK;
+}
+
+int sg_spconv_profile_detail(float *ms, int32_t *dims, int cap, int *calls) {
+  const int n = static_cast<int>(g_conv_prof.used / 2);
+  if (calls) *calls = n;
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (hipEventSynchronize(g_conv_prof.pool[2 * i + 1]) != hipSuccess) {
+      set_error("sg_spconv_profile_detail: event synchronisation failed");
+      return SG_ERR_LAUNCH;
+    }
+    float t = 0.f;
+    hipEventElapsedTime(&t, g_conv_prof.pool[2 * i], g_conv_prof.pool[2 * i + 1]);
+    if (ms) ms[i] = t;
+    if (dims)
+      for (int j = 0; j < 5; ++j) dims[5 * i + j] = g_conv_prof.dims[5 * static_cast<size_t>(i) + j];
+  }
   return SG_OK;
 }
 
@@ -1406,13 +1430,17 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   struct ProfScope {      // start event now, stop event when the call has enqueued its last kernel
     hipStream_t st;
     bool on;
-    ProfScope(hipStream_t s, bool count) : st(s), on(g_conv_prof.enabled && count) {
-      if (on) hipEventRecord(g_conv_prof.take(), st);
+    ProfScope(hipStream_t s, bool count, int m, int k, int ci, int co, int rows_in)
+        : st(s), on(g_conv_prof.enabled && count) {
+      if (on) {
+        hipEventRecord(g_conv_prof.take(), st);
+        for (int v : {m, k, ci, co, rows_in}) g_conv_prof.dims.push_back(v);
+      }
     }
     ~ProfScope() {
       if (on) hipEventRecord(g_conv_prof.take(), st);
     }
-  } prof_scope(stream, K > 1);     // the 1x1 identity-branch convs are not part of the conv roofline
+  } prof_scope(stream, K > 1, M_out, K, Cin, Cout, num_in_rows);     // the 1x1 identity-branch convs are not part of the conv roofline
   if (Cout % 4 != 0) {
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
                                 stream>>>(in, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,

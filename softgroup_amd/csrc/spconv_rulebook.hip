@@ -10,6 +10,8 @@
 // only visits offsets that some row of the tile really has.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "radix_sort.h"
 #include "scan.h"
@@ -166,127 +168,7 @@ __global__ void __launch_bounds__(256) inverse_rulebook_kernel(const int32_t *__
 // least significant.  Rows that have a rare offset end up together (so few tiles pay for it) and
 // neighbouring keys differ in offsets almost every row has anyway.  Measured on the S2 scene:
 // 8-10 % fewer (tile, offset) pairs than sorting by the raw mask on the two big U-Net levels.
-__global__ void __launch_bounds__(256) plan_mask_kernel(const int32_t *__restrict__ nbr, int M, int K,
-                                                       uint32_t *__restrict__ mask,
-                                                       int32_t *__restrict__ row,
-                                                       int32_t *__restrict__ freq) {
-  __shared__ int cnt[32];
-  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  uint32_t m = 0;
-  if (j < M) {
-    for (int k = 0; k < K; ++k) m |= (nbr[static_cast<int64_t>(j) * K + k] >= 0 ? 1u : 0u) << k;
-    mask[j] = m;
-    row[j] = j;
-  }
-  for (int k = 0; k < K; ++k) {
-    const int c = __popcll(__ballot((m >> k) & 1u));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[k], c);
-  }
-  __syncthreads();
-  if (threadIdx.x < K && cnt[threadIdx.x]) atomicAdd(&freq[threadIdx.x], cnt[threadIdx.x]);
-}
-
-// position of offset k in the sort key: number of offsets that are more common (ties: the lower
-// offset counts as more common), i.e. the most common offset is bit 0, the rarest bit K-1
-__device__ __forceinline__ void plan_bit_positions(const int32_t *__restrict__ freq, int K, int *pos) {
-  if (threadIdx.x < 32) {
-    const int k = threadIdx.x;
-    int p = 0;
-    if (k < K) {
-      const int fk = freq[k];
-      for (int o = 0; o < K; ++o) {
-        const int fo = freq[o];
-        p += (fo > fk || (fo == fk && o < k)) ? 1 : 0;
-      }
-    }
-    pos[k] = p;
-  }
-  __syncthreads();
-}
-
-__global__ void __launch_bounds__(256) plan_key_kernel(const int32_t *__restrict__ freq, int M, int K,
-                                                      uint32_t *__restrict__ mask_to_key) {
-  __shared__ int pos[32];
-  plan_bit_positions(freq, K, pos);
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= M) return;
-  const uint32_t m = mask_to_key[j];
-  uint32_t key = 0;
-  for (int k = 0; k < K; ++k) key |= ((m >> k) & 1u) << pos[k];
-  mask_to_key[j] = key;
-}
-
-__global__ void __launch_bounds__(256) plan_tiles_kernel(const uint32_t *__restrict__ key_sorted,
-                                                        const int32_t *__restrict__ freq, int M, int K,
-                                                        uint32_t *__restrict__ tile_mask) {
-  __shared__ int pos[32];
-  plan_bit_positions(freq, K, pos);
-  const int j = blockIdx.x * 256 + threadIdx.x;  // 256 rows = 8 tiles of 32 per block
-  uint32_t key = j < M ? key_sorted[j] : 0u;
-  // OR over each aligned group of 32 lanes (commutes with the bit permutation), then back to offsets
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) key |= __shfl_xor(key, o, 64);
-  if ((threadIdx.x & 31) == 0 && j < M) {
-    uint32_t m = 0;
-    for (int k = 0; k < K; ++k) m |= ((key >> pos[k]) & 1u) << k;
-    tile_mask[j >> 5] = m;
-  }
-}
-
-// tiles in descending order of work (number of kernel offsets present): with the heaviest
-// tiles dispatched first and workgroups handed to CUs round-robin, every SIMD ends up with a mix
-// of heavy and light waves instead of a tail of heavy ones (longest-processing-time-first).
-__global__ void __launch_bounds__(1024) plan_tile_order_kernel(const uint32_t *__restrict__ tile_mask,
-                                                              int num_tiles,
-                                                              int32_t *__restrict__ tile_order,
-                                                              uint32_t *__restrict__ hist_out) {
-  // one workgroup: counting sort of the tiles by popcount, descending (order inside a bucket is
-  // irrelevant for load balance, so positions come from LDS atomics)
-  __shared__ int hist[33], base[33];
-  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < num_tiles; t += 1024) atomicAdd(&hist[__popc(tile_mask[t])], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int b = 32; b >= 0; --b) { base[b] = run; run += hist[b]; }
-  }
-  // tiles per number of offsets, behind the plan's tile masks (SG_PLAN_HIST_WORDS words)
-  if (threadIdx.x < SG_PLAN_HIST_WORDS) hist_out[threadIdx.x] = threadIdx.x < 33 ? hist[threadIdx.x] : 0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < num_tiles; t += 1024)
-    tile_order[atomicAdd(&base[__popc(tile_mask[t])], 1)] = t;
-}
-
-// final layout, tile t' = tile_order[t'] of the mask-sorted sequence: rows of the tile (-1 pad),
-// its mask, and its gather-table rows copied contiguously (the conv kernel then reads one
-// linear 32*K block per tile instead of chasing order[] -> nbr[]).
-__global__ void __launch_bounds__(256) plan_emit_kernel(const int32_t *__restrict__ nbr, int M, int K,
-                                                       const int32_t *__restrict__ row_sorted,
-                                                       const uint32_t *__restrict__ tile_mask_sorted,
-                                                       const int32_t *__restrict__ tile_order,
-                                                       int num_tiles, int32_t *__restrict__ order,
-                                                       uint32_t *__restrict__ tile_mask,
-                                                       int32_t *__restrict__ nbr_tiles) {
-  const int per_tile = 32 * K;
-  for (int t2 = blockIdx.x; t2 < num_tiles; t2 += gridDim.x) {
-    const int t = tile_order[t2];
-    if (threadIdx.x == 0) tile_mask[t2] = tile_mask_sorted[t];
-    if (threadIdx.x < 32) {
-      const int pos = t * 32 + threadIdx.x;
-      order[t2 * 32 + threadIdx.x] = pos < M ? row_sorted[pos] : -1;
-    }
-    for (int e = threadIdx.x; e < per_tile; e += 256) {
-      const int r = e / K, k = e - r * K;
-      const int pos = t * 32 + r;
-      nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
-          pos < M ? nbr[static_cast<int64_t>(row_sorted[pos]) * K + k] : -1;
-    }
-  }
-}
-
+// (the kernels are the segmented ones further down: a single table is a plan problem of one segment)
 
 // =============================================================================================
 // Whole-pyramid index build: every level of a U-Net in a handful of launches.
@@ -426,12 +308,138 @@ struct PlanSeg {
   int32_t *order;
   uint32_t *tile_mask;
   int32_t *nbr_tiles;
-  int rows, K, row_base, tile_base;
+  int rows, K, row_base, tile_base, sb_base, sb_rows;      // sb_rows: rows per super-block of this table (multiple of 32)
 };
 struct PlanSegs {
-  int n, total_rows, total_tiles;
+  int n, total_rows, total_tiles, total_sbs;
   PlanSeg s[kPyrMaxSegs];
 };
+
+// ---- spatially local tile plans (round 5; SG_PLAN_ORDER=1|2, NOT the default -- see build_plans).  With the rows of a table in Morton order (the executor's
+// internal row order, unet_exec.hip) a SUPER-BLOCK of kSbRows consecutive rows is a compact region
+// of the scene.  Rows are mask-sorted inside their super-block only (a local sort in LDS instead of
+// a device-wide radix sort), so a tile's 32 rows and their neighbours lie in one region; the tiles
+// of a table are dealt to the 8 XCDs in CONTIGUOUS ranges (position p of the emitted list runs on
+// XCD p % 8 -- the conv kernel keeps unit -> XCD fixed -- and holds the (p / 8)-th tile of that
+// XCD's range), so a region's rows and halo are gathered through ONE 4 MB L2; inside an XCD's range
+// the tiles are emitted heaviest first (mode 1) or super-block by super-block, heaviest first inside
+// (mode 2).  Tables of <= kSbRows rows come out exactly as under the global sort.
+constexpr int kSbRowsMax = 16384;      // 128 KB of LDS for the sort
+constexpr int kSbIndexBits = 14;
+// rows per super-block of a table: SG_PLAN_SB (developer knob) or, by default, an eighth of the
+// table -- one XCD's share -- capped by what the LDS sort holds
+static int plan_sb_rows(int rows) {
+  static const int env = getenv("SG_PLAN_SB") ? atoi(getenv("SG_PLAN_SB")) : 0;
+  int sb = env > 0 ? env : (rows + 7) / 8;
+  if (env <= 0 && sb < 4096) sb = 4096;       // (small tables: one super-block = sorted as a whole)
+  sb = (sb + 31) / 32 * 32;
+  if (sb < 32) sb = 32;
+  if (sb > kSbRowsMax) sb = kSbRowsMax;
+  return sb;
+}
+
+// mask -> sort key (bits permuted by offset frequency), sort of one super-block, tile masks
+__global__ void __launch_bounds__(1024) plan_sort_sb_kernel(PlanSegs P, const uint32_t *__restrict__ mask,
+                                                           const int32_t *__restrict__ bitpos,
+                                                           int32_t *__restrict__ val_sorted,
+                                                           uint32_t *__restrict__ tmask) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t e[];
+  __shared__ int pos[32];
+  int seg = 0;
+  while (seg + 1 < P.n && static_cast<int>(blockIdx.x) >= P.s[seg + 1].sb_base) ++seg;
+  const PlanSeg &S = P.s[seg];
+  const int sb = blockIdx.x - S.sb_base;
+  const int first = sb * S.sb_rows;
+  const int cnt = min(S.sb_rows, S.rows - first);
+  const int K = S.K;
+  if (threadIdx.x < 32) pos[threadIdx.x] = bitpos[seg * 32 + threadIdx.x];
+  int N = 64;
+  while (N < cnt) N <<= 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    uint64_t v = ~0ull;
+    if (i < cnt) {
+      uint32_t key = 0;
+      for (uint32_t mm = mask[S.row_base + first + i]; mm; mm &= mm - 1) key |= 1u << pos[__ffs(static_cast<int>(mm)) - 1];
+      v = (static_cast<uint64_t>(key) << kSbIndexBits) | static_cast<uint64_t>(i);     // index in the low bits: stable
+    }
+    e[i] = v;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < N / 2; t += 1024) {
+        const int i = 2 * t - (t & (j - 1));
+        const int l = i + j;
+        const uint64_t a = e[i], b = e[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { e[i] = b; e[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i0 = 0; i0 < N; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    uint32_t key = 0;
+    if (i < cnt) {
+      const uint64_t v = e[i];
+      val_sorted[S.row_base + first + i] = first + static_cast<int>(v & ((1u << kSbIndexBits) - 1u));     // row inside the table
+      key = static_cast<uint32_t>(v >> kSbIndexBits);
+    }
+    // OR over each aligned group of 32 lanes (commutes with the bit permutation), then back to offsets
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) key |= __shfl_xor(key, o, 64);
+    if ((threadIdx.x & 31) == 0 && i < cnt) {
+      uint32_t m = 0;
+      for (int k = 0; k < K; ++k) m |= ((key >> pos[k]) & 1u) << k;
+      tmask[S.tile_base + sb * (S.sb_rows >> 5) + (i >> 5)] = m;
+    }
+  }
+}
+
+// Emission order of a table's tiles: grid (segment, XCD).  XCD x owns tiles [start, start + cnt) of
+// the super-block-major sequence, cnt = the number of positions p < nt with p % 8 == x; its k-th
+// tile goes to position 8 k + x.  Rank inside the range: descending number of offsets (mode 1) or
+// (super-block, descending number of offsets) (mode 2), ties in ascending tile order -- by counting
+// the tiles that come before (a few hundred per range; no atomics, deterministic).
+__global__ void __launch_bounds__(1024) plan_tile_order_xcd_kernel(PlanSegs P, const uint32_t *__restrict__ tmask,
+                                                                  int mode, int32_t *__restrict__ torder) {
+  __shared__ int bucket[4096];
+  __shared__ int hist[33];
+  const PlanSeg &S = P.s[blockIdx.x];
+  const int nt = (S.rows + 31) / 32;
+  const int x = blockIdx.y, q = nt >> 3, r = nt & 7;
+  const int cnt = q + (x < r ? 1 : 0), start = x * q + min(x, r);
+  if (x == 0) {      // tiles per number of offsets, behind the segment's final tile masks
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 1024) atomicAdd(&hist[__popc(tmask[S.tile_base + t])], 1);
+    __syncthreads();
+    if (threadIdx.x < SG_PLAN_HIST_WORDS) S.tile_mask[nt + threadIdx.x] = threadIdx.x < 33 ? hist[threadIdx.x] : 0;
+  }
+  const int sb_tiles = S.sb_rows >> 5;
+  const int sb0 = start / sb_tiles;
+  auto bucket_of = [&](int t) {
+    const int b = 32 - __popc(tmask[S.tile_base + t]);
+    return mode == 2 ? (t / sb_tiles - sb0) * 33 + b : b;
+  };
+  for (int c0 = 0; c0 < cnt; c0 += 4096) {      // (ranges above 4096 tiles: chunks keep their order)
+    const int n = min(4096, cnt - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) bucket[i] = bucket_of(start + c0 + i);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const int bi = bucket[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const int bj = bucket[j];
+        rank += (bj < bi || (bj == bi && j < i)) ? 1 : 0;
+      }
+      torder[S.tile_base + (c0 + rank) * 8 + x] = start + c0 + i;
+    }
+  }
+}
+
 // grid.y = segment (blocks past the segment's rows exit at once): the segment is block-uniform,
 // its descriptor comes straight from the kernel arguments through scalar loads
 __global__ void __launch_bounds__(256) plan_mask_all_kernel(PlanSegs P, uint32_t *__restrict__ mask,
@@ -563,12 +571,15 @@ __global__ void __launch_bounds__(1024) plan_tile_order_all_kernel(PlanSegs P, c
 }
 
 // grid = (tile blocks, segments)
+// (`val_bias`: what is subtracted from val_sorted to get the row inside the table -- the radix path
+// sorts table-global row ids (bias = row_base), the super-block sort writes local ones (0))
 __global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const int32_t *__restrict__ val_sorted,
                                                            const uint32_t *__restrict__ tmask,
-                                                           const int32_t *__restrict__ torder) {
+                                                           const int32_t *__restrict__ torder, int local_vals) {
   const int seg = blockIdx.y;
-  const int rows = P.s[seg].rows, K = P.s[seg].K, row_base = P.s[seg].row_base,
-            tile_base = P.s[seg].tile_base;
+  const int rows = P.s[seg].rows, K = P.s[seg].K, tile_base = P.s[seg].tile_base;
+  const int val_base = P.s[seg].row_base;
+  const int row_base = local_vals ? 0 : val_base;
   const int nt = (rows + 31) / 32, per_tile = 32 * K;
   const int32_t *nbr = P.s[seg].nbr;
   int32_t *order = P.s[seg].order, *nbr_tiles = P.s[seg].nbr_tiles;
@@ -578,15 +589,83 @@ __global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const in
     if (threadIdx.x == 0) tile_mask[t2] = tmask[tile_base + t];
     if (threadIdx.x < 32) {
       const int pos = t * 32 + threadIdx.x;
-      order[t2 * 32 + threadIdx.x] = pos < rows ? val_sorted[row_base + pos] - row_base : -1;
+      order[t2 * 32 + threadIdx.x] = pos < rows ? val_sorted[val_base + pos] - row_base : -1;
     }
     for (int e = threadIdx.x; e < per_tile; e += 256) {
       const int r = e / K, k = e - r * K;
       const int pos = t * 32 + r;
       nbr_tiles[static_cast<int64_t>(t2) * per_tile + e] =
-          pos < rows ? nbr[static_cast<int64_t>(val_sorted[row_base + pos] - row_base) * K + k] : -1;
+          pos < rows ? nbr[static_cast<int64_t>(val_sorted[val_base + pos] - row_base) * K + k] : -1;
     }
   }
+}
+
+// scratch of build_plans for R rows in T tiles
+static size_t plan_scratch_bytes(size_t R, size_t T) {
+  return 2 * align_up(R * 4) + 2 * align_up(T * 4) + 2 * align_up(kPyrMaxSegs * 32 * 4) +
+         radix_sort_workspace_bytes(static_cast<int64_t>(R)) + 512;
+}
+
+// Tile plans of the P.n tables described by P (row_base / tile_base / sb_base filled by the caller).
+// SG_PLAN_ORDER: 0 (default) = device-wide radix sort by mask, heaviest tiles first over the whole
+// table; 1 = super-block sort, XCD ranges, heaviest first inside a range; 2 = the same with
+// super-block-major emission inside a range.  1 and 2 are the spatially local plans of round 5,
+// measured SLOWER on every level of the bench scene (fewer L2 misses per item, but 17-58 % more
+// (tile, offset) items than the global sort: profiles/r05_conv_locality.txt) -- kept as A/B knobs.
+static int plan_order_mode() {
+  static const int mode = getenv("SG_PLAN_ORDER") ? atoi(getenv("SG_PLAN_ORDER")) : 0;
+  return mode;
+}
+static int build_plans(const PlanSegs &P, void *ws2, size_t ws2_bytes, bool zero_freq, hipStream_t stream,
+                       const char *who) {
+  Workspace wsp(ws2, ws2_bytes);
+  const size_t R = static_cast<size_t>(P.total_rows);
+  uint32_t *mask = wsp.take<uint32_t>(R);
+  int32_t *val = wsp.take<int32_t>(R);
+  uint32_t *tmask = wsp.take<uint32_t>(P.total_tiles);
+  int32_t *torder = wsp.take<int32_t>(P.total_tiles);
+  int32_t *freq = wsp.take<int32_t>(kPyrMaxSegs * 32);
+  int32_t *bitpos = wsp.take<int32_t>(kPyrMaxSegs * 32);
+  const size_t rs_bytes = radix_sort_workspace_bytes(static_cast<int64_t>(R));
+  void *rs_ws = wsp.take<char>(rs_bytes);
+  if (!rs_ws) {
+    set_error("%s: build workspace too small", who);
+    return SG_ERR_WORKSPACE;
+  }
+  if (zero_freq) hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);
+  int max_rows = 0;
+  for (int i = 0; i < P.n; ++i) max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
+  const dim3 grid((max_rows + 255) / 256, P.n);
+  plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
+  static const bool raw_env = getenv("SG_PLAN_RAW") != nullptr;     // developer knob: sort by the raw mask
+  if (raw_env) hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);   // equal counts -> identity permutation
+  plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
+  const int mode = plan_order_mode();
+  if (mode == 0) {
+    plan_key_all_kernel<<<grid, 256, 0, stream>>>(P, bitpos, mask);
+    uint32_t *ms;
+    int32_t *vs;
+    int nbits = kPlanKeyBits;
+    for (int n = P.n - 1; n > 0; n >>= 1) ++nbits;
+    int rc = radix_sort_pairs(mask, val, static_cast<int64_t>(R), nbits, rs_ws, rs_bytes, stream, &ms, &vs);
+    if (rc != SG_OK) return rc;
+    plan_tiles_all_kernel<<<grid, 256, 0, stream>>>(P, ms, bitpos, tmask);
+    plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(P, tmask, torder);
+    plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, vs, tmask, torder, 0);
+  } else {
+    int max_sb = 64;
+    for (int i = 0; i < P.n; ++i)
+      while (max_sb < P.s[i].sb_rows && max_sb < P.s[i].rows) max_sb <<= 1;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(plan_sort_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kSbRowsMax * 8);
+    });
+    plan_sort_sb_kernel<<<P.total_sbs, 1024, static_cast<size_t>(max_sb) * 8, stream>>>(P, mask, bitpos, val, tmask);
+    plan_tile_order_xcd_kernel<<<dim3(P.n, 8), 1024, 0, stream>>>(P, tmask, mode, torder);
+    plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, val, tmask, torder, 1);
+  }
+  return check_launch(who);
 }
 
 struct PyrWs {
@@ -767,8 +846,7 @@ size_t sg_spconv_pyramid_build_workspace_bytes(const sg_pyramid_level *levels, i
   }
   const size_t R = static_cast<size_t>(total > 0 ? total : 1);
   const size_t T = R / 32 + static_cast<size_t>(3 * n_levels) + 1;
-  return 2 * align_up(R * 4) + 2 * align_up(T * 4) + 2 * align_up(kPyrMaxSegs * 32 * 4) +
-         radix_sort_workspace_bytes(static_cast<int64_t>(R)) + 512;
+  return plan_scratch_bytes(R, T);
 }
 
 int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape_host, int n_levels,
@@ -790,13 +868,15 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
   PyrOut o;
   PlanSegs P;
   P.n = 0;
-  int row_base = 0, tile_base = 0;
+  int row_base = 0, tile_base = 0, sb_base = 0;
   auto add_seg = [&](const int32_t *nbr, int rows, int K, const sg_plan_ptrs &pl) {
     PlanSeg &S = P.s[P.n++];
     S.nbr = nbr; S.order = pl.order; S.tile_mask = pl.tile_mask; S.nbr_tiles = pl.nbr_tiles;
-    S.rows = rows; S.K = K; S.row_base = row_base; S.tile_base = tile_base;
+    S.rows = rows; S.K = K; S.row_base = row_base; S.tile_base = tile_base; S.sb_base = sb_base;
+    S.sb_rows = plan_sb_rows(rows);
     row_base += rows;
     tile_base += (rows + 31) / 32;
+    sb_base += (rows + S.sb_rows - 1) / S.sb_rows;
   };
   Shape3 s{shape_host[0], shape_host[1], shape_host[2]};
   o.pre27[0] = 0;
@@ -828,20 +908,22 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
   }
   P.total_rows = row_base;
   P.total_tiles = tile_base;
+  P.total_sbs = sb_base;
   if (P.n == 0) return check_launch("sg_spconv_pyramid_build");
-  Workspace a(ws2, ws2_bytes);
-  const size_t R = static_cast<size_t>(P.total_rows);
-  uint32_t *mask = a.take<uint32_t>(R);
-  int32_t *val = a.take<int32_t>(R);
-  uint32_t *tmask = a.take<uint32_t>(P.total_tiles);
-  int32_t *torder = a.take<int32_t>(P.total_tiles);
-  int32_t *freq = a.take<int32_t>(kPyrMaxSegs * 32);
-  int32_t *bitpos = a.take<int32_t>(kPyrMaxSegs * 32);
-  const size_t rs_bytes = radix_sort_workspace_bytes(static_cast<int64_t>(R));
-  void *rs_ws = a.take<char>(rs_bytes);
-  if (!rs_ws) {
-    set_error("sg_spconv_pyramid_build: build workspace too small");
-    return SG_ERR_WORKSPACE;
+  // (freq sits where build_plans carves it: the fill below clears it together with the child tables)
+  int32_t *freq;
+  {
+    Workspace wsp(ws2, ws2_bytes);
+    const size_t R = static_cast<size_t>(P.total_rows);
+    wsp.take<uint32_t>(R);
+    wsp.take<int32_t>(R);
+    wsp.take<uint32_t>(P.total_tiles);
+    wsp.take<int32_t>(P.total_tiles);
+    freq = wsp.take<int32_t>(kPyrMaxSegs * 32);
+    if (!freq) {
+      set_error("sg_spconv_pyramid_build: build workspace too small");
+      return SG_ERR_WORKSPACE;
+    }
   }
   {      // one launch: the strided tables' "no child" marks and the offset histogram of the plans
     static_assert(kPyrMaxLevels + 1 <= kFillMax, "one fill region per level + the histogram");
@@ -859,63 +941,25 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
         indices, M0, L, w.vals, w.rowtab, w.cap, w.slot, w.pos, o);
   }
   pyr_subm_kernel<<<grid_for(o.pre27[L], 256, 8192), 256, 0, stream>>>(L, w.keys, w.rowtab, w.cap, o);
-  int max_rows = 0;
-  for (int i = 0; i < P.n; ++i) max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
-  const dim3 grid((max_rows + 255) / 256, P.n);
-  plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
-  plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
-  plan_key_all_kernel<<<grid, 256, 0, stream>>>(P, bitpos, mask);
-  uint32_t *ms;
-  int32_t *vs;
-  int nbits = kPlanKeyBits;
-  for (int n = P.n - 1; n > 0; n >>= 1) ++nbits;
-  int rc = radix_sort_pairs(mask, val, static_cast<int64_t>(R), nbits, rs_ws, rs_bytes, stream, &ms, &vs);
-  if (rc != SG_OK) return rc;
-  plan_tiles_all_kernel<<<grid, 256, 0, stream>>>(P, ms, bitpos, tmask);
-  plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(P, tmask, torder);
-  plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, vs, tmask, torder);
-  return check_launch("sg_spconv_pyramid_build");
+  return build_plans(P, ws2, ws2_bytes, false, stream, "sg_spconv_pyramid_build");
 }
 
 size_t sg_spconv_plan_workspace_bytes(int M) {
   const size_t nn = static_cast<size_t>(M > 0 ? M : 1);
-  const size_t nt = (nn + 31) / 32;
-  return 2 * align_up(nn * 4) + 2 * align_up(nt * 4) + align_up(32 * 4) + radix_sort_workspace_bytes(M) + 256;
+  return plan_scratch_bytes(nn, (nn + 31) / 32 + 1);
 }
 
 int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *tile_mask,
                    int32_t *nbr_tiles, void *ws, size_t ws_bytes, sg_stream_t stream_) {
-  SG_REQUIRE(M >= 0 && K >= 1 && K <= 32, "sg_spconv_plan: bad arguments (M=%d K=%d)", M, K);
+  SG_REQUIRE(M >= 0 && K >= 1 && K <= 27, "sg_spconv_plan: bad arguments (M=%d K=%d)", M, K);
   if (M == 0) return SG_OK;
-  hipStream_t stream = as_stream(stream_);
-  const int num_tiles = (M + 31) / 32;
-  Workspace a(ws, ws_bytes);
-  uint32_t *mask = a.take<uint32_t>(M);
-  int32_t *row = a.take<int32_t>(M);
-  uint32_t *tmask = a.take<uint32_t>(num_tiles);
-  int32_t *torder = a.take<int32_t>(num_tiles);
-  int32_t *freq = a.take<int32_t>(32);
-  const size_t rs_bytes = radix_sort_workspace_bytes(M);
-  void *rs_ws = a.take<char>(rs_bytes);
-  if (!rs_ws) {
-    set_error("sg_spconv_plan: workspace too small");
-    return SG_ERR_WORKSPACE;
-  }
-  const int grid = (M + 255) / 256;
-  hipMemsetAsync(freq, 0, 32 * 4, stream);
-  plan_mask_kernel<<<grid, 256, 0, stream>>>(nbr, M, K, mask, row, freq);
-  static const bool raw_env = getenv("SG_PLAN_RAW") != nullptr;     // developer knob: sort by the raw mask
-  if (raw_env) hipMemsetAsync(freq, 0, 32 * 4, stream);             // equal counts -> identity permutation
-  plan_key_kernel<<<grid, 256, 0, stream>>>(freq, M, K, mask);
-  uint32_t *ms;
-  int32_t *rs;
-  int rc = radix_sort_pairs(mask, row, M, K, rs_ws, rs_bytes, stream, &ms, &rs);
-  if (rc != SG_OK) return rc;
-  plan_tiles_kernel<<<grid, 256, 0, stream>>>(ms, freq, M, K, tmask);
-  plan_tile_order_kernel<<<1, 1024, 0, stream>>>(tmask, num_tiles, torder, tile_mask + num_tiles);
-  plan_emit_kernel<<<min(num_tiles, 4096), 256, 0, stream>>>(nbr, M, K, rs, tmask, torder, num_tiles,
-                                                            order, tile_mask, nbr_tiles);
-  return check_launch("sg_spconv_plan");
+  PlanSegs P;
+  P.n = 1;
+  P.s[0] = PlanSeg{nbr, order, tile_mask, nbr_tiles, M, K, 0, 0, 0, plan_sb_rows(M)};
+  P.total_rows = M;
+  P.total_tiles = (M + 31) / 32;
+  P.total_sbs = (M + P.s[0].sb_rows - 1) / P.s[0].sb_rows;
+  return build_plans(P, ws, ws_bytes, true, as_stream(stream_), "sg_spconv_plan");
 }
 
 }  // extern "C"

@@ -18,10 +18,78 @@
 #include <utility>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
+#include "radix_sort.h"
 #include "unet_common.h"
 
 namespace sg {
+
+// ---------------------------------------------------------------------------------------------
+// Internal row order (round 5; SG_UNET_MORTON=1, off by default).  The rows of an API tensor are in first-seen order of a randomly
+// ordered point cloud, i.e. spatially unsorted: the 27-neighbour gather of a 32-row tile then
+// touches ~150 unrelated 128-B lines, no two tiles on an XCD share any, and every re-read of a
+// row misses that XCD's 4 MB L2.  The executor therefore works on a PERMUTED copy of the level-0
+// voxels, sorted by (batch, Morton code of the coordinates): the whole-pyramid index build numbers
+// the sites of every coarser level by their smallest level-0 descendant, and the descendants of a
+// coarse cell are contiguous in Morton order -- so every level of the U-Net comes out in Morton
+// order from this ONE sort.  Behind the API nothing changes: the input features are gathered into
+// the internal order where they are padded anyway, the output rows are scattered back.
+// key = top 24 bits of (batch | z-order interleave of the coordinates >> s): 3 radix passes; rows
+// that share a key (the same 2^s-cell) keep their first-seen order (stable sort).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) batch_max_kernel(const int32_t *__restrict__ indices, int M,
+                                                       int32_t *__restrict__ bmax) {
+  int m = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) m = max(m, indices[4 * i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(bmax, m);
+}
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {      // 21 bits -> every third bit
+  uint64_t x = v & 0x1fffffu;
+  x = (x | (x << 32)) & 0x1f00000000ffffull;
+  x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+  x = (x | (x << 8)) & 0x100f00f00f00f00full;
+  x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+__global__ void __launch_bounds__(256) morton_key_kernel(const int32_t *__restrict__ indices, int M,
+                                                        int dim_bits, const int32_t *__restrict__ bmax,
+                                                        uint32_t *__restrict__ key, int32_t *__restrict__ val) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int4 c = reinterpret_cast<const int4 *>(indices)[i];
+  const int bb = 32 - __clz(*bmax);                 // bits of the batch index
+  const uint64_t code = (static_cast<uint64_t>(static_cast<uint32_t>(c.x)) << (3 * dim_bits)) |
+                        (spread3(c.y) << 2) | (spread3(c.z) << 1) | spread3(c.w);
+  const int total = bb + 3 * dim_bits;
+  key[i] = static_cast<uint32_t>(total > 24 ? code >> (total - 24) : code);
+  val[i] = i;
+}
+__global__ void __launch_bounds__(256) permute_indices_kernel(const int32_t *__restrict__ indices,
+                                                             const int32_t *__restrict__ perm, int M,
+                                                             int32_t *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < M) reinterpret_cast<int4 *>(out)[i] = reinterpret_cast<const int4 *>(indices)[perm[i]];
+}
+// out[perm ? dst-major gather : identity]: rows of `in` [*, c4 float4] gathered (out[j] = in[perm[j]]) or
+// scattered (out[perm[j]] = in[j])
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) permute_rows_kernel(const float4 *__restrict__ in,
+                                                          const int32_t *__restrict__ perm, int64_t rows,
+                                                          int c4, float4 *__restrict__ out) {
+  const int64_t total = rows * c4;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int64_t r = t / c4;
+    const int c = static_cast<int>(t - r * c4);
+    const int64_t o = perm[r];
+    if (SCATTER) out[o * c4 + c] = in[t];
+    else out[t] = in[o * c4 + c];
+  }
+}
 
 // out = [a | b] row-wise; optionally also out_act = relu(out * scale + shift) (the BatchNorm1d +
 // ReLU in front of the first tail block)
@@ -236,13 +304,16 @@ int unet_build_index(const char *who, int L, const int32_t *indices, int num_row
 }
 
 // feature rows zero-padded to `cpad` channels (the input conv on the persistent kernel: Cin % 16 == 0)
+// (`perm` != null: row r of the result is row perm[r] of `in` -- the executor's internal row order)
 __global__ void __launch_bounds__(256) pad_channels_kernel(const float *__restrict__ in, int64_t rows, int cin,
-                                                          int cpad, float *__restrict__ out) {
+                                                          int cpad, const int32_t *__restrict__ perm,
+                                                          float *__restrict__ out) {
   const int64_t total = rows * cpad;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
     const int64_t r = t / cpad;
     const int c = static_cast<int>(t - r * cpad);
-    out[t] = c < cin ? in[r * cin + c] : 0.f;
+    const int64_t src = perm ? perm[r] : r;
+    out[t] = c < cin ? in[src * cin + c] : 0.f;
   }
 }
 
@@ -258,6 +329,7 @@ struct Exec {
   Arena ar;             // features and conv scratch: caller's stream only
   sg_stream_t stream;   // caller's stream (convolutions, elementwise)
   const LevelIdx *idx;  // per level: rows, tables and plans (complete before the first conv runs)
+  const int32_t *perm = nullptr;   // internal row j = API row perm[j] (null: API order); level 0 input only
 
   Exec(const sg_unet_desc *desc, void *arena, size_t bytes, sg_stream_t s, const LevelIdx *li)
       : d(desc), ar(arena, bytes), stream(s), idx(li) {}
@@ -326,10 +398,10 @@ struct Exec {
       // weights packed for more input channels than the features have (a multiple of 16: the
       // persistent MFMA kernel instead of the general one): convolve a zero-padded copy
       const int cpk = d->input_cin_packed > pre_cin ? d->input_cin_packed : pre_cin;
-      if (cpk != pre_cin && rows) {
+      if ((cpk != pre_cin || perm != nullptr) && rows) {       // (the copy that also brings the rows into internal order)
         SG_ALLOC(xp, float, static_cast<size_t>(rows) * cpk);
         pad_channels_kernel<<<grid_for(static_cast<int64_t>(rows) * cpk, 256), 256, 0, as_stream(stream)>>>(
-            pre_in, rows, pre_cin, cpk, xp);
+            pre_in, rows, pre_cin, cpk, perm, xp);
         pre_in = xp;
       }
       SG_TRY(conv(pre_in, rows, subm, cpk, c, d->input_w, nullptr, nullptr, nullptr, a0, x0));
@@ -451,6 +523,9 @@ size_t sg_unet_arena_bytes(const sg_unet_desc *d, int num_rows) {
   // feature part: at most ~12 live buffers of 2*planes floats per level (stack discipline)
   size_t total = unet_index_bytes(d->n_levels, num_rows) + (1 << 20);
   const size_t rows = static_cast<size_t>(num_rows > 0 ? num_rows : 1);
+  // internal row order: keys + row ids + sort scratch, permuted coordinates, permuted input and output rows
+  total += 2 * align_up(rows * 4) + radix_sort_workspace_bytes(static_cast<int64_t>(rows)) + align_up(rows * 16) +
+           2 * align_up(rows * static_cast<size_t>(d->levels[0].planes) * 4) + 4096;
   for (int l = 0; l < d->n_levels; ++l)
     total += rows * 12 * 2 * static_cast<size_t>(d->levels[l].planes) * 4 + (64 << 10);
   return total;
@@ -473,22 +548,79 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     explicit ArithScope(int a) : keep(t_conv_arith) { if (a > 0) t_conv_arith = a; }
     ~ArithScope() { t_conv_arith = keep; }
   } arith_scope(d->arithmetic);
+  // ---- internal row order (see morton_key_kernel): SG_UNET_MORTON=1 turns it on (A/B knob; off by
+  //      default: measured neutral under the default tile plan and not enough to pay for the spatially
+  //      local plans' extra items, profiles/r05_conv_locality.txt), SG_UNET_MORTON_MIN = smallest input
+  static const int morton_env = getenv("SG_UNET_MORTON") ? atoi(getenv("SG_UNET_MORTON")) : 0;
+  static const int morton_min = getenv("SG_UNET_MORTON_MIN") ? atoi(getenv("SG_UNET_MORTON_MIN")) : 16384;
+  const bool pre = d->input_w != nullptr;
+  const int c0 = d->levels[0].planes;
+  const bool morton = morton_env != 0 && num_rows >= morton_min;
+  Arena head(arena, arena_bytes);
+  const int32_t *perm = nullptr;
+  const int32_t *idx_in = indices;
+  const float *feats_in = feats;
+  float *out_int = out;
+  if (morton) {
+    hipStream_t st = as_stream(stream);
+    const size_t M = static_cast<size_t>(num_rows);
+    uint32_t *key = head.take<uint32_t>(M);
+    int32_t *val = head.take<int32_t>(M);
+    const size_t rs_bytes = radix_sort_workspace_bytes(static_cast<int64_t>(M));
+    void *rs_ws = head.take<char>(rs_bytes);
+    int32_t *idx_p = head.take<int32_t>(M * 4);
+    int32_t *bmax = head.take<int32_t>(64);
+    float *out_p = head.take<float>(M * c0);
+    float *feats_p = pre ? out_p : head.take<float>(M * c0);     // (with an input conv the padding copy permutes)
+    if (feats_p == nullptr || out_p == nullptr) {
+      set_error("sg_unet_forward: arena too small (%zu bytes) for the internal row order", arena_bytes);
+      return SG_ERR_WORKSPACE;
+    }
+    int dim_bits = 1;
+    for (int a = 0; a < 3; ++a)
+      while ((1 << dim_bits) < spatial_shape_host[a]) ++dim_bits;
+    SG_REQUIRE(dim_bits <= 20, "sg_unet_forward: spatial extent above 2^20");
+    hipMemsetAsync(bmax, 0, 4, st);
+    batch_max_kernel<<<grid_for(num_rows, 256, 256), 256, 0, st>>>(indices, num_rows, bmax);
+    morton_key_kernel<<<(num_rows + 255) / 256, 256, 0, st>>>(indices, num_rows, dim_bits, bmax, key, val);
+    uint32_t *ks;
+    int32_t *vs;
+    SG_TRY(radix_sort_pairs(key, val, static_cast<int64_t>(M), 24, rs_ws, rs_bytes, st, &ks, &vs));
+    permute_indices_kernel<<<(num_rows + 255) / 256, 256, 0, st>>>(indices, vs, num_rows, idx_p);
+    perm = vs;
+    idx_in = idx_p;
+    out_int = out_p;
+    if (!pre) {
+      permute_rows_kernel<false><<<grid_for(static_cast<int64_t>(M) * (c0 / 4), 256), 256, 0, st>>>(
+          reinterpret_cast<const float4 *>(feats), vs, num_rows, c0 / 4, reinterpret_cast<float4 *>(feats_p));
+      feats_in = feats_p;
+    }
+    SG_TRY(check_launch("sg_unet_forward(row order)"));
+  }
+  const size_t head_bytes = align_up(head.off, 4096);
+  char *rest = static_cast<char *>(arena) + head_bytes;
+  const size_t rest_bytes = arena_bytes > head_bytes ? arena_bytes - head_bytes : 0;
   // ---- gather tables and tile plans of all levels (index stream; this stream waits for them once)
   LevelIdx li[SG_PYRAMID_MAX_LEVELS];
   std::unique_lock<std::mutex> guard;
   size_t index_bytes = 0;
-  SG_TRY(unet_build_index("sg_unet_forward", L, indices, num_rows, spatial_shape_host, arena, arena_bytes, stream,
+  SG_TRY(unet_build_index("sg_unet_forward", L, idx_in, num_rows, spatial_shape_host, rest, rest_bytes, stream,
                           li, &index_bytes, &guard));
   // ---- the convolutions: feature part of the arena
   const size_t used = align_up(index_bytes, 4096);
-  if (arena_bytes <= used) {
+  if (rest_bytes <= used) {
     set_error("sg_unet_forward: arena too small (%zu bytes)", arena_bytes);
     return SG_ERR_WORKSPACE;
   }
-  Exec ex(d, static_cast<char *>(arena) + used, arena_bytes - used, stream, li);
-  const bool pre = d->input_w != nullptr;
-  const int rc = ex.level(0, pre ? nullptr : feats, nullptr, pre ? feats : nullptr, d->input_cin,
-                          d->out_bn_scale, d->out_bn_shift, out);
+  Exec ex(d, rest + used, rest_bytes - used, stream, li);
+  ex.perm = pre ? perm : nullptr;
+  int rc = ex.level(0, pre ? nullptr : feats_in, nullptr, pre ? feats : nullptr, d->input_cin,
+                    d->out_bn_scale, d->out_bn_shift, out_int);
+  if (rc == SG_OK && morton) {      // back to the API's row order
+    permute_rows_kernel<true><<<grid_for(static_cast<int64_t>(num_rows) * (c0 / 4), 256), 256, 0, as_stream(stream)>>>(
+        reinterpret_cast<const float4 *>(out_int), perm, num_rows, c0 / 4, reinterpret_cast<float4 *>(out));
+    rc = check_launch("sg_unet_forward(row order)");
+  }
   return rc;
 }
 
