@@ -384,6 +384,24 @@ int sg_spconv_profile_read(double *total_ms, int *launches);
  * a single-threaded developer hook: one stream at a time). */
 int sg_spconv_profile_detail(float *ms, int32_t *dims, int cap, int *calls);
 
+/* ---- point-wise heads (csrc/heads.hip) -------------------------------------------------------
+ * Replaces, in SoftGroup.forward_backbone / forward_test (softgroup/model/softgroup.py:374-376,320), the
+ * devoxelize gather `output.features[input_map.long()]`, the two MLP heads `semantic_linear` /
+ * `offset_linear` (softgroup/model/blocks.py:9-27: Linear, BatchNorm1d, ReLU, Linear) in eval mode and
+ * `semantic_scores.max(1)[1]` by one kernel.  sg_mlp2: w1 [C][C] and w2 [out][C] in nn.Linear's [out, in]
+ * layout, b1 [C], b2 [out], the eval-mode BatchNorm1d folded to y = x * bn_scale + bn_shift.
+ * v2p_map [n_points] int32 or int64 (NULL: identity), channels 16 or 32, semantic->out <= 32,
+ * offset->out <= 4.  output_feats [n_points, channels] and semantic_preds [n_points] (int64, first
+ * maximum) may be NULL.  fp32 FMA chains in ascending channel order (deterministic). */
+typedef struct sg_mlp2 {
+  const float *w1, *b1, *bn_scale, *bn_shift, *w2, *b2;
+  int out;
+} sg_mlp2;
+int sg_pointwise_heads(const float *voxel_feats, const void *v2p_map, int v2p_is_int64, int n_points,
+                       int channels, const sg_mlp2 *semantic, const sg_mlp2 *offset, float *output_feats,
+                       float *semantic_scores, float *pt_offsets, int64_t *semantic_preds,
+                       sg_stream_t stream);
+
 /* ---- training side of the sparse convolution (csrc/spconv_train.hip; spconv's autograd reached from
  * tools/train.py:47-58 under autocast) ---------------------------------------------------------
  * bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16), bf16 result rounded to nearest even:

@@ -73,6 +73,7 @@ SIGNATURES = {
     'sg_unet_train_forward': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'sg_unet_train_backward': (_i, [_vp, _vp, _vp, _vp]),
     'sg_unet_train_release': (None, [_vp]),
+    'sg_pointwise_heads': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sg_spconv_packed_weight_elems': (_sz, [_i, _i, _i]),
     'sg_spconv_pack_weight': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'sg_spconv_conv_workspace_bytes': (_sz, [_i, _i]),

@@ -4,6 +4,8 @@
 // Ranks inside a wave come from ballot "match-any" masks, so the scatter needs no sorting in
 // LDS and keeps the pass stable.
 #pragma once
+#include <mutex>
+
 #include "common.h"
 #include "scan.h"
 
@@ -38,6 +40,13 @@ static __global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const uint32_t
   if (totals && h[threadIdx.x]) atomicAdd(&totals[threadIdx.x], h[threadIdx.x]);
 }
 
+// Stable scatter of one pass.  The block's tile is first sorted by digit INSIDE LDS (rank of a pair =
+// start of its digit in the tile + pairs of that digit in earlier rounds / waves / lanes), then written
+// out in tile order: consecutive threads hold consecutive pairs of a digit's run, i.e. coalesced stores,
+// and nothing waits for a store before the kernel ends.  (The first version stored every round's pairs
+// straight to their final, scattered addresses; `__syncthreads()` waits for outstanding stores on this
+// target, so each of a block's 8-16 rounds paid a full store round trip: 23-34 us per pass over 220-550 k
+// pairs, profiles/r05_index_build.txt.)  Dynamic LDS: items * 256 * 8 bytes.
 static __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint32_t *__restrict__ keys,
                                                              const int32_t *__restrict__ vals,
                                                              int64_t n, int shift, int nblk, int items,
@@ -45,31 +54,74 @@ static __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint3
                                                              const int32_t *__restrict__ totals,
                                                              uint32_t *__restrict__ keys_out,
                                                              int32_t *__restrict__ vals_out) {
-  __shared__ int base[kRsBuckets];
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+  uint32_t *skey = reinterpret_cast<uint32_t *>(rs_lds);
+  int32_t *sval = reinterpret_cast<int32_t *>(rs_lds) + items * kRsBlock;
+  __shared__ int base[kRsBuckets];        // global position of the tile's first pair of each digit
+  __shared__ int dstart[kRsBuckets];      // start of the digit's run inside the tile
+  __shared__ int run[kRsBuckets];         // pairs of the digit placed so far (earlier rounds)
   __shared__ int wcnt[4][kRsBuckets];
   __shared__ int lds4[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * items * kRsBlock;
+  const int in_tile = static_cast<int>(n - tile < static_cast<int64_t>(items) * kRsBlock ? n - tile
+                                                                                       : static_cast<int64_t>(items) * kRsBlock);
+  // ---- digit counts of this tile (LDS atomics; order does not matter for counts)
+  run[threadIdx.x] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < in_tile; e += kRsBlock) atomicAdd(&run[(keys[tile + e] >> shift) & 0xff], 1);
+  __syncthreads();
+  const int mine = run[threadIdx.x];
+  {
+    const int incl = block_incl_scan_256(mine, lds4, nullptr);
+    dstart[threadIdx.x] = incl - mine;
+  }
   if (totals) {
     // small inputs: hist holds raw per-block counts; this block's base of digit d =
     // (exclusive prefix of the digit totals) + (counts of d in the blocks before this one)
-    const int64_t row = static_cast<int64_t>(threadIdx.x) * nblk;
-    int before = 0;
-    for (int b = 0; b < static_cast<int>(blockIdx.x); ++b) before += hist[row + b];
+    // (16 independent loads per step: as a plain loop the compiler waits for every load before the
+    // next -- ~0.25 us each -- and the LAST block of a 113-block pass spent 25 us here, which was the
+    // length of the whole kernel whatever the number of pairs)
+    const int32_t *row = hist + static_cast<int64_t>(threadIdx.x) * nblk;
+    const int nb = static_cast<int>(blockIdx.x);
+    int before = 0, b = 0;
+    for (; b + 16 <= nb; b += 16) {
+      int v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = row[b + q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) before += v[q];
+    }
+    for (; b < nb; ++b) before += row[b];
     const int tot = totals[threadIdx.x];
     const int incl = block_incl_scan_256(tot, lds4, nullptr);
     base[threadIdx.x] = incl - tot + before;
   } else {
     base[threadIdx.x] = hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x];
   }
-  const int64_t tile = static_cast<int64_t>(blockIdx.x) * items * kRsBlock;
+  run[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- rounds of 256 pairs: rank inside the tile, pair into its LDS slot
+  uint32_t pk[8];
+  int32_t pv[8];
   for (int r = 0; r < items; ++r) {
+    if ((r & 7) == 0) {       // the loads of 8 rounds are requested together (items is a multiple of 8)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int64_t j = tile + static_cast<int64_t>(r + q) * kRsBlock + threadIdx.x;
+        pk[q] = j < n ? keys[j] : 0u;
+        pv[q] = j < n ? vals[j] : 0;
+      }
+    }
 #pragma unroll
     for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
-    const int64_t i = tile + r * kRsBlock + threadIdx.x;
-    const bool valid = i < n;
-    const uint32_t key = valid ? keys[i] : 0u;
-    const int32_t val = valid ? vals[i] : 0;
+    const bool valid = tile + static_cast<int64_t>(r) * kRsBlock + threadIdx.x < n;
+    uint32_t key = 0u;
+    int32_t val = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)        // (static register indices: no scratch)
+      if ((r & 7) == q) { key = pk[q]; val = pv[q]; }
     const int d = (key >> shift) & 0xff;
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -81,21 +133,31 @@ static __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint3
     if (valid && lane_rank == 0) wcnt[wave][d] = __popcll(peers);
     __syncthreads();
     if (valid) {
-      int off = base[d] + lane_rank;
+      int off = dstart[d] + run[d] + lane_rank;
       for (int w = 0; w < wave; ++w) off += wcnt[w][d];
-      keys_out[off] = key;
-      vals_out[off] = val;
+      skey[off] = key;
+      sval[off] = val;
     }
     __syncthreads();
-    base[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] +
-                         wcnt[3][threadIdx.x];
-    __syncthreads();
+    run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] +
+                        wcnt[3][threadIdx.x];
+  }
+  __syncthreads();
+  // ---- tile order out: pair e of the tile (digit d, e - dstart[d] into the digit's run) -> base[d] + that
+  for (int e = threadIdx.x; e < in_tile; e += kRsBlock) {
+    const uint32_t key = skey[e];
+    const int d = (key >> shift) & 0xff;
+    const int off = base[d] + (e - dstart[d]);
+    keys_out[off] = key;
+    vals_out[off] = sval[e];
   }
 }
 
 // Sorts by the low `num_bits` of the keys.  keys/vals are clobbered; the sorted result is in
 // (*keys_sorted, *vals_sorted), which alias either the inputs or the workspace buffers.
-inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bits, void *ws,
+static std::once_flag g_rs_lds_once;
+
+static inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bits, void *ws,
                             size_t ws_bytes, hipStream_t stream, uint32_t **keys_sorted,
                             int32_t **vals_sorted) {
   *keys_sorted = keys;
@@ -112,6 +174,11 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
     items *= 2;
   const int64_t tile = static_cast<int64_t>(items) * kRsBlock;
   const int nblk = static_cast<int>((n + tile - 1) / tile);
+  const size_t lds = static_cast<size_t>(tile) * 8;       // the scatter kernel's tile staging (<= 128 KB)
+  std::call_once(g_rs_lds_once, [] {      // (per translation unit, like the static kernel it configures)
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        64 * kRsBlock * 8);
+  });
   const int64_t hist_n = static_cast<int64_t>(nblk) * kRsBuckets;
   Workspace a(ws, ws_bytes);
   int32_t *hist = a.take<int32_t>(hist_n + 1);
@@ -131,7 +198,7 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
     if (local_scan) {
       int32_t *t = totals + pass * kRsBuckets;
       rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, t);
-      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, items, hist, t, kout, vout);
+      rs_scatter_kernel<<<nblk, kRsBlock, lds, stream>>>(kin, vin, n, shift, nblk, items, hist, t, kout, vout);
     } else {
       rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, nullptr);
       int32_t *h = hist;
@@ -139,8 +206,8 @@ inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bi
                               [h] __device__(int64_t i, int v) { h[i] = v; }, hist_n, nullptr, sws,
                               sbytes, stream);
       if (rc != SG_OK) return rc;
-      rs_scatter_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, vin, n, shift, nblk, items, hist, nullptr,
-                                                       kout, vout);
+      rs_scatter_kernel<<<nblk, kRsBlock, lds, stream>>>(kin, vin, n, shift, nblk, items, hist, nullptr,
+                                                         kout, vout);
     }
     uint32_t *tk = kin; kin = kout; kout = tk;
     int32_t *tv = vin; vin = vout; vout = tv;

@@ -54,17 +54,28 @@ __device__ __forceinline__ uint64_t lin_key(int b, int x, int y, int z, Shape3 s
   return ((static_cast<uint64_t>(b) * s.s0 + x) * s.s1 + y) * s.s2 + z;
 }
 
-// insert key -> min(value); returns the slot
+// insert key -> min(value); returns the slot.  Test before the atomics: the coarse levels of a
+// pyramid have a handful of sites that EVERY level-0 row inserts into -- thousands of same-address
+// atomics in a row (pyr_insert_kernel 134 us on the bench scene, most of it at the three deepest
+// levels).  A plain load that already shows the key with a value <= ours makes both atomics
+// redundant (values only ever decrease; a stale read just means the atomics run as before).
 __device__ __forceinline__ uint32_t hash_insert_min(uint64_t *keys, int32_t *vals, uint32_t mask,
                                                     uint64_t key, int32_t val) {
   uint32_t s = static_cast<uint32_t>(mix64(key)) & mask;
   while (true) {
-    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[s]),
-                                        static_cast<unsigned long long>(kKeyEmpty),
-                                        static_cast<unsigned long long>(key));
-    if (prev == kKeyEmpty || prev == key) {
-      atomicMin(&vals[s], val);
+    const uint64_t seen = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == key) {
+      if (__hip_atomic_load(&vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > val) atomicMin(&vals[s], val);
       return s;
+    }
+    if (seen == kKeyEmpty) {
+      unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[s]),
+                                          static_cast<unsigned long long>(kKeyEmpty),
+                                          static_cast<unsigned long long>(key));
+      if (prev == kKeyEmpty || prev == key) {
+        atomicMin(&vals[s], val);
+        return s;
+      }
     }
     s = (s + 1) & mask;
   }
@@ -309,9 +320,16 @@ struct PlanSeg {
   uint32_t *tile_mask;
   int32_t *nbr_tiles;
   int rows, K, row_base, tile_base, sb_base, sb_rows;      // sb_rows: rows per super-block of this table (multiple of 32)
+  // radix path: the table's sort key = permuted mask (key_bits wide) | seg_code << key_bits; where its
+  // sorted keys / row ids ended up (set by build_plans after the sorts)
+  int key_bits, seg_code;
+  const uint32_t *key_sorted;
+  const int32_t *val_sorted;
 };
 struct PlanSegs {
   int n, total_rows, total_tiles, total_sbs;
+  int n_big, big_rows;      // the first n_big tables (big_rows rows) are sorted by the device-wide radix sorts:
+  int n_wide, wide_rows;    // the first n_wide of them (27-bit masks) by one sort, the rest (8-bit masks) by another
   PlanSeg s[kPyrMaxSegs];
 };
 
@@ -345,7 +363,7 @@ __global__ void __launch_bounds__(1024) plan_sort_sb_kernel(PlanSegs P, const ui
                                                            uint32_t *__restrict__ tmask) {
   extern __shared__ __attribute__((aligned(16))) uint64_t e[];
   __shared__ int pos[32];
-  int seg = 0;
+  int seg = P.n_big;      // (the tables before that are sorted by the radix sort)
   while (seg + 1 < P.n && static_cast<int>(blockIdx.x) >= P.s[seg + 1].sb_base) ++seg;
   const PlanSeg &S = P.s[seg];
   const int sb = blockIdx.x - S.sb_base;
@@ -496,12 +514,11 @@ __global__ void __launch_bounds__(256) plan_key_all_kernel(PlanSegs P, const int
   const int g = P.s[seg].row_base + j;
   uint32_t key = 0;
   for (uint32_t mm = mask_to_key[g]; mm; mm &= mm - 1) key |= 1u << pos[__ffs(static_cast<int>(mm)) - 1];
-  mask_to_key[g] = key | (static_cast<uint32_t>(seg) << kPlanKeyBits);
+  mask_to_key[g] = key | (static_cast<uint32_t>(P.s[seg].seg_code) << P.s[seg].key_bits);
 }
 
 // 256 sorted rows = 8 tiles per block, OR over each aligned 32-lane group (as plan_tiles_kernel)
-__global__ void __launch_bounds__(256) plan_tiles_all_kernel(PlanSegs P, const uint32_t *__restrict__ key_sorted,
-                                                            const int32_t *__restrict__ bitpos,
+__global__ void __launch_bounds__(256) plan_tiles_all_kernel(PlanSegs P, const int32_t *__restrict__ bitpos,
                                                             uint32_t *__restrict__ tmask) {
   __shared__ int pos[32];
   const int seg = blockIdx.y;
@@ -510,7 +527,7 @@ __global__ void __launch_bounds__(256) plan_tiles_all_kernel(PlanSegs P, const u
   if (threadIdx.x < 32) pos[threadIdx.x] = bitpos[seg * 32 + threadIdx.x];
   __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
-  uint32_t key = j < rows ? key_sorted[P.s[seg].row_base + j] & ((1u << kPlanKeyBits) - 1u) : 0u;
+  uint32_t key = j < rows ? P.s[seg].key_sorted[P.s[seg].row_base + j] & ((1u << P.s[seg].key_bits) - 1u) : 0u;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) key |= __shfl_xor(key, o, 64);
   if ((threadIdx.x & 31) == 0 && j < rows) {
@@ -571,14 +588,15 @@ __global__ void __launch_bounds__(1024) plan_tile_order_all_kernel(PlanSegs P, c
 }
 
 // grid = (tile blocks, segments)
-// (`val_bias`: what is subtracted from val_sorted to get the row inside the table -- the radix path
-// sorts table-global row ids (bias = row_base), the super-block sort writes local ones (0))
-__global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const int32_t *__restrict__ val_sorted,
+// (the radix path sorts table-global row ids -- row_base is subtracted --, the LDS sort writes local ones)
+__global__ void __launch_bounds__(256) plan_emit_all_kernel(PlanSegs P, const int32_t *__restrict__ val_local,
                                                            const uint32_t *__restrict__ tmask,
-                                                           const int32_t *__restrict__ torder, int local_vals) {
+                                                           const int32_t *__restrict__ torder) {
   const int seg = blockIdx.y;
   const int rows = P.s[seg].rows, K = P.s[seg].K, tile_base = P.s[seg].tile_base;
   const int val_base = P.s[seg].row_base;
+  const bool local_vals = seg >= P.n_big;
+  const int32_t *val_sorted = local_vals ? val_local : P.s[seg].val_sorted;
   const int row_base = local_vals ? 0 : val_base;
   const int nt = (rows + 31) / 32, per_tile = 32 * K;
   const int32_t *nbr = P.s[seg].nbr;
@@ -616,6 +634,51 @@ static int plan_order_mode() {
   static const int mode = getenv("SG_PLAN_ORDER") ? atoi(getenv("SG_PLAN_ORDER")) : 0;
   return mode;
 }
+// Lays the tables of P out for build_plans: big tables first (they share the radix sort, their
+// segment index is part of its key), then the ones one workgroup sorts in LDS.
+static void finalize_segs(PlanSegs &P) {
+  const int mode = plan_order_mode();
+  PlanSeg big[kPyrMaxSegs], small[kPyrMaxSegs];
+  int nb = 0, ns = 0;
+  // mode 0: every table goes through a radix sort -- the wide ones (K > 8: 27 mask bits) first, then
+  // the narrow ones (strided / inverse convs: 8 mask bits), each group with its own sort
+  P.n_wide = 0;
+  P.wide_rows = 0;
+  if (mode == 0) {
+    for (int i = 0; i < P.n; ++i)
+      if (P.s[i].K > 8) big[nb++] = P.s[i];
+    P.n_wide = nb;
+    for (int i = 0; i < P.n; ++i)
+      if (P.s[i].K <= 8) big[nb++] = P.s[i];
+    for (int i = 0; i < nb; ++i) {
+      big[i].key_bits = i < P.n_wide ? static_cast<int>(kPlanKeyBits) : 8;
+      big[i].seg_code = i < P.n_wide ? i : i - P.n_wide;
+    }
+  } else {
+    for (int i = 0; i < P.n; ++i) small[ns++] = P.s[i];
+  }
+  int row_base = 0, tile_base = 0, sb_base = 0;
+  P.n_big = nb;
+  for (int i = 0; i < P.n; ++i) {
+    PlanSeg &S = P.s[i];
+    S = i < nb ? big[i] : small[i - nb];
+    S.row_base = row_base;
+    S.tile_base = tile_base;
+    S.sb_base = sb_base;
+    // mode 0: a small table is ONE super-block (= sorted as a whole); modes 1 / 2: plan_sb_rows
+    S.sb_rows = mode == 0 ? (S.rows + 31) / 32 * 32 : plan_sb_rows(S.rows);
+    row_base += S.rows;
+    tile_base += (S.rows + 31) / 32;
+    if (i >= nb) sb_base += (S.rows + S.sb_rows - 1) / S.sb_rows;
+    if (i + 1 == nb) P.big_rows = row_base;
+    if (i + 1 == P.n_wide) P.wide_rows = row_base;
+  }
+  if (nb == 0) P.big_rows = 0;
+  P.total_rows = row_base;
+  P.total_tiles = tile_base;
+  P.total_sbs = sb_base;
+}
+
 static int build_plans(const PlanSegs &P, void *ws2, size_t ws2_bytes, bool zero_freq, hipStream_t stream,
                        const char *who) {
   Workspace wsp(ws2, ws2_bytes);
@@ -633,38 +696,67 @@ static int build_plans(const PlanSegs &P, void *ws2, size_t ws2_bytes, bool zero
     return SG_ERR_WORKSPACE;
   }
   if (zero_freq) hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);
-  int max_rows = 0;
-  for (int i = 0; i < P.n; ++i) max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
+  int max_rows = 0, max_big = 0;
+  for (int i = 0; i < P.n; ++i) {
+    max_rows = P.s[i].rows > max_rows ? P.s[i].rows : max_rows;
+    if (i < P.n_big) max_big = P.s[i].rows > max_big ? P.s[i].rows : max_big;
+  }
   const dim3 grid((max_rows + 255) / 256, P.n);
   plan_mask_all_kernel<<<grid, 256, 0, stream>>>(P, mask, val, freq);
   static const bool raw_env = getenv("SG_PLAN_RAW") != nullptr;     // developer knob: sort by the raw mask
   if (raw_env) hipMemsetAsync(freq, 0, kPyrMaxSegs * 32 * 4, stream);   // equal counts -> identity permutation
   plan_pos_all_kernel<<<P.n, 32, 0, stream>>>(P, freq, bitpos);
   const int mode = plan_order_mode();
-  if (mode == 0) {
-    plan_key_all_kernel<<<grid, 256, 0, stream>>>(P, bitpos, mask);
-    uint32_t *ms;
-    int32_t *vs;
-    int nbits = kPlanKeyBits;
-    for (int n = P.n - 1; n > 0; n >>= 1) ++nbits;
-    int rc = radix_sort_pairs(mask, val, static_cast<int64_t>(R), nbits, rs_ws, rs_bytes, stream, &ms, &vs);
-    if (rc != SG_OK) return rc;
-    plan_tiles_all_kernel<<<grid, 256, 0, stream>>>(P, ms, bitpos, tmask);
-    plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(P, tmask, torder);
-    plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, vs, tmask, torder, 0);
-  } else {
+  // ---- big tables: one device-wide radix sort, the table's index in the key bits above the mask
+  PlanSegs Q = P;      // + where each table's sorted keys / row ids are
+  if (P.n_big > 0) {
+    const dim3 gbig((max_big + 255) / 256, P.n_big);
+    plan_key_all_kernel<<<gbig, 256, 0, stream>>>(P, bitpos, mask);
+    // two sorts, in stream order through the same scratch: the K = 27 tables (27 mask bits + table code:
+    // 4 passes) and the K = 8 tables (8 + code: 2 passes) -- one sort of everything moved the 60 % of
+    // the rows that belong to narrow tables through 4 passes as well
+    struct Group { int first, count, row0, rows, key_bits; } groups[2] = {
+        {0, P.n_wide, 0, P.wide_rows, static_cast<int>(kPlanKeyBits)},
+        {P.n_wide, P.n_big - P.n_wide, P.wide_rows, P.big_rows - P.wide_rows, 8}};
+    for (const Group &g : groups) {
+      if (g.count == 0 || g.rows == 0) continue;
+      int nbits = g.key_bits;
+      for (int n = g.count - 1; n > 0; n >>= 1) ++nbits;
+      uint32_t *ms;
+      int32_t *vs;
+      int rc = radix_sort_pairs(mask + g.row0, val + g.row0, static_cast<int64_t>(g.rows), nbits, rs_ws, rs_bytes,
+                                stream, &ms, &vs);
+      if (rc != SG_OK) return rc;
+      // (a result left in the shared scratch would be overwritten by the next group's sort: both groups
+      // take an even number of passes -- 4 and 2 -- and so end in their own mask / val ranges)
+      if (ms != mask + g.row0) {
+        hipMemcpyAsync(mask + g.row0, ms, static_cast<size_t>(g.rows) * 4, hipMemcpyDeviceToDevice, stream);
+        hipMemcpyAsync(val + g.row0, vs, static_cast<size_t>(g.rows) * 4, hipMemcpyDeviceToDevice, stream);
+      }
+      for (int i = g.first; i < g.first + g.count; ++i) {
+        Q.s[i].key_sorted = mask;      // (tables index with their global row_base)
+        Q.s[i].val_sorted = val;
+      }
+    }
+    plan_tiles_all_kernel<<<gbig, 256, 0, stream>>>(Q, bitpos, tmask);
+  }
+  // ---- modes 1 / 2: every table super-block by super-block, one workgroup per super-block sorts in LDS
+  //      (measured as a replacement of the radix sort for the small tables of mode 0 too: a 16 384-entry
+  //      bitonic sort takes one workgroup 79 us, more than the eight radix launches it would replace)
+  if (P.total_sbs > 0) {
     int max_sb = 64;
-    for (int i = 0; i < P.n; ++i)
+    for (int i = P.n_big; i < P.n; ++i)
       while (max_sb < P.s[i].sb_rows && max_sb < P.s[i].rows) max_sb <<= 1;
     static std::once_flag once;
     std::call_once(once, [] {
       hipFuncSetAttribute(reinterpret_cast<const void *>(plan_sort_sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kSbRowsMax * 8);
     });
-    plan_sort_sb_kernel<<<P.total_sbs, 1024, static_cast<size_t>(max_sb) * 8, stream>>>(P, mask, bitpos, val, tmask);
-    plan_tile_order_xcd_kernel<<<dim3(P.n, 8), 1024, 0, stream>>>(P, tmask, mode, torder);
-    plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(P, val, tmask, torder, 1);
+    plan_sort_sb_kernel<<<P.total_sbs, 1024, static_cast<size_t>(max_sb) * 8, stream>>>(Q, mask, bitpos, val, tmask);
   }
+  if (mode == 0) plan_tile_order_all_kernel<<<P.n, 1024, 0, stream>>>(Q, tmask, torder);
+  else plan_tile_order_xcd_kernel<<<dim3(P.n, 8), 1024, 0, stream>>>(Q, tmask, mode, torder);
+  plan_emit_all_kernel<<<dim3(min((max_rows + 31) / 32, 2048), P.n), 256, 0, stream>>>(Q, val, tmask, torder);
   return check_launch(who);
 }
 
@@ -868,15 +960,10 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
   PyrOut o;
   PlanSegs P;
   P.n = 0;
-  int row_base = 0, tile_base = 0, sb_base = 0;
   auto add_seg = [&](const int32_t *nbr, int rows, int K, const sg_plan_ptrs &pl) {
     PlanSeg &S = P.s[P.n++];
     S.nbr = nbr; S.order = pl.order; S.tile_mask = pl.tile_mask; S.nbr_tiles = pl.nbr_tiles;
-    S.rows = rows; S.K = K; S.row_base = row_base; S.tile_base = tile_base; S.sb_base = sb_base;
-    S.sb_rows = plan_sb_rows(rows);
-    row_base += rows;
-    tile_base += (rows + 31) / 32;
-    sb_base += (rows + S.sb_rows - 1) / S.sb_rows;
+    S.rows = rows; S.K = K;
   };
   Shape3 s{shape_host[0], shape_host[1], shape_host[2]};
   o.pre27[0] = 0;
@@ -906,10 +993,8 @@ int sg_spconv_pyramid_build(const int32_t *indices, int M0, const int32_t *shape
       if (levels[l].rows > 0) add_seg(levels[l].inv, levels[l].rows, 8, levels[l].up);
     }
   }
-  P.total_rows = row_base;
-  P.total_tiles = tile_base;
-  P.total_sbs = sb_base;
   if (P.n == 0) return check_launch("sg_spconv_pyramid_build");
+  finalize_segs(P);
   // (freq sits where build_plans carves it: the fill below clears it together with the child tables)
   int32_t *freq;
   {
@@ -955,10 +1040,8 @@ int sg_spconv_plan(const int32_t *nbr, int M, int K, int32_t *order, uint32_t *t
   if (M == 0) return SG_OK;
   PlanSegs P;
   P.n = 1;
-  P.s[0] = PlanSeg{nbr, order, tile_mask, nbr_tiles, M, K, 0, 0, 0, plan_sb_rows(M)};
-  P.total_rows = M;
-  P.total_tiles = (M + 31) / 32;
-  P.total_sbs = (M + P.s[0].sb_rows - 1) / P.s[0].sb_rows;
+  P.s[0] = PlanSeg{nbr, order, tile_mask, nbr_tiles, M, K, 0, 0, 0, 0, 0, 0, nullptr, nullptr};
+  finalize_segs(P);
   return build_plans(P, ws, ws_bytes, true, as_stream(stream_), "sg_spconv_plan");
 }
 

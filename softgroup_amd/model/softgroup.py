@@ -14,6 +14,7 @@ What differs is how the forward is driven:
     [nProposal, N] int masks (reference softgroup.py:568-603).
 """
 import functools
+import ctypes
 import os
 import threading
 from collections import OrderedDict
@@ -31,6 +32,12 @@ from ..util.lazy import LazyResults, worker as lazy_worker
 from ..spconv.unet_exec import UNetExecutor
 from ..spconv.unet_train import UNetTrainExecutor
 from .blocks import MLP, ResidualBlock, UBlock
+
+
+class _Mlp2(ctypes.Structure):       # sg_mlp2 (include/softgroup_hip.h)
+    _fields_ = [('w1', ctypes.c_void_p), ('b1', ctypes.c_void_p), ('bn_scale', ctypes.c_void_p),
+                ('bn_shift', ctypes.c_void_p), ('w2', ctypes.c_void_p), ('b2', ctypes.c_void_p),
+                ('out', ctypes.c_int)]
 
 
 _scan_local = threading.local()      # per worker thread: its HIP stream
@@ -106,6 +113,7 @@ class SoftGroup(nn.Module):
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
         # train() mode U-Nets as one autograd node each (csrc/unet_train.hip); SG_TRAIN_EXEC=0: the modules
         self.use_train_executor = os.environ.get('SG_TRAIN_EXEC', '1') != '0'
+        self.use_fused_heads = os.environ.get('SG_FUSED_HEADS', '1') != '0'   # devoxelize + point-wise heads + arg-max as one kernel (inference)
         self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
@@ -258,14 +266,15 @@ class SoftGroup(nn.Module):
 
         lvl_fusion = _cfg(tcfg, 'lvl_fusion', False)
         x4_split = _cfg(tcfg, 'x4_split', False)
-        semantic_scores, pt_offsets, output_feats = self.forward_backbone(
+        semantic_scores, pt_offsets, output_feats, semantic_preds = self._forward_backbone(
             x, v2p_map, x4_split=x4_split, lvl_fusion=lvl_fusion)
         if x4_split:
             coords_float = self.merge_4_parts(coords_float)
             semantic_labels = self.merge_4_parts(semantic_labels)
             instance_labels = self.merge_4_parts(instance_labels)
             pt_offset_labels = self.merge_4_parts(pt_offset_labels)
-        semantic_preds = semantic_scores.max(1)[1]
+        if semantic_preds is None:
+            semantic_preds = semantic_scores.max(1)[1]
         tasks = _cfg(tcfg, 'eval_tasks')
         ret = LazyResults(scan_id=scan_ids[0])
         inst = None
@@ -469,16 +478,78 @@ class SoftGroup(nn.Module):
         return ex
 
     def forward_backbone(self, input, input_map, x4_split=False, lvl_fusion=False):
+        return self._forward_backbone(input, input_map, x4_split, lvl_fusion)[:3]
+
+    def _forward_backbone(self, input, input_map, x4_split=False, lvl_fusion=False):
+        """-> (semantic_scores, pt_offsets, output_feats, semantic_preds or None).  In inference the
+        devoxelize gather, both point-wise heads and the arg-max run as ONE kernel (sg_pointwise_heads);
+        training, half precision and anything but the reference's MLP structure take the modules."""
         if x4_split:
             assert not lvl_fusion, 'x4_split not support lvl_fusion'
             output_feats = self.merge_4_parts(self.forward_4_parts(input, input_map))
         else:
             output_feats = self._unet_features(input)
+            heads = self._fused_heads(output_feats)
+            if heads is not None:
+                return self._run_fused_heads(heads, output_feats, None if lvl_fusion else input_map)
             if not lvl_fusion:
                 output_feats = _take_rows(output_feats, input_map)       # devoxelize
         semantic_scores = self.semantic_linear(output_feats)
         pt_offsets = self.offset_linear(output_feats)
-        return semantic_scores, pt_offsets, output_feats
+        return semantic_scores, pt_offsets, output_feats, None
+
+    # ---- point-wise heads as one kernel (csrc/heads.hip)
+    def _fused_heads(self, feats):
+        """the two MLP heads as C descriptors, or None when the fused kernel does not apply"""
+        if not (self.use_fused_heads and feats.is_cuda and feats.dtype == torch.float32
+                and not torch.is_grad_enabled() and feats.shape[1] in (16, 32)):
+            return None
+        from ..spconv import core as spcore
+        out = []
+        for mlp in (self.semantic_linear, self.offset_linear):
+            mods = list(mlp._modules.values())
+            if not (len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.BatchNorm1d)
+                    and isinstance(mods[2], nn.ReLU) and isinstance(mods[3], nn.Linear)):
+                return None
+            l1, bn, _, l2 = mods
+            if (bn.training or bn.running_mean is None or l1.bias is None or l2.bias is None
+                    or l1.weight.shape != (feats.shape[1], feats.shape[1]) or l2.weight.shape[1] != feats.shape[1]):
+                return None
+            ts = (l1.weight, l1.bias, l2.weight, l2.bias)
+            if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts):
+                return None
+            scale, shift = spcore._bn_affine(bn)
+            out.append((l1.weight, l1.bias, scale, shift, l2.weight, l2.bias))
+        if not (out[0][4].shape[0] <= 32 and out[1][4].shape[0] <= 4):
+            return None
+        return out
+
+    def _run_fused_heads(self, heads, voxel_feats, v2p_map):
+        from .. import _lib as L
+        import ctypes as C
+        voxel_feats = voxel_feats.contiguous()
+        dev = voxel_feats.device
+        c = voxel_feats.shape[1]
+        if v2p_map is not None:
+            v2p_map = v2p_map.contiguous()
+            if v2p_map.dtype not in (torch.int32, torch.int64):
+                v2p_map = v2p_map.long()
+        n = voxel_feats.shape[0] if v2p_map is None else v2p_map.numel()
+        descs = []
+        for w1, b1, sc, sh, w2, b2 in heads:
+            d = _Mlp2()
+            d.w1, d.b1, d.bn_scale, d.bn_shift, d.w2, d.b2 = (t.data_ptr() for t in (w1, b1, sc, sh, w2, b2))
+            d.out = w2.shape[0]
+            descs.append(d)
+        sem = torch.empty((n, descs[0].out), dtype=torch.float32, device=dev)
+        off = torch.empty((n, descs[1].out), dtype=torch.float32, device=dev)
+        preds = torch.empty((n, ), dtype=torch.int64, device=dev)
+        out_feats = voxel_feats if v2p_map is None else torch.empty((n, c), dtype=torch.float32, device=dev)
+        L.check(L.lib().sg_pointwise_heads(
+            L.ptr(voxel_feats), L.ptr(v2p_map), int(v2p_map is not None and v2p_map.dtype == torch.int64), n, c,
+            C.byref(descs[0]), C.byref(descs[1]), None if v2p_map is None else L.ptr(out_feats), L.ptr(sem),
+            L.ptr(off), L.ptr(preds), L.stream()), 'sg_pointwise_heads')
+        return sem, off, out_feats, preds
 
     def forward_4_parts(self, x, input_map):
         """S3DIS: the scene arrives as 4 interleaved sub-clouds (batch ids 0..3); run them one at a

@@ -529,3 +529,42 @@ def test_pyramid_inverse_map_equals_the_dense_reference_formulation():
     assert torch.equal(got_idx.long(), exp)
     counts = torch.bincount(exp[:, 0], minlength=n_prop)
     assert torch.equal(got_off.long(), torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]))
+
+
+@pytest.mark.parametrize('channels,n_sem,idx_dtype', [(32, 20, torch.int64), (32, 13, torch.int32), (16, 15, torch.int64),
+                                                      (16, 20, None)])
+def test_pointwise_heads_equal_the_modules(channels, n_sem, idx_dtype):
+    """sg_pointwise_heads (devoxelize gather + semantic_linear + offset_linear + arg-max in one kernel)
+    against the module path of forward_backbone (softgroup/model/softgroup.py:374-376,320): the fp32
+    reference is the same layers evaluated by torch in float64; tolerance 1e-4 of the output scale
+    (north-star tolerance for float features), gathered features and arg-max exact."""
+    from softgroup_amd import synthetic
+    cfg = dict(synthetic.SCANNET_MODEL_CFG, channels=channels, semantic_classes=n_sem, instance_classes=n_sem - 2)
+    cfg['grouping_cfg'] = dict(cfg['grouping_cfg'], class_numpoint_mean=[1.0] * n_sem)
+    model = synthetic.build_model(cfg=cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    M, N = 7000, 9001
+    vox = (torch.randn(M, channels, generator=g) * 2).to(DEV)
+    v2p = None if idx_dtype is None else torch.randint(0, M, (N, ), generator=g).to(DEV).to(idx_dtype)
+    with torch.no_grad():
+        heads = model._fused_heads(vox)
+        assert heads is not None
+        sem, off, feats, preds = model._run_fused_heads(heads, vox, v2p)
+        ref_feats = vox if v2p is None else vox[v2p.long()]
+        assert torch.equal(feats, ref_feats)
+        d = ref_feats.double()
+        ref_sem = model.semantic_linear.double()(d)
+        ref_off = model.offset_linear.double()(d)
+        model.float()
+    assert sem.shape == (ref_feats.shape[0], n_sem) and off.shape == (ref_feats.shape[0], 3)
+    for got, ref in ((sem, ref_sem), (off, ref_off)):
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) <= 1e-4 * max(scale, 1.0)
+    assert torch.equal(preds, sem.max(1)[1])
+    # the model takes the fused path in inference and the modules under autograd, same numbers
+    with torch.no_grad():
+        model.use_fused_heads = False
+        m_sem = model.semantic_linear(ref_feats)
+        m_off = model.offset_linear(ref_feats)
+    assert float((m_sem - sem).abs().max()) <= 1e-4 * max(float(m_sem.abs().max()), 1.0)
+    assert float((m_off - off).abs().max()) <= 1e-4 * max(float(m_off.abs().max()), 1.0)

@@ -1,0 +1,38 @@
+"""N whole scans (model(batch), one at a time, results in line) of the bench scene and nothing else: the
+workload for rocprofv3 traces of ONE scan (tools/scan_sequence.py post-processes the kernel trace).
+Usage (GPU box): python tools/scan_only.py [scans] [points] [config: scannet|stpls3d_pp|kitti]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from softgroup_amd import synthetic  # noqa: E402
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
+    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=n)
+    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    model = synthetic.build_model(seed=0)
+    model.async_results = os.environ.get('SCAN_ASYNC', '0') == '1'
+    with torch.no_grad():
+        for _ in range(3):
+            dict(model(batch))
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = dict(model(batch))
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    print(f'{reps} scans, latency ms min {ts[0]:.3f} median {ts[len(ts) // 2]:.3f} max {ts[-1]:.3f}; '
+          f'{len(r["pred_instances"])} instances')
+
+
+if __name__ == '__main__':
+    main()
