@@ -281,6 +281,16 @@ __global__ void __launch_bounds__(256) bfs_edge_rec_kernel(const int32_t *__rest
   }
 }
 
+// LDS-DMA of 4 bytes per active lane to LDS[lds_dst + lane * 4]: used as a PREFETCH (the data is never
+// read).  asm on purpose, like the conv kernel's metadata DMA: outside the compiler's vmcnt bookkeeping
+// an older untracked load can only make a later counted wait longer, never wrong.
+__device__ __forceinline__ void lds_prefetch_b32(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // ---------------------------------------------------------------- D. ordered emission
 // workgroup-wide exclusive scan of one int per thread (kEmitThreads threads)
 __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
@@ -334,7 +344,11 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
   __shared__ unsigned short ebuf[kE2];     // fast level, per edge: target slot
   __shared__ int e_st[kE2], e_g[kE2];      //   target list start, global edge index
   __shared__ unsigned short e_ln[kE2];     //   target list length
+  __shared__ int pf_sink[kEmitThreads];    // landing zone of the edge-record prefetches (never read)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned pf_dst = __builtin_amdgcn_readfirstlane(
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>(pf_sink + wave * 64)));
+  static_assert(sizeof(int2) == 8, "edge records are 8 bytes: 16 per 128-byte line");
   for (int c = blockIdx.x; c < n_cluster; c += gridDim.x) {
     const int seed = seeds[c];
     const int off = cluster_offsets[c];
@@ -420,7 +434,22 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
           e_ln[e] = static_cast<unsigned short>(r.x >> 16);
           if (slot != 0xffffu) {
             if (own_in_lds) {
-              if (own_lds[slot] > e) atomicMin(&own_lds[slot], e);
+              const int cur_owner = own_lds[slot];
+              if (cur_owner > e) atomicMin(&own_lds[slot], e);
+              // A level is ONE dependent memory round trip (the edge records of its frontier), and
+              // those records were written by another kernel on all 8 XCDs: ~1 us from the fabric.
+              // Every still-unvisited target of this level is a candidate frontier node of the next:
+              // request the lines of ITS edge records now (LDS-DMA into a sink: no register, nothing
+              // waits for it), so that the next level finds them in this XCD's L2 / this CU's L1.
+              if (cur_owner >= 0) {
+                const int tl = r.x >> 16;
+                const char *first = reinterpret_cast<const char *>(erec + r.y);
+                const char *last = reinterpret_cast<const char *>(erec + r.y + max(tl, 1) - 1);
+                const uintptr_t l0 = reinterpret_cast<uintptr_t>(first) & ~static_cast<uintptr_t>(127);
+                const int nlines = static_cast<int>(((reinterpret_cast<uintptr_t>(last) & ~static_cast<uintptr_t>(127)) - l0) >> 7) + 1;
+                for (int j = 0; j < 4; ++j)
+                  if (j < nlines) lds_prefetch_b32(reinterpret_cast<const void *>(l0 + 128u * j), pf_dst);
+              }
             } else {          // cluster larger than the LDS claim array: claims by point id in global
               const int v = idx[g];
               if (SG_LD(&owner_g[v]) > e) atomicMin(&owner_g[v], e);

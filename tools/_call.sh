@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-echo "A default";            python tools/scan_only.py 30 2>&1 | tail -1
-echo "B SG_EARLY_COPY=0";    SG_EARLY_COPY=0 python tools/scan_only.py 30 2>&1 | tail -1
-echo "C HSA_ENABLE_SDMA=1";  HSA_ENABLE_SDMA=1 python tools/scan_only.py 30 2>&1 | tail -1
-echo "D HSA_ENABLE_SDMA=0";  HSA_ENABLE_SDMA=0 python tools/scan_only.py 30 2>&1 | tail -1
-echo "E SDMA=1 EARLY=0";     HSA_ENABLE_SDMA=1 SG_EARLY_COPY=0 python tools/scan_only.py 30 2>&1 | tail -1
-echo "A default";            python tools/scan_only.py 30 2>&1 | tail -1
+python -m pytest tests/test_spconv_gpu.py -x -q 2>&1 | tail -2
+python tools/conv_exec_layers.py 150000 10 > gpurun_out/c13_layers.txt 2>&1; tail -1 gpurun_out/c13_layers.txt | cut -c1-150
+python tools/scan_only.py 30 2>&1 | tail -1
