@@ -73,24 +73,30 @@ __device__ __forceinline__ int mask_prefix(uint64_t m) {
                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide integer reductions / scan on the DPP path (row_shr within rows of 16 lanes, row_bcast:15 /
+// row_bcast:31 across them): six plain VALU operations, ~100 cycles.  The __shfl_xor / __shfl_up forms
+// these replace compile to ds_bpermute -- a trip through the LDS crossbar per step, ~600 cycles per
+// reduction -- which was most of the per-instance time of the single-wave panoptic walk.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_or_zero(int v) {      // lanes without a source read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// inclusive scan across the wave
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_or_zero<0x111>(v);                 // row_shr:1
+  v += dpp_or_zero<0x112>(v);                 // row_shr:2
+  v += dpp_or_zero<0x114>(v);                 // row_shr:4
+  v += dpp_or_zero<0x118>(v);                 // row_shr:8
+  v += dpp_or_zero<0x142, 0xa>(v);            // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xc>(v);            // row_bcast:31 into rows 2 and 3
   return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+  return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
 }
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
-}
-// inclusive scan across the wave
-__device__ __forceinline__ int wave_incl_scan(int v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(v, o, 64);
-    if (l >= o) v += t;
-  }
   return v;
 }
 

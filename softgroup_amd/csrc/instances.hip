@@ -19,6 +19,10 @@
 //                        run of instance k -- exactly what sg_rle_format_host turns into the
 //                        reference's "start len start len ..." strings.
 // HBM-bound streaming work: S*nc score reads + n_kept*N/8 bitmap bytes (written once, read 3x).
+#include <stdlib.h>
+
+#include <mutex>
+
 #include "common.h"
 #include "scan.h"
 
@@ -197,125 +201,294 @@ __global__ void instance_runs_total_kernel(const int32_t *__restrict__ total, in
 // rows of the kept instances: in the given order (descending confidence, decided by the caller like
 // the reference's np.argsort) an instance is skipped when more than skip_iou of its points are
 // already taken (intersect / (npoint + 1e-5) in double, like numpy), otherwise its free points get
-// the next panoptic id and the instance's class.  The order makes it a sequential scan over the
-// instances: ONE workgroup walks them, every thread owning a fixed set of 32-point words of the
-// `taken` row (no hazards between threads; two block reductions per instance).  The reference
-// decodes every RLE string to a dense N-vector on the host (and round 3 re-parsed the RLE text):
-// 21 ms per LiDAR sweep with ~1000 instances, profiles/r04_kitti_host_profile.txt.
-constexpr int kFuseThreads = 1024;
-constexpr int kFuseWpt = 8;          // 32-point words a thread owns in the register path (N <= 262 144 points)
-__global__ void __launch_bounds__(kFuseThreads) panoptic_fusion_kernel(
-    const uint32_t *__restrict__ bits, int words, int n_inst, const int32_t *__restrict__ order,
-    const int32_t *__restrict__ label_id, const int64_t *__restrict__ semantic_preds, int n_points,
-    int cls_offset, double skip_iou, int semantic_classes, int thing_class_min, uint32_t *__restrict__ taken,
-    uint32_t *__restrict__ ids, int32_t *__restrict__ label_of_id, uint32_t *__restrict__ out) {
-  __shared__ int red[2][2][kFuseThreads / 64];          // [parity][inter | count][wave]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < n_points; i += kFuseThreads) ids[i] = 0u;
-  int next_id = 1;
-  if (words <= kFuseWpt * kFuseThreads) {
-    // ---- register path: thread t owns words t, t + 1024, ... of the `taken` row for the whole walk;
-    //      the next instance's row is on its way while this one is decided (the order is known up
-    //      front), so an instance costs one block reduction, not two memory round trips
-    uint32_t tk[kFuseWpt], rw[kFuseWpt], nx[kFuseWpt];
-    auto fetch = [&](int r, uint32_t (&dst)[kFuseWpt]) {
+// the next panoptic id and the instance's class.  The order makes it a sequential walk over the
+// instances.  The reference decodes every RLE string to a dense N-vector on the host (21 ms per
+// LiDAR sweep with ~1000 instances); round 4 walked the dense bit rows with one workgroup and a
+// barrier per instance (2.2 ms: 1088 instances x 15 KB of mostly zero words).  A mask is SPARSE --
+// ~100 points of 120 000 -- so:
+//   1. panoptic_summary_kernel (whole chip): per instance one bit per 32-point word, "word != 0";
+//   2. panoptic_walk_kernel: ONE WAVE walks the instances; the instance's non-zero words are dealt
+//      to the lanes from a list in LDS, the `taken` row lives in LDS, the two counts meet by DPP
+//      reductions -- no barrier; a SECOND wave runs a few instances ahead and touches the lines the
+//      walker is about to read, so the walker waits for cache hits, not for the fabric;
+//   3. panoptic_assign_kernel (whole chip): every point takes the id of the first pasted instance that
+//      holds it (atomicMin over the visiting rank) -- the walker itself issues NO global store: stores
+//      share the loads' in-order counter, the next instance's first load would wait for them;
+//   4. panoptic_encode_kernel (whole chip): class | id << 16.
+constexpr int kFuseSumPerLane = 16;                       // summary words a lane owns: rows of <= 32 768 words
+constexpr int kFuseTakenWords = kFuseSumPerLane * 64 * 32;      // = 32 768 words of `taken` in LDS (128 KB, 1 M points)
+constexpr int kFuseListCap = 8192;                           // non-zero words of one instance kept as a list (16 KB)
+
+__global__ void __launch_bounds__(256) panoptic_summary_kernel(const uint32_t *__restrict__ bits, int words,
+                                                              int sum_words, int n_inst,
+                                                              uint32_t *__restrict__ summary) {
+  // one thread per (instance, word): the wave's 64 "non-zero" flags are two summary words
+  const int64_t padded = static_cast<int64_t>(sum_words) * 32;
+  const int64_t total = static_cast<int64_t>(n_inst) * padded;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int64_t k = t / padded;
+    const int w = static_cast<int>(t - k * padded);
+    const uint32_t v = w < words ? bits[k * words + w] : 0u;
+    const uint64_t bal = __ballot(v != 0u);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0) summary[k * sum_words + (w >> 5)] = static_cast<uint32_t>(bal >> (lane & 32));
+  }
+}
+
+template <int SPL>      // summary words per lane (1, 2, 4, 8, 16)
+__global__ void __launch_bounds__(128) panoptic_walk_kernel(const uint32_t *__restrict__ bits, int words, int sum_words,
+                                                           const uint32_t *__restrict__ summary, int n_inst,
+                                                           const int32_t *__restrict__ order,
+                                                           const int32_t *__restrict__ label_id, int cls_offset,
+                                                           double skip_iou, uint32_t *__restrict__ id_of_rank,
+                                                           int32_t *__restrict__ label_of_id) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t taken[];      // [words rounded up]
+  __shared__ unsigned short list[kFuseListCap];                         // non-zero words of the instance at hand
+  __shared__ uint32_t pasted[2048];                                     // one bit per visited instance (n_inst < 65 536)
+  __shared__ int progress;                                              // instance the walker is at
+  const int lane = threadIdx.x & 63;
+  const int padded = sum_words * 32;
+  for (int w = threadIdx.x; w < padded; w += 128) taken[w] = 0u;
+  for (int w = threadIdx.x; w < 2048; w += 128) pasted[w] = 0u;
+  if (threadIdx.x == 0) progress = 0;
+  __syncthreads();
+  auto fetch_summary = [&](int r, uint32_t (&dst)[SPL]) {
+    const uint32_t *row = summary + static_cast<int64_t>(order[r]) * sum_words;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const int c = lane + 64 * j;
+      dst[j] = c < sum_words ? row[c] : 0u;
+    }
+  };
+  if (threadIdx.x >= 64) {
+    // ---- wave 1, the PREFETCHER: it touches what the walker will read -- summary words and the
+    //      128-byte line of every non-zero 32-word group of the next instances -- a bounded distance
+    //      ahead.  Loads of one wave return in order, so a wave that waits for an L1 hit cannot have a
+    //      fabric round trip outstanding without waiting for that too: the slow loads need a wave of
+    //      their own.  Nothing is handed over but cache lines (the CU's L1, the XCD's L2).
+    constexpr int kAhead = 12;
+    uint32_t sink = 0;
+    for (int r = 0; r < n_inst; ++r) {
+      while (r > __hip_atomic_load(&progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kAhead)
+        __builtin_amdgcn_s_sleep(8);
+      uint32_t sm[SPL];
+      fetch_summary(r, sm);
       const uint32_t *row = bits + static_cast<int64_t>(order[r]) * words;
 #pragma unroll
-      for (int j = 0; j < kFuseWpt; ++j) {
-        const int w = threadIdx.x + j * kFuseThreads;
-        dst[j] = w < words ? row[w] : 0u;
-      }
-    };
-#pragma unroll
-    for (int j = 0; j < kFuseWpt; ++j) tk[j] = nx[j] = 0u;
-    if (n_inst > 0) fetch(0, nx);
-    for (int r = 0; r < n_inst; ++r) {
-#pragma unroll
-      for (int j = 0; j < kFuseWpt; ++j) rw[j] = nx[j];
-      if (r + 1 < n_inst) fetch(r + 1, nx);
-      int inter = 0, cnt = 0;
-#pragma unroll
-      for (int j = 0; j < kFuseWpt; ++j) {
-        cnt += __popc(rw[j]);
-        inter += __popc(rw[j] & tk[j]);
-      }
-      inter = wave_sum(inter);
-      cnt = wave_sum(cnt);
-      const int par = r & 1;                           // double-buffered: one barrier per instance
-      if (lane == 0) {
-        red[par][0][wave] = inter;
-        red[par][1][wave] = cnt;
-      }
-      __syncthreads();
-      long long ti = 0, tc = 0;
-#pragma unroll
-      for (int v = 0; v < kFuseThreads / 64; ++v) {
-        ti += red[par][0][v];
-        tc += red[par][1][v];
-      }
-      const bool paste_it = !(static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou);   // every thread, same numbers
-      if (paste_it) {
-        if (threadIdx.x == 0) label_of_id[next_id] = label_id[order[r]] + cls_offset;
-#pragma unroll
-        for (int j = 0; j < kFuseWpt; ++j) {
-          uint32_t paste = rw[j] & ~tk[j];
-          tk[j] |= paste;
-          const int w = threadIdx.x + j * kFuseThreads;
-          while (paste) {
-            const int bb = __ffs(static_cast<int>(paste)) - 1;
-            paste &= paste - 1;
-            ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
-          }
+      for (int j = 0; j < SPL; ++j)
+        if (sm[j]) {
+          const int w0 = (lane + 64 * j) * 32;
+          sink ^= row[w0 + __ffs(static_cast<int>(sm[j])) - 1];
+          sink ^= row[min(w0 + 31 - __clz(static_cast<int>(sm[j])) + 0, words - 1)];      // (a group may straddle two lines)
         }
-        ++next_id;
-      }
     }
+    asm volatile("" ::"v"(sink));
   } else {
-    for (int w = threadIdx.x; w < words; w += kFuseThreads) taken[w] = 0u;
-    for (int r = 0; r < n_inst; ++r) {
-      const int k = order[r];
-      const uint32_t *row = bits + static_cast<int64_t>(k) * words;
-      int inter = 0, cnt = 0;
-      for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+  // (`order` 64 entries at a time in a register per lane, read back by v_readlane: a load of order[r]
+  // in every iteration would be one more dependent round trip per instance)
+  // ---- wave 0, the WALKER: loads only -- a store in flight (the pasted points' ids, as the first
+  //      version wrote them here) would be waited for by the next instance's first load, a fabric
+  //      round trip per instance; the ids are assigned by panoptic_assign_kernel from the decisions
+  uint32_t s_cur[SPL], s_nxt[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) s_cur[j] = s_nxt[j] = 0u;
+  int ord_cur = lane < n_inst ? order[lane] : 0;            // order[64 b + lane] of the block at hand
+  int ord_nxt = 64 + lane < n_inst ? order[64 + lane] : 0;  // ... and of the next block
+  auto summary_of = [&](int k, uint32_t (&dst)[SPL]) {
+    const uint32_t *row = summary + static_cast<int64_t>(k) * sum_words;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      const int c = lane + 64 * j;
+      dst[j] = c < sum_words ? row[c] : 0u;
+    }
+  };
+  if (n_inst > 0) summary_of(__builtin_amdgcn_readlane(ord_cur, 0), s_cur);
+  // (Tried: requesting an instance's words one instance ahead -- a software pipeline over the walk, 1 or
+  // 4 words per lane in registers: 959 / 1103 us against 827 us for this loop on the KITTI-like sweep.
+  // What an instance costs is its instruction stream -- list build, 2 DPP reductions, LDS traffic --
+  // not its one round trip to an L1 / L2 that the prefetcher wave keeps warm.)
+  for (int r = 0; r < n_inst; ++r) {
+    if (lane == 0) __hip_atomic_store(&progress, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int k = __builtin_amdgcn_readlane(ord_cur, r & 63);
+    if ((r & 63) == 63) {         // uniform: next block of the order
+      ord_cur = ord_nxt;
+      ord_nxt = r + 65 + lane < n_inst ? order[r + 65 + lane] : 0;
+    }
+    if (r + 1 < n_inst) summary_of(__builtin_amdgcn_readlane(ord_cur, (r + 1) & 63), s_nxt);
+    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
+    // ---- the instance's non-zero words as a compact list in LDS (lane l's words behind those of the
+    //      lanes before it), then handed out round-robin: a mask that is one contiguous run of the
+    //      cloud puts all its words into ONE lane's summary word -- walked lane by lane that is up to
+    //      32 dependent loads; from the list every lane gets T / 64 of them
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) mine += __popc(s_cur[j]);
+    const int before = wave_incl_scan(mine) - mine;
+    const int T = __builtin_amdgcn_readlane(before + mine, 63);
+    int inter = 0, cnt = 0, w_first = -1;
+    uint32_t bw_first = 0u;
+    const bool listed = T <= kFuseListCap;      // uniform
+    if (listed) {
+      int at = before;
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        const int w0 = (lane + 64 * j) * 32;
+        for (uint32_t m = s_cur[j]; m; m &= m - 1) list[at++] = static_cast<unsigned short>(w0 + __ffs(static_cast<int>(m)) - 1);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): one wave, LDS in program order -- no barrier
+      for (int i = lane; i < T; i += 64) {
+        const int w = list[i];
         const uint32_t bw = row[w];
         cnt += __popc(bw);
         inter += __popc(bw & taken[w]);
+        if (i == lane) { w_first = w; bw_first = bw; }      // (kept for the paste: most masks are <= 64 words)
       }
-      inter = wave_sum(inter);
-      cnt = wave_sum(cnt);
-      const int par = r & 1;
-      if (lane == 0) {
-        red[par][0][wave] = inter;
-        red[par][1][wave] = cnt;
-      }
-      __syncthreads();
-      long long ti = 0, tc = 0;
-      for (int v = 0; v < kFuseThreads / 64; ++v) {
-        ti += red[par][0][v];
-        tc += red[par][1][v];
-      }
-      const bool paste_it = !(static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou);
-      if (paste_it) {
-        if (threadIdx.x == 0) label_of_id[next_id] = label_id[k] + cls_offset;
-        for (int w = threadIdx.x; w < words; w += kFuseThreads) {
-          uint32_t paste = row[w] & ~taken[w];
-          if (paste == 0u) continue;
-          taken[w] |= paste;
-          while (paste) {
-            const int bb = __ffs(static_cast<int>(paste)) - 1;
-            paste &= paste - 1;
-            ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
-          }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        const int w0 = (lane + 64 * j) * 32;
+        for (uint32_t m = s_cur[j]; m; m &= m - 1) {
+          const int w = w0 + __ffs(static_cast<int>(m)) - 1;
+          const uint32_t bw = row[w];
+          cnt += __popc(bw);
+          inter += __popc(bw & taken[w]);
         }
-        ++next_id;
       }
     }
+    const long long ti = wave_sum(inter), tc = wave_sum(cnt);
+    // intersect / (npoint + 1e-5) > skip_iou as numpy evaluates it (double).  The quotient can only
+    // round across the threshold when ti - skip_iou * (tc + 1e-5) is within a few ulps of zero: away
+    // from that (always, in practice -- the 1e-5 makes exact ties impossible) the sign of the
+    // difference decides and the ~40-instruction double division stays off the chain.
+    const double den = static_cast<double>(tc) + 1e-5;
+    const double diff = static_cast<double>(ti) - skip_iou * den;
+    const bool paste_it = fabs(diff) > 1e-9 * den ? !(diff > 0.0)
+                                                  : !(static_cast<double>(ti) / den > skip_iou);   // every lane, same numbers
+    if (paste_it) {
+      if (lane == 0) pasted[r >> 5] |= 1u << (r & 31);
+      auto paste_word = [&](int w) { taken[w] |= row[w]; };      // (an L1 hit: read a moment ago)
+      if (listed) {
+        if (w_first >= 0) taken[w_first] |= bw_first;
+        for (int i = lane + 64; i < T; i += 64) paste_word(list[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+          const int w0 = (lane + 64 * j) * 32;
+          for (uint32_t m = s_cur[j]; m; m &= m - 1) paste_word(w0 + __ffs(static_cast<int>(m)) - 1);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) s_cur[j] = s_nxt[j];
   }
-  __threadfence_block();
+  if (lane == 0) __hip_atomic_store(&progress, n_inst + (1 << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   __syncthreads();
-  // encode: class | id << 16; thing classes that nobody claimed -> ignore (semantic_classes)
-  for (int i = threadIdx.x; i < n_points; i += kFuseThreads) {
-    const uint32_t id = ids[i];
+  // ---- decisions -> panoptic ids: the r-th visited instance, if pasted, gets 1 + (pasted before it)
+  if (threadIdx.x < 64) {
+    int base = 0;
+    for (int c0 = 0; c0 * 32 < n_inst; c0 += 64) {
+      const int c = c0 + lane;
+      const uint32_t bitsw = c < 2048 ? pasted[c] : 0u;
+      const int pc = __popc(bitsw);
+      const int incl = wave_incl_scan(pc);
+      int id = base + incl - pc;
+      for (int b = 0; b < 32; ++b) {
+        const int r = c * 32 + b;
+        if (r >= n_inst) break;
+        const bool on = (bitsw >> b) & 1u;
+        if (on) {
+          ++id;
+          label_of_id[id] = label_id[order[r]] + cls_offset;
+        }
+        id_of_rank[r] = on ? static_cast<uint32_t>(id) : 0u;
+      }
+      base += __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+}
+
+// the pasted instances' points: a point takes the id of the FIRST pasted instance (in visiting order)
+// whose mask holds it -- what the sequential paste of the reference leaves behind
+__global__ void __launch_bounds__(256) panoptic_assign_kernel(const uint32_t *__restrict__ bits, int words, int sum_words,
+                                                             const uint32_t *__restrict__ summary, int n_inst,
+                                                             const int32_t *__restrict__ order,
+                                                             const uint32_t *__restrict__ id_of_rank,
+                                                             uint32_t *__restrict__ first) {
+  const int64_t total = static_cast<int64_t>(n_inst) * sum_words;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int r = static_cast<int>(t / sum_words), c = static_cast<int>(t - static_cast<int64_t>(r) * sum_words);
+    if (id_of_rank[r] == 0u) continue;
+    const int k = order[r];
+    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
+    for (uint32_t m = summary[static_cast<int64_t>(k) * sum_words + c]; m; m &= m - 1) {
+      const int w = c * 32 + __ffs(static_cast<int>(m)) - 1;
+      for (uint32_t bw = row[w]; bw; bw &= bw - 1) atomicMin(&first[w * 32 + __ffs(static_cast<int>(bw)) - 1], static_cast<uint32_t>(r));
+    }
+  }
+}
+
+// rows too long for the LDS `taken` row (> 1 M points): the dense walk of round 4, one workgroup
+constexpr int kFuseThreads = 1024;
+__global__ void __launch_bounds__(kFuseThreads) panoptic_walk_dense_kernel(
+    const uint32_t *__restrict__ bits, int words, int n_inst, const int32_t *__restrict__ order,
+    const int32_t *__restrict__ label_id, int cls_offset, double skip_iou, uint32_t *__restrict__ taken,
+    uint32_t *__restrict__ ids, int32_t *__restrict__ label_of_id) {
+  __shared__ int red[2][2][kFuseThreads / 64];          // [parity][inter | count][wave]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int next_id = 1;
+  for (int w = threadIdx.x; w < words; w += kFuseThreads) taken[w] = 0u;
+  for (int r = 0; r < n_inst; ++r) {
+    const int k = order[r];
+    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
+    int inter = 0, cnt = 0;
+    for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+      const uint32_t bw = row[w];
+      cnt += __popc(bw);
+      inter += __popc(bw & taken[w]);
+    }
+    inter = wave_sum(inter);
+    cnt = wave_sum(cnt);
+    const int par = r & 1;
+    if (lane == 0) {
+      red[par][0][wave] = inter;
+      red[par][1][wave] = cnt;
+    }
+    __syncthreads();
+    long long ti = 0, tc = 0;
+    for (int v = 0; v < kFuseThreads / 64; ++v) {
+      ti += red[par][0][v];
+      tc += red[par][1][v];
+    }
+    const bool paste_it = !(static_cast<double>(ti) / (static_cast<double>(tc) + 1e-5) > skip_iou);
+    if (paste_it) {
+      if (threadIdx.x == 0) label_of_id[next_id] = label_id[k] + cls_offset;
+      for (int w = threadIdx.x; w < words; w += kFuseThreads) {
+        uint32_t paste = row[w] & ~taken[w];
+        if (paste == 0u) continue;
+        taken[w] |= paste;
+        while (paste) {
+          const int bb = __ffs(static_cast<int>(paste)) - 1;
+          paste &= paste - 1;
+          ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
+        }
+      }
+
+    }
+  }
+}
+
+// encode: class | id << 16; thing classes that nobody claimed -> ignore (semantic_classes)
+// (`id_of_rank` != null: ids[] holds the rank of the first pasted instance of the point, 0xffffffff = none)
+__global__ void __launch_bounds__(256) panoptic_encode_kernel(const uint32_t *__restrict__ ids,
+                                                             const uint32_t *__restrict__ id_of_rank,
+                                                             const int32_t *__restrict__ label_of_id,
+                                                             const int64_t *__restrict__ semantic_preds, int n_points,
+                                                             int semantic_classes, int thing_class_min,
+                                                             uint32_t *__restrict__ out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_points; i += gridDim.x * 256) {
+    uint32_t id = ids[i];
+    if (id_of_rank) id = id == 0xffffffffu ? 0u : id_of_rank[id];
     const uint32_t cls = id ? static_cast<uint32_t>(label_of_id[id]) : static_cast<uint32_t>(semantic_preds[i]);
     uint32_t v = (cls & 0xFFFFu) | (id << 16);
     if (cls >= static_cast<uint32_t>(thing_class_min) && id == 0u) v = static_cast<uint32_t>(semantic_classes);
@@ -433,8 +606,12 @@ int sg_rle_format_device(const int32_t *starts, const int32_t *ends, const int64
   return check_launch("sg_rle_format_device");
 }
 
+static int fuse_summary_words(int n_points) { return static_cast<int>((instance_words(n_points) + 31) / 32); }
+
 size_t sg_panoptic_fusion_workspace_bytes(int n_inst, int n_points) {
   return align_up(static_cast<size_t>(instance_words(n_points)) * 4) + align_up(static_cast<size_t>(n_points > 0 ? n_points : 1) * 4) +
+         align_up((static_cast<size_t>(n_inst) + 2) * 4) +
+         align_up(static_cast<size_t>(n_inst > 0 ? n_inst : 1) * fuse_summary_words(n_points) * 4) +
          align_up((static_cast<size_t>(n_inst) + 2) * 4) + 256;
 }
 
@@ -448,14 +625,47 @@ int sg_panoptic_fusion(const uint32_t *bits, int n_inst, int n_points, const int
   SG_REQUIRE(ws != nullptr && ws_bytes >= sg_panoptic_fusion_workspace_bytes(n_inst, n_points),
              "sg_panoptic_fusion: workspace too small");
   if (n_points == 0) return SG_OK;
+  hipStream_t stream = as_stream(stream_);
   Workspace a(ws, ws_bytes);
   const int words = static_cast<int>(instance_words(n_points));
+  const int sum_words = fuse_summary_words(n_points);
   uint32_t *taken = a.take<uint32_t>(words);
   uint32_t *ids = a.take<uint32_t>(n_points);
   int32_t *label_of_id = a.take<int32_t>(static_cast<size_t>(n_inst) + 2);
-  panoptic_fusion_kernel<<<1, kFuseThreads, 0, as_stream(stream_)>>>(
-      bits, words, n_inst, order, label_id, semantic_preds, n_points, cls_offset, skip_iou, semantic_classes,
-      thing_class_min, taken, ids, label_of_id, out);
+  uint32_t *summary = a.take<uint32_t>(static_cast<size_t>(n_inst > 0 ? n_inst : 1) * sum_words);
+  uint32_t *id_of_rank = a.take<uint32_t>(static_cast<size_t>(n_inst) + 2);
+  static const bool dense_env = getenv("SG_PANOPTIC_DENSE") != nullptr;      // developer A/B knob: round 4's walk
+  const bool sparse = n_inst > 0 && words <= kFuseTakenWords && !dense_env;
+  hipMemsetAsync(ids, sparse ? 0xff : 0, static_cast<size_t>(n_points) * 4, stream);
+  if (sparse) {
+    panoptic_summary_kernel<<<grid_for(static_cast<int64_t>(n_inst) * sum_words * 32, 256, 4096), 256, 0, stream>>>(
+        bits, words, sum_words, n_inst, summary);
+    const size_t lds = static_cast<size_t>(sum_words) * 32 * 4;
+    const int spl = (sum_words + 63) / 64;
+#define SG_WALK(SPL)                                                                                                  \
+  do {                                                                                                                \
+    static std::once_flag once;                                                                                       \
+    std::call_once(once, [] {                                                                                         \
+      hipFuncSetAttribute(reinterpret_cast<const void *>(panoptic_walk_kernel<SPL>),                                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (kFuseTakenWords + 64) * 4);                    \
+    });                                                                                                               \
+    panoptic_walk_kernel<SPL><<<1, 128, lds, stream>>>(bits, words, sum_words, summary, n_inst, order, label_id,      \
+                                                      cls_offset, skip_iou, id_of_rank, label_of_id);                \
+  } while (0)
+    if (spl <= 1) SG_WALK(1);
+    else if (spl <= 2) SG_WALK(2);
+    else if (spl <= 4) SG_WALK(4);
+    else if (spl <= 8) SG_WALK(8);
+    else SG_WALK(16);
+#undef SG_WALK
+    panoptic_assign_kernel<<<grid_for(static_cast<int64_t>(n_inst) * sum_words, 256, 4096), 256, 0, stream>>>(
+        bits, words, sum_words, summary, n_inst, order, id_of_rank, ids);
+  } else if (n_inst > 0) {
+    panoptic_walk_dense_kernel<<<1, kFuseThreads, 0, stream>>>(bits, words, n_inst, order, label_id, cls_offset,
+                                                              skip_iou, taken, ids, label_of_id);
+  }
+  panoptic_encode_kernel<<<grid_for(n_points, 256, 2048), 256, 0, stream>>>(ids, sparse ? id_of_rank : nullptr, label_of_id, semantic_preds, n_points,
+                                                                          semantic_classes, thing_class_min, out);
   return check_launch("sg_panoptic_fusion");
 }
 

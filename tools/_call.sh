@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_spconv_gpu.py -x -q 2>&1 | tail -2
-python tools/conv_exec_layers.py 150000 10 > gpurun_out/c13_layers.txt 2>&1; tail -1 gpurun_out/c13_layers.txt | cut -c1-150
-python tools/scan_only.py 30 2>&1 | tail -1
+python -m pytest tests/test_native_scan_gpu.py tests/test_dropin_gpu.py tests/test_variants_gpu.py tests/test_ops_gpu.py -x -q > gpurun_out/c16_pytest.log 2>&1
+grep -E "passed|failed|error" gpurun_out/c16_pytest.log | tail -3

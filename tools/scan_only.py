@@ -14,10 +14,24 @@ from softgroup_amd import synthetic  # noqa: E402
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
-    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=n)
-    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    which = sys.argv[3] if len(sys.argv) > 3 else 'scannet'
+    import copy
+    import numpy as np
+    if which == 'stpls3d_pp':         # BASELINE config 4 (bench.py config_legs)
+        xyz, rgb, inst = synthetic.scene_s2(seed=1, n=n)
+        xyz = (xyz * np.float32(40)).astype(np.float32)
+        batch = synthetic.make_batch(xyz, rgb, scale=3, instance_labels=inst)
+        cfg = copy.deepcopy(synthetic.STPLS3D_PP_MODEL_CFG)
+    elif which == 'kitti':            # BASELINE config 5
+        xyz, rgb, inst = synthetic.scene_lidar(seed=3, n=min(n, 120000))
+        batch = synthetic.make_batch(xyz, rgb, scale=20, instance_labels=inst)
+        cfg = copy.deepcopy(synthetic.KITTI_MODEL_CFG)
+    else:
+        xyz, rgb, inst = synthetic.scene_s2(seed=1, n=n)
+        batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+        cfg = None
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-    model = synthetic.build_model(seed=0)
+    model = synthetic.build_model(cfg, seed=0)
     model.async_results = os.environ.get('SCAN_ASYNC', '0') == '1'
     with torch.no_grad():
         for _ in range(3):
@@ -31,7 +45,7 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
     print(f'{reps} scans, latency ms min {ts[0]:.3f} median {ts[len(ts) // 2]:.3f} max {ts[-1]:.3f}; '
-          f'{len(r["pred_instances"])} instances')
+          f'{len(r.get("pred_instances", []))} instances ({which})')
 
 
 if __name__ == '__main__':

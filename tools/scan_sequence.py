@@ -1,7 +1,7 @@
 """Post-process a rocprofv3 kernel trace (+ memory-copy trace) of tools/scan_only.py: the launch sequence of
 ONE scan from the middle of the run (start, duration, gap to the previous operation) and the per-kernel table
 averaged over the middle scans.  A scan is delimited by its first kernel (voxelize_fp_kernel, launched once
-per scan).  Usage: python tools/scan_sequence.py <trace dir> <out prefix>"""
+per scan; another marker kernel as third argument).  Usage: python tools/scan_sequence.py <trace dir> <out prefix> [marker]"""
 import collections
 import csv
 import glob
@@ -10,6 +10,7 @@ import sys
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
+    marker = sys.argv[3] if len(sys.argv) > 3 else 'voxelize_fp_kernel'
     ops = []
     for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
         for r in csv.DictReader(open(f)):
@@ -19,7 +20,7 @@ def main():
         for r in csv.DictReader(open(f)):
             ops.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', '?'), ''))
     ops.sort()
-    marks = [i for i, o in enumerate(ops) if 'voxelize_fp_kernel' in o[2]]
+    marks = [i for i, o in enumerate(ops) if marker in o[2]]
     n = len(marks)
     a, b = marks[n // 2], marks[n // 2 + 1]
     with open(out + '_sequence.txt', 'w') as fo:
