@@ -82,8 +82,128 @@ def host_thread_plan(contexts, world):
     cores = os.cpu_count() or 1
     per_rank_budget = max(3, (cores // 2) // max(world, 1))
     used = max(1, min(contexts, per_rank_budget - 2))
+    # page-locked result staging of one rank: one ~12 MB block per scan in flight, twice (a block is
+    # handed back when the consumer lets go of the previous result) -- what the timed region can hold
+    # at most; beyond SG_PINNED_RESULTS_MB results are copied to pageable memory (util/cast.py)
+    pinned_mb = 12 * used * 2
     return used, {'scan_threads': used, 'results_thread': 1, 'main_thread': 1, 'per_rank': used + 2,
-                  'all_ranks': world * (used + 2), 'host_cores': cores, 'intra_op_threads': 1}
+                  'all_ranks': world * (used + 2), 'host_cores': cores, 'intra_op_threads': 1,
+                  'pinned_staging_mb_per_rank_bound': pinned_mb}
+
+
+def bind_rank_to_cores(local_rank, world):
+    """One contiguous slice of the host cores per rank (rank r of N: cores [r * C / N, (r + 1) * C / N) of
+    the cores this process may run on -- on a two-socket box with the GPUs split between the sockets
+    that is the NUMA-local half).  Returns the slice as [first, last] or None where the platform has
+    no sched_setaffinity or the launcher already pinned the rank to fewer cores than its share."""
+    if world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        share = len(allowed) // world
+        if share < 1:
+            return None
+        mine = allowed[local_rank * share:(local_rank + 1) * share]
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except OSError:
+        return None
+
+
+def ddp_leg(args, rank, world, local_rank, stub):
+    """N > 1 only: what the training side adds per step on this node -- the gradient all-reduce of the
+    trainable heads (2 919 208 bytes with the fine-tune configs' frozen backbone: DistributedDataParallel
+    puts them in one bucket; reference tools/train.py:172-174) -- measured on the job's own process
+    group (RCCL over xGMI on the GPU node, gloo in the CPU plumbing test), and a short DDP training
+    leg on every rank: softgroup_s3dis_fold5.yaml shapes, one 150 k-point scene per rank, frozen
+    backbone, forward_train + backward + Adam under bf16 autocast.  The stub leg trains a parameter
+    vector of the same byte size on the host.  -> dict for the JSON line (rank 0), per-rank step times
+    gathered from all ranks."""
+    import numpy as np
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    n_bytes = 2919208
+    dev = torch.device('cpu') if stub else torch.device('cuda', local_rank)
+    bucket = torch.ones(n_bytes // 4, dtype=torch.float32, device=dev)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    for _ in range(3):
+        dist.all_reduce(bucket)
+    sync()
+    ts = []
+    for _ in range(20):
+        bucket.fill_(1.0)
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(bucket)
+        sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    assert float(bucket[0]) == float(world), 'all-reduce(SUM) of ones must give the world size'
+    ts.sort()
+    rec = {'allreduce_bytes': n_bytes, 'allreduce_ms_median': round(ts[len(ts) // 2], 4),
+           'allreduce_ms_min': round(ts[0], 4), 'backend': dist.get_backend(),
+           'algbw_GBps': round(n_bytes / (ts[len(ts) // 2] * 1e-3) / 1e9, 3)}
+    # ---- DDP training steps
+    steps = 6
+    if stub:
+        torch.manual_seed(0)
+        net = torch.nn.Linear(n_bytes // 4 - 1, 1)          # weight + bias = n_bytes / 4 parameters
+        model = DDP(net)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        x = torch.randn(4, n_bytes // 4 - 1)
+        step_ms = []
+        for it in range(steps + 2):
+            t0 = time.perf_counter()
+            loss = model(x).square().mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+        trainable = sum(p.numel() * p.element_size() for p in net.parameters())
+    else:
+        import copy
+        from softgroup_amd import synthetic
+        from softgroup_amd.data import collate_device, make_item
+        from softgroup_amd.model import SoftGroup
+        cfg = copy.deepcopy(synthetic.S3DIS_MODEL_CFG)
+        torch.manual_seed(0)
+        net = SoftGroup(**cfg).cuda()
+        with torch.no_grad():
+            net.semantic_linear[-1].weight.normal_(0, 20.0)
+        net.train()
+        model = DDP(net, device_ids=[local_rank], find_unused_parameters=True)
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4)
+        x, c, ins = synthetic.scene_s2(seed=31 + rank, n=args.points)
+        sem = np.where(ins >= 0, 2 + ins % 11, 0).astype(np.int64)
+        batch = collate_device([make_item(x, c, 50, sem, ins, f'crop_{rank}')])
+        batch['instance_cls'] = batch['instance_cls'].clamp(min=0)
+        step_ms = []
+        for it in range(steps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss, _ = model(batch, return_loss=True)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+        trainable = sum(p.numel() * p.element_size() for p in params)
+    mine = sorted(step_ms[2:])[len(step_ms[2:]) // 2]
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, round(mine, 3))
+    rec.update({'train_steps_timed': steps, 'trainable_bytes': int(trainable),
+                'train_ms_per_step_per_rank': per_rank, 'train_ms_per_step_min': min(per_rank),
+                'train_ms_per_step_max': max(per_rank),
+                'workload': ('stub: Linear of the same parameter bytes on the host' if stub else
+                             'softgroup_s3dis_fold5.yaml shapes, one 150 k-point scene per rank, frozen backbone, '
+                             'bf16 autocast, DistributedDataParallel')})
+    return rec
 
 
 def spawn_ranks(args):
@@ -610,6 +730,10 @@ def stub_main(args, rank, world, devices):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ddp = ddp_leg(args, rank, world, int(os.environ.get('LOCAL_RANK', '0')), True) if world > 1 else None
+    cores = [None] * world
+    if world > 1:
+        dist.all_gather_object(cores, args._core_slice)
     if rank == 0:
         print(json.dumps({'metric': 'stub steps/s (plumbing test)', 'value': round(world * args.steps / elapsed, 3),
                           'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -617,6 +741,7 @@ def stub_main(args, rank, world, devices):
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub',
                           'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices,
                           'host_threads': host_thread_plan(args.contexts, world)[1],
+                          'rank_core_slices': cores, 'ddp': ddp,
                           'legs': 'skipped (N>1)' if world > 1 else 'skipped (stub)'}))
     if world > 1:
         dist.barrier()
@@ -646,6 +771,8 @@ def main():
         assert n_dev > local_rank, (f'rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible -- '
                                     f'refusing to share a device between ranks')
         torch.cuda.set_device(local_rank)
+    # every rank on its own slice of the host cores (its scan / results threads inherit it)
+    args._core_slice = bind_rank_to_cores(local_rank, world)
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(args.backend)       # 'nccl' is RCCL on ROCm
@@ -914,6 +1041,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs:
         out.setdefault('legs', {}).update(measurement_legs(args, model, batch, xyz, rgb, inst))
 
+    if dist_on:
+        # N > 1: the training side's per-step exchange on this node -- gradient all-reduce of the
+        # trainable heads over the job's RCCL group -- and a short DDP training leg on every rank
+        model.scan_contexts = 1
+        ddp = ddp_leg(args, rank, world, local_rank, False)
+        cores = [None] * world
+        dist.all_gather_object(cores, args._core_slice)
+        out['ddp'] = ddp
+        out['rank_core_slices'] = cores
     if rank == 0:
         if world > 1:           # nothing is skipped silently: the single-GPU legs do not run with N > 1
             out['legs'] = 'skipped (N>1)'

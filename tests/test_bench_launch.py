@@ -83,3 +83,25 @@ def test_host_thread_plan_caps_contexts():
     used8, plan8 = bench.host_thread_plan(4, 8)
     assert 1 <= used8 <= 4 and plan8['all_ranks'] == 8 * (used8 + 2)
     assert used8 == max(1, min(4, max(3, (cores // 2) // 8) - 2))
+
+
+def test_n_gt_1_line_carries_the_ddp_leg_and_the_rank_core_slices():
+    """N > 1: the line reports the gradient all-reduce of the trainable heads (2 919 208 bytes, what
+    DistributedDataParallel exchanges per step with the fine-tune configs' frozen backbone; reference
+    tools/train.py:172-174) measured on the job's own process group, per-rank DDP training step times,
+    and the slice of host cores every rank bound itself to (disjoint slices; pinned result staging of
+    a rank bounded by 12 MB x scan threads x 2)."""
+    out = _run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1', '--backend', 'gloo',
+                '--stub'])
+    d = out['ddp']
+    assert d['allreduce_bytes'] == 2919208 and d['backend'] == 'gloo'
+    assert 0 < d['allreduce_ms_min'] <= d['allreduce_ms_median']
+    assert len(d['train_ms_per_step_per_rank']) == 2 and d['train_ms_per_step_min'] <= d['train_ms_per_step_max']
+    assert d['trainable_bytes'] == 2919208
+    ht = out['host_threads']
+    assert ht['pinned_staging_mb_per_rank_bound'] == 12 * ht['scan_threads'] * 2
+    slices = out['rank_core_slices']
+    assert len(slices) == 2
+    if hasattr(os, 'sched_setaffinity') and all(s is not None for s in slices):
+        (a0, a1), (b0, b1) = slices
+        assert a1 < b0 or b1 < a0, slices              # disjoint

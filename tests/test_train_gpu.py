@@ -396,3 +396,27 @@ def test_bf16_autocast_losses_explained():
         else:
             assert abs(same[k] - want) <= 0.02 * abs(want) + 5e-3, (k, same[k], want)
     assert agree >= 0.9
+
+
+def test_bench_ddp_leg_runs_on_rccl():
+    """bench.py's N > 1 leg (gradient all-reduce of the trainable heads on the job's RCCL group + a DDP
+    training step per rank, softgroup_s3dis_fold5.yaml shapes) executed on the 'nccl' backend at world
+    size 1 -- the GPU box exposes one device; the world-2 path of the same function runs on gloo in
+    tests/test_bench_launch.py."""
+    import argparse
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        rec = bench.ddp_leg(argparse.Namespace(points=30000), 0, 1, 0, False)
+    finally:
+        dist.destroy_process_group()
+    assert rec['backend'] == 'nccl' and rec['allreduce_bytes'] == 2919208
+    assert rec['trainable_bytes'] == 2919208            # what DDP all-reduces: the heads, not the frozen backbone
+    assert 0 < rec['allreduce_ms_min'] and 0 < rec['train_ms_per_step_min'] < 1000
