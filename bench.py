@@ -31,6 +31,7 @@ scans, as a serving deployment would.  ``ms_per_step_unpipelined`` is one scan a
 result formatting in line (the latency figure).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -1023,15 +1024,24 @@ def main():
         # one oracle forward of the SAME scene: timed as the CPU baseline, and its outputs are the
         # full-size parity check of the GPU path (stage-wise: floats <= 1e-4, proposals / instance
         # labels / RLE strings identical; end to end: instance drift)
+        # `cores` = the threads really used: the port is run on ONE thread.  (Its sparse conv has an
+        # OpenMP loop, but the scan's CPU time is in single-threaded parts -- hash-based rulebooks,
+        # brute-force ball query and BFS as in the reference's CPU ops: round 4 reported 256 cores for a
+        # forward that took 1.99 s on all cores and 1.90 s on one, legs.S1_backbone.)
+        threads = 1
+        try:
+            ctypes.CDLL('libgomp.so.1').omp_set_num_threads(1)
+        except OSError:
+            threads = os.cpu_count()
         rep = parity.parity_report(model, cpu_batch, synthetic.SCANNET_MODEL_CFG, timed_path=True)
         cpu_s = rep.pop('oracle_forward_s')
         out['parity_at_bench'] = rep
         ref_ops = reference_cpu_ops_leg(model, batch)
         out['cpu_baseline'] = {
-            'value': round(1.0 / cpu_s, 4), 'unit': 'scans/s', 'cores': os.cpu_count(),
+            'value': round(1.0 / cpu_s, 4), 'unit': 'scans/s', 'cores': threads,
             'kind': 'port',
-            'sample': f'1 scan of the same S2 scene ({args.points} pts): C/OpenMP sparse conv on all '
-                      f'cores, single-thread brute-force ball query + BFS like the reference CPU ops; '
+            'sample': f'1 scan of the same S2 scene ({args.points} pts) on {threads} thread(s): C sparse conv, '
+                      f'brute-force ball query + BFS like the reference CPU ops; '
                       f'{cpu_s:.1f} s.  reference_ops: the reference\'s OWN CPU ops (oracle/_ref/sg_ref_ops.so = '
                       f'softgroup/ops/src compiled unmodified, 1 thread) on the same scan'
                       + ('' if ref_ops else ' -- library not on this box, not timed'),
