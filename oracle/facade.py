@@ -122,14 +122,53 @@ class _Conv(SparseModule):
         self.bias = None
 
 
+class _GatherConvFn(torch.autograd.Function):
+    """out[j] = sum_k W[:, k, :] . in[table[j, k]] (table entry -1: no term) -- the one operator behind
+    the three conv flavours (oracle/sg_oracle_conv.c `gather_conv`).  Forward: the C oracle itself, so
+    values are those of the non-differentiable stand-ins.  Backward: the textbook gradients of that
+    sum, accumulated in float64 -- d in[i] += W[:, k, :]^T . d out[j] over the pairs (j, k) that
+    gathered row i, d W[:, k, :] = sum_j d out[j] (x) in[table[j, k]] -- i.e. what spconv's backward
+    computes (its source is not vendored), used by tests/golden/make_ref_train.py for the
+    GRADIENT goldens of the reference's forward_train."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, table, fwd):
+        ctx.save_for_backward(feats, weight)
+        ctx.table = table
+        return _t(fwd(_n(feats), _n(weight)))
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, weight = ctx.saved_tensors
+        tab = torch.from_numpy(np.ascontiguousarray(ctx.table).astype(np.int64))
+        K, cout, cin = tab.shape[1], weight.shape[0], feats.shape[1]
+        W = weight.detach().reshape(cout, K, cin).double()
+        x, g = feats.detach().double(), g.double()
+        gx, gW = torch.zeros_like(x), torch.zeros_like(W)
+        for k in range(K):
+            m = tab[:, k] >= 0
+            if not bool(m.any()):
+                continue
+            idx, gk = tab[m, k], g[m]
+            gW[:, k, :] = gk.t() @ x[idx]
+            gx.index_add_(0, idx, gk @ W[:, k, :])
+        return gx.to(feats.dtype), gW.reshape(weight.shape).to(weight.dtype), None, None
+
+
+def _conv(feats, weight, table, fwd):
+    if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad):
+        return _GatherConvFn.apply(feats, weight, table, fwd)
+    return _t(fwd(_n(feats), _n(weight)))
+
+
 class SubMConv3d(_Conv):
 
     def forward(self, x):
         assert self.kernel_size == 3 and self.padding == 1
         if self.indice_key not in x.indice_dict:
             x.indice_dict[self.indice_key] = O.subm_rulebook(_n(x.indices), x.spatial_shape)
-        out = O.subm_conv3d(_n(x.features), x.indice_dict[self.indice_key], _n(self.weight))
-        return x.replace_feature(_t(out))
+        nbr = x.indice_dict[self.indice_key]
+        return x.replace_feature(_conv(x.features, self.weight, nbr, lambda f, w: O.subm_conv3d(f, nbr, w)))
 
 
 class SparseConv3d(_Conv):
@@ -137,8 +176,8 @@ class SparseConv3d(_Conv):
     def forward(self, x):
         assert self.kernel_size == 2 and self.stride == 2 and self.padding == 0
         out_idx, in2out, child, oshape = O.down_rulebook(_n(x.indices), x.spatial_shape)
-        out = O.sparse_conv3d_k2s2(_n(x.features), child, _n(self.weight))
-        y = SparseConvTensor(_t(out), _t(out_idx), oshape, x.batch_size, x.grid)
+        out = _conv(x.features, self.weight, child, lambda f, w: O.sparse_conv3d_k2s2(f, child, w))
+        y = SparseConvTensor(out, _t(out_idx), oshape, x.batch_size, x.grid)
         y.indice_dict = x.indice_dict
         y.indice_dict[self.indice_key] = (x.indices, in2out, x.spatial_shape)
         return y
@@ -148,10 +187,40 @@ class SparseInverseConv3d(_Conv):
 
     def forward(self, x):
         fine_indices, in2out, fine_shape = x.indice_dict[self.indice_key]
-        out = O.inverse_conv3d_k2(_n(x.features), _n(fine_indices), in2out, _n(self.weight))
-        y = SparseConvTensor(_t(out), fine_indices, fine_shape, x.batch_size, x.grid)
+        fi = _n(fine_indices)
+        kk = (fi[:, 1] & 1) * 4 + (fi[:, 2] & 1) * 2 + (fi[:, 3] & 1)
+        table = np.full((fi.shape[0], 8), -1, np.int32)            # sg_oracle_conv.c:156-166
+        table[np.arange(fi.shape[0]), kk] = in2out
+        out = _conv(x.features, self.weight, table, lambda f, w: O.inverse_conv3d_k2(f, fi, in2out, w))
+        y = SparseConvTensor(out, fine_indices, fine_shape, x.batch_size, x.grid)
         y.indice_dict = x.indice_dict
         return y
+
+
+class _VoxelizationFn(torch.autograd.Function):
+    """softgroup/ops/functions.py:105-150 (`Voxelization`): forward voxelize_fp, backward voxelize_bp"""
+
+    @staticmethod
+    def forward(ctx, feats, map_rule, mode):
+        ctx.map_rule, ctx.mode, ctx.n = _n(map_rule), mode, feats.shape[0]
+        return _t(O.voxelization(_n(feats), ctx.map_rule, mode))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _t(O.voxelization_bp(_n(g.contiguous()), ctx.map_rule, ctx.n, ctx.mode)), None, None
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    """softgroup/ops/functions.py:333-371 (`GlobalAvgPool`): forward / backward of the ROI average pool"""
+
+    @staticmethod
+    def forward(ctx, feats, offsets):
+        ctx.offsets, ctx.n = _n(offsets), feats.shape[0]
+        return _t(O.global_avg_pool(_n(feats), ctx.offsets))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _t(O.global_avg_pool_bp(_n(g.contiguous()), ctx.offsets, ctx.n)), None
 
 
 def _spconv_modules():
@@ -176,7 +245,14 @@ def _ops_module():
         return _t(oc), _t(im), _t(om)
 
     def voxelization(feats, map_rule, mode=4):
+        if torch.is_grad_enabled() and feats.requires_grad:
+            return _VoxelizationFn.apply(feats, map_rule, mode)
         return _t(O.voxelization(_n(feats), _n(map_rule), mode))
+
+    def global_avg_pool(feats, offsets):
+        if torch.is_grad_enabled() and feats.requires_grad:
+            return _GlobalAvgPoolFn.apply(feats, offsets)
+        return _t(O.global_avg_pool(_n(feats), _n(offsets)))
 
     def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
         idx, sl = O.ballquery_batch_p(_n(coords), _n(batch_idxs), _n(batch_offsets), radius, meanActive)
@@ -215,7 +291,7 @@ def _ops_module():
 
     for k, v in dict(voxelization_idx=voxelization_idx, voxelization=voxelization,
                      ballquery_batch_p=ballquery_batch_p, octree_ball_query=octree_ball_query,
-                     ball_query=ball_query, bfs_cluster=bfs_cluster, global_avg_pool=_seg('global_avg_pool'),
+                     ball_query=ball_query, bfs_cluster=bfs_cluster, global_avg_pool=global_avg_pool,
                      sec_min=_seg('sec_min'), sec_max=_seg('sec_max'), sec_mean=_seg('sec_mean'),
                      get_mask_iou_on_cluster=get_mask_iou_on_cluster,
                      get_mask_iou_on_pred=get_mask_iou_on_pred, get_mask_label=get_mask_label).items():

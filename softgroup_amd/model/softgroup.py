@@ -628,18 +628,30 @@ class SoftGroup(nn.Module):
         dev = scores.device
         idx_list, off_list = [], []
         n_prop, n_pts = 0, 0
-        for class_id in classes:
-            obj = (scores[:, class_id] > _cfg(self.grouping_cfg, 'score_thr')).nonzero().view(-1)
-            if obj.size(0) < min_npoint:
+        # the selected points of ALL classes by one nonzero (class-major, points ascending = what the
+        # reference's per-class `.nonzero()` yields) and ONE read-back of the per-class counts; the
+        # per-class loop then slices (it used to issue a compare + nonzero + host sync per class: 15
+        # syncs per STPLS3D scan before any class was known to be large enough)
+        cls_t = torch.tensor(classes, device=dev)
+        sel = scores[:, cls_t].t() > _cfg(self.grouping_cfg, 'score_thr')          # [n_classes, N]
+        counts = sel.sum(1, dtype=torch.int32).tolist()
+        _, obj_all = sel.nonzero(as_tuple=True)
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        for ci, class_id in enumerate(classes):
+            if counts[ci] < min_npoint:
                 continue
+            obj = obj_all[int(starts[ci]):int(starts[ci + 1])]
             b_, c_, o_ = batch_idxs[obj], coords_float[obj], pt_offsets[obj]
             radius, level, l2p_map = radius0, 1, None
             if with_pyramid:
                 level = self.get_level(c_.size(0))
                 radius = radius0 * level
                 if level > 1 or not lvl_fusion:
-                    c_, o_, b_, l2p_map = self.pyramid_map(c_, o_, b_, level, base_size)
-            offs = self.get_batch_offsets(b_, batch_size)
+                    c_, o_, b_, l2p_map = self.pyramid_map(c_, o_, b_, level, base_size, batch_size=batch_size)
+            if batch_size == 1:          # (no bincount / cumsum for a single scene)
+                offs = torch.tensor([0, b_.size(0)], dtype=torch.int32, device=dev)
+            else:
+                offs = self.get_batch_offsets(b_, batch_size)
             nbr, start_len = ops.ball_query((c_ + o_).contiguous(), b_.int().contiguous(), offs,
                                             radius, mean_active, with_octree=with_octree)
             pidx, poff = ops.bfs_cluster(class_mean, nbr, start_len, npoint_thr, class_id)
@@ -664,12 +676,16 @@ class SoftGroup(nn.Module):
             return 3
         return 2 if num_points > 100000 else 1
 
-    def pyramid_map(self, coords_float, pt_offsets, batch_idxs, level=1, base_size=0.02):
+    def pyramid_map(self, coords_float, pt_offsets, batch_idxs, level=1, base_size=0.02, batch_size=None):
         """coarse voxels for big classes; .long() truncates toward zero like the reference
-        (softgroup.py:491-498)"""
+        (softgroup.py:491-498).  ``batch_size``: what the reference reads back from
+        the GPU (`batch_idxs[-1] + 1`) when the caller knows it -- the voxel index depends on it only
+        through the key range"""
         vox = (coords_float / (base_size * level)).long()
         vox = torch.cat([batch_idxs[:, None].long(), vox], dim=1).contiguous()
-        out_coords, l2p_map, p2l_map = ops.voxelization_idx(vox, int(batch_idxs[-1].item()) + 1)
+        if batch_size is None:
+            batch_size = int(batch_idxs[-1].item()) + 1
+        out_coords, l2p_map, p2l_map = ops.voxelization_idx(vox, int(batch_size))
         coords_float = ops.voxelization(coords_float.contiguous(), p2l_map)
         pt_offsets = ops.voxelization(pt_offsets.contiguous(), p2l_map)
         return coords_float, pt_offsets, out_coords[:, 0].int(), l2p_map

@@ -104,6 +104,96 @@ def apply_gt(batch, gt):
     return batch
 
 
+# ---------------------------------------------------------------------------------------------------
+# GRADIENT goldens (round 5): d loss / d parameter of the reference's forward_train, by autograd through
+# the reference's own Python over the differentiable stand-ins of oracle/facade.py (conv: the gradients
+# of out[j] = sum_k W_k . in[nbr[j, k]] in float64; voxelization / ROI pool: the C restatements of the
+# reference's own backward kernels).
+#
+# A ReLU whose input lies within rounding distance of zero makes the gradient discontinuous: an
+# implementation that differs in the 7th digit of that pre-activation may take the other branch, and
+# the gradient of everything upstream moves by that unit's whole contribution.  With ~10^6 ReLU inputs
+# per case a handful always sit that close, so a tolerance alone cannot separate "wrong" from "flipped".
+# The generator therefore measures it: every ReLU records its inputs with |x| < GRAD_MARGIN * rms(x)
+# ("ambiguous"), the backward runs a second time with exactly those units' branches inverted, and the
+# per-tensor difference of the two gradients is stored as `slack`: the test allows
+# 1e-4 * max|g_ref| + 2 * slack, i.e. a strict tolerance plus only what the measured ambiguous units
+# can explain.
+GRAD_MARGIN = 5e-6
+GRAD_CASES = {
+    # case -> which gradients are stored (None: every trainable parameter)
+    'scannet_frozen': None,
+    's3dis_fold5': None,
+    'scannet_full': ('tiny_unet', 'cls_linear', 'mask_linear', 'iou_score_linear', 'semantic_linear',
+                     'offset_linear', 'input_conv.0.weight', 'unet.blocks.block0.conv_branch.2.weight',
+                     'unet.blocks.block1.conv_branch.5.weight', 'unet.conv.2.weight', 'unet.deconv.2.weight',
+                     'unet.u.u.blocks.block0.conv_branch.2.weight', 'unet.blocks_tail.block0.i_branch.0.weight',
+                     'unet.blocks.block0.conv_branch.0', 'unet.u.conv.0', 'unet.u.u.u.deconv.0', 'output_layer.0'),
+}
+
+
+class _ProbeReLUFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, probe):
+        ctx.save_for_backward(x)
+        ctx.probe = probe
+        return x.clamp(min=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x, ) = ctx.saved_tensors
+        rms = float(x.detach().double().pow(2).mean().sqrt())
+        close = x.abs() < GRAD_MARGIN * max(rms, 1e-12)
+        st = ctx.probe.stats
+        st['inputs'] += x.numel()
+        st['ambiguous'] += int(close.sum())
+        mask = x > 0
+        if ctx.probe.stats['flip']:
+            mask = mask ^ close
+        return g * mask.to(g.dtype), None
+
+
+class ProbeReLU(torch.nn.Module):
+    """nn.ReLU with the same forward; backward counts the ambiguous inputs and can invert their branch"""
+    stats = dict(inputs=0, ambiguous=0, flip=False)
+
+    def forward(self, x):
+        return _ProbeReLUFn.apply(x, self) if torch.is_grad_enabled() and x.requires_grad else x.clamp(min=0)
+
+
+def _swap_relus(model):
+    for parent in model.modules():
+        for name, child in list(parent._modules.items()):
+            if isinstance(child, torch.nn.ReLU):
+                assert not child.inplace
+                parent._modules[name] = ProbeReLU()
+
+
+def reference_gradients(cfg, sd, batch, mod_lvl2, keep):
+    """-> (names, grads, slack, stats): gradients of the reference's forward_train loss"""
+    out = []
+    for flip in (False, True):
+        ref, mod = facade.reference_model(cfg, sd)
+        if mod_lvl2:
+            ref.get_level = G.lvl2
+        ref.train()
+        _swap_relus(ref)
+        ProbeReLU.stats.update(inputs=0, ambiguous=0, flip=flip)
+        torch.manual_seed(SEED)
+        with facade.cpu_only(mod):
+            loss, _ = ref(batch, return_loss=True)
+            loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters()
+                 if p.requires_grad and p.grad is not None and
+                 (keep is None or any(n == k or n.startswith(k + '.') for k in keep))}
+        out.append((grads, dict(ProbeReLU.stats), float(loss.detach())))
+    (g0, st, loss0), (g1, _, _) = out
+    names = sorted(g0)
+    slack = np.array([float((g0[n] - g1[n]).abs().max()) for n in names], np.float64)
+    return names, [g0[n].numpy().astype(np.float32) for n in names], slack, st, loss0
+
+
 def main():
     only = sys.argv[1:]
     for case, c in CASES.items():
@@ -136,6 +226,16 @@ def main():
                    n_proposals_eval=np.int64(len(poff) - 1),
                    log_keys=np.array(list(log_vars.keys())),
                    log_vals=np.array([float(v) for v in log_vars.values()], np.float64))
+        if case in GRAD_CASES:
+            names, grads, slack, st, loss_g = reference_gradients(cfg, sd, batch, fc.get('force_lvl2'), GRAD_CASES[case])
+            assert abs(loss_g - float(log_vars['loss'])) <= 1e-5 * abs(float(log_vars['loss'])), (loss_g, log_vars['loss'])
+            rec.update(grad_names=np.array(names), grad_slack=slack, grad_margin=np.float64(GRAD_MARGIN),
+                       grad_relu_inputs=np.int64(st['inputs']), grad_relu_ambiguous=np.int64(st['ambiguous']))
+            for i, g in enumerate(grads):
+                rec[f'grad_{i:03d}'] = g
+            worst = max((float(sl) / max(float(np.abs(g).max()), 1e-30) for sl, g in zip(slack, grads)), default=0.0)
+            print(f'  gradients: {len(names)} tensors, {sum(g.size for g in grads)} values; ReLU inputs {st["inputs"]}, '
+                  f'ambiguous {st["ambiguous"]}; largest slack / max|g| = {worst:.2e}')
         path = os.path.join(HERE, f'ref_train_{case}.npz')
         np.savez_compressed(path, **rec)
         print(case, 'points', xyz.shape[0], 'GT instances', len(gt['instance_pointnum']),

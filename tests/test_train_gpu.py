@@ -348,6 +348,47 @@ def test_forward_train_losses_match_reference(case):
         assert model.cls_linear.weight.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize('case', sorted(GT.GRAD_CASES))
+def test_forward_train_gradients_match_reference(case):
+    """d loss / d parameter of softgroup_amd's forward_train + backward on the GPU (training executor:
+    sg_unet_train_forward / _backward; the operators' own backward kernels) against autograd through the
+    REFERENCE'S forward_train (softgroup/model/softgroup.py:113-298 executed as written over the
+    differentiable oracle stand-ins, tests/golden/make_ref_train.py `reference_gradients`).
+    Tolerance per tensor: 1e-4 of the tensor's largest reference entry, plus twice the `slack` the
+    generator measured for that tensor by inverting the branch of the ReLU inputs that lie within
+    5e-6 rms of zero (a handful of ~10^6: units that another fp32 summation order may flip; 0 for the
+    tensors behind the last ReLU).  Not a comparison with the module path."""
+    g = np.load(os.path.join(HERE, 'golden', f'ref_train_{case}.npz'))
+    names = [str(n) for n in g['grad_names']]
+    model, batch, ref, seed = _train_case(case)
+    model.train()
+    torch.manual_seed(seed)
+    loss, _ = model(batch, return_loss=True)
+    loss.backward()
+    params = dict(model.named_parameters())
+    worst, strict = [], 0
+    # (a parameter whose true gradient is zero -- the bias of a Linear in front of a training-mode
+    # BatchNorm -- carries only rounding noise (sums of ~10^4 cancelling terms): floor of 1e-5 of the largest
+    # gradient entry of the case)
+    floor = 1e-5 * max(float(np.abs(g[f'grad_{i:03d}']).max()) for i in range(len(names)))
+    for i, n in enumerate(names):
+        want = torch.from_numpy(g[f'grad_{i:03d}'])
+        p = params[n]
+        got = torch.zeros_like(want) if p.grad is None else p.grad.detach().float().cpu()
+        assert got.shape == want.shape, n
+        scale = float(want.abs().max())
+        slack = float(g['grad_slack'][i])
+        tol = 1e-4 * scale + 2.0 * slack + floor
+        err = float((got - want).abs().max())
+        worst.append((err / max(scale, 1e-30), n, err, tol))
+        strict += slack == 0.0
+        assert err <= tol, f'{n}: max |d| {err:.3e} > {tol:.3e} (scale {scale:.3e}, slack {slack:.3e})'
+    worst.sort(reverse=True)
+    print(case, f'{len(names)} tensors ({strict} with zero slack), ambiguous ReLU inputs '
+                f'{int(g["grad_relu_ambiguous"])} of {int(g["grad_relu_inputs"])}; worst relative errors:',
+          [(round(w[0], 7), w[1]) for w in worst[:3]])
+
+
 def test_bf16_autocast_losses_explained():
     """bf16 autocast vs fp32 on the same batch, weights and seed (BASELINE config 3 precision).
     The two runs differ for two reasons that this test separates:

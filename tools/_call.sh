@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_native_scan_gpu.py tests/test_dropin_gpu.py tests/test_variants_gpu.py tests/test_ops_gpu.py -x -q > gpurun_out/c16_pytest.log 2>&1
-grep -E "passed|failed|error" gpurun_out/c16_pytest.log | tail -3
+python -m pytest tests/test_train_gpu.py -x -q -s -k "gradients_match_reference" > gpurun_out/c18_pytest.log 2>&1
+grep -E "passed|failed|error|tensors|Error|assert" gpurun_out/c18_pytest.log | tail -12
