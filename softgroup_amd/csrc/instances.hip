@@ -410,21 +410,19 @@ __global__ void __launch_bounds__(128) panoptic_walk_kernel(const uint32_t *__re
 
 // the pasted instances' points: a point takes the id of the FIRST pasted instance (in visiting order)
 // whose mask holds it -- what the sequential paste of the reference leaves behind
-__global__ void __launch_bounds__(256) panoptic_assign_kernel(const uint32_t *__restrict__ bits, int words, int sum_words,
-                                                             const uint32_t *__restrict__ summary, int n_inst,
+__global__ void __launch_bounds__(256) panoptic_assign_kernel(const uint32_t *__restrict__ bits, int words, int n_inst,
                                                              const int32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ id_of_rank,
                                                              uint32_t *__restrict__ first) {
-  const int64_t total = static_cast<int64_t>(n_inst) * sum_words;
+  // one thread per (visited instance, word of its row): coalesced over the row, the few non-zero words
+  // of a pasted instance spread over as many threads (per summary word, the first version, a thread
+  // walked up to 32 words x 32 bits of atomics alone: 130 us)
+  const int64_t total = static_cast<int64_t>(n_inst) * words;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
-    const int r = static_cast<int>(t / sum_words), c = static_cast<int>(t - static_cast<int64_t>(r) * sum_words);
+    const int r = static_cast<int>(t / words), w = static_cast<int>(t - static_cast<int64_t>(r) * words);
     if (id_of_rank[r] == 0u) continue;
-    const int k = order[r];
-    const uint32_t *row = bits + static_cast<int64_t>(k) * words;
-    for (uint32_t m = summary[static_cast<int64_t>(k) * sum_words + c]; m; m &= m - 1) {
-      const int w = c * 32 + __ffs(static_cast<int>(m)) - 1;
-      for (uint32_t bw = row[w]; bw; bw &= bw - 1) atomicMin(&first[w * 32 + __ffs(static_cast<int>(bw)) - 1], static_cast<uint32_t>(r));
-    }
+    for (uint32_t bw = bits[static_cast<int64_t>(order[r]) * words + w]; bw; bw &= bw - 1)
+      atomicMin(&first[w * 32 + __ffs(static_cast<int>(bw)) - 1], static_cast<uint32_t>(r));
   }
 }
 
@@ -658,8 +656,8 @@ int sg_panoptic_fusion(const uint32_t *bits, int n_inst, int n_points, const int
     else if (spl <= 8) SG_WALK(8);
     else SG_WALK(16);
 #undef SG_WALK
-    panoptic_assign_kernel<<<grid_for(static_cast<int64_t>(n_inst) * sum_words, 256, 4096), 256, 0, stream>>>(
-        bits, words, sum_words, summary, n_inst, order, id_of_rank, ids);
+    panoptic_assign_kernel<<<grid_for(static_cast<int64_t>(n_inst) * words, 256, 8192), 256, 0, stream>>>(
+        bits, words, n_inst, order, id_of_rank, ids);
   } else if (n_inst > 0) {
     panoptic_walk_dense_kernel<<<1, kFuseThreads, 0, stream>>>(bits, words, n_inst, order, label_id, cls_offset,
                                                               skip_iou, taken, ids, label_of_id);
