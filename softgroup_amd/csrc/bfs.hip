@@ -108,7 +108,16 @@ __global__ void __launch_bounds__(256) bfs_init_kernel(int n, int32_t *parent, i
   }
 }
 
-// one wave per source node u; lanes stride over list(u)
+// one wave per source node u; lanes stride over list(u).
+// Two passes: a cheap first pass links every node to a neighbour (bfs_hook_min_kernel; SAMPLE = 1, the
+// first kSample entries of the list through the union-find, is what unsorted lists take), the trees are
+// flattened (bfs_compress_kernel: parent[i] = root); SAMPLE = 0 then
+// walks the whole list, but an edge whose target already carries the source's root -- almost all of them:
+// a point has ~36 neighbours and its cluster is connected through any two -- costs ONE load of
+// parent[v] instead of two pointer chases and a CAS (the single pass took 0.16 ms on the bench scene and
+// 1.19 ms on the KITTI-like sweep).  A stale root only sends the edge down the full union path.
+constexpr int kSample = 2;
+template <int SAMPLE>
 __global__ void __launch_bounds__(256) bfs_union_kernel(const int32_t *__restrict__ idx,
                                                        const int32_t *__restrict__ start_len, int n,
                                                        int lists_sorted, int radius_lists,
@@ -116,9 +125,11 @@ __global__ void __launch_bounds__(256) bfs_union_kernel(const int32_t *__restric
                                                        int32_t *counters) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int u = blockIdx.x * 4 + wave; u < n; u += gridDim.x * 4) {
-    const int st = start_len[2 * u], ln = start_len[2 * u + 1];
-    const bool u_capped = ln >= kCap;
+    const int st = start_len[2 * u], ln_all = start_len[2 * u + 1];
+    const int ln = SAMPLE ? min(ln_all, kSample) : ln_all;
+    const bool u_capped = ln_all >= kCap;
     bool any_asym = false;
+    const int ru = SAMPLE ? -1 : SG_LD(&parent[u]);      // (flattened: the root of u as of the sampling pass)
     for (int p0 = 0; p0 < ln; p0 += 64) {
       const int p = p0 + lane;
       const int v = p < ln ? idx[st + p] : u;
@@ -135,15 +146,39 @@ __global__ void __launch_bounds__(256) bfs_union_kernel(const int32_t *__restric
           }
         }
         if (sym) {
-          if (v < u) uf_union(parent, uf_find(parent, u), uf_find(parent, v));
+          if (v < u && (SAMPLE || SG_LD(&parent[v]) != ru)) uf_union(parent, uf_find(parent, u), uf_find(parent, v));
         }
       }
       any_asym |= !sym;
     }
-    if (__any(any_asym)) {
+    if (!SAMPLE && __any(any_asym)) {
       if (lane == 0) asym_nodes[atomicAdd(&counters[0], 1)] = u;
     }
   }
+}
+
+// Pass 1 of the clustering: every node hooks itself under its SMALLEST neighbour (lists are sorted: the
+// first entry), a plain store -- pointers strictly decrease, so this is a forest; no atomics, no pointer
+// chasing.  (Sampling the first two entries through the union-find itself, the first version of this pass,
+// cost 88 / 309 us on the bench scene / the KITTI-like sweep: everybody hooks towards the same low roots.)
+// Same edge predicate as the full pass: a capped list's edge counts only if it is symmetric.
+__global__ void __launch_bounds__(256) bfs_hook_min_kernel(const int32_t *__restrict__ idx,
+                                                          const int32_t *__restrict__ start_len, int n,
+                                                          int lists_sorted, int radius_lists, int32_t *parent) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n) return;
+  const int st = start_len[2 * u], ln = start_len[2 * u + 1];
+  if (ln == 0 || !lists_sorted) return;
+  const int v = idx[st];
+  if (v >= u) return;
+  if (!radius_lists || ln >= kCap || start_len[2 * v + 1] >= kCap)
+    if (!list_has_sorted(idx + start_len[2 * v], start_len[2 * v + 1], u)) return;
+  parent[u] = v;
+}
+// between the passes: parent[i] = root(i) (path halving on the way: nothing else runs)
+__global__ void __launch_bounds__(256) bfs_compress_kernel(int n, int32_t *parent) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) SG_ST(&parent[i], uf_find(parent, i));
 }
 
 __global__ void __launch_bounds__(256) bfs_flatten_kernel(int n, int32_t *parent, int32_t *lab) {
@@ -1004,10 +1039,23 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
   const int grid = (n + 255) / 256;
   hipMemsetAsync(w.counters, 0, 64 * 4, stream);
   bfs_init_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.size, w.owner);
-  bfs_union_kernel<<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, start_len, n,
-                                                               list_flags & SG_LISTS_SORTED,
-                                                               list_flags & SG_LISTS_RADIUS,
-                                                               w.parent, w.asym_nodes, w.counters);
+  static const bool one_pass = getenv("SG_BFS_ONE_PASS") != nullptr;      // developer A/B knob: round 4's single pass
+  if (!one_pass) {
+    static const bool sample_env = getenv("SG_BFS_SAMPLE") != nullptr;      // developer A/B knob: union-find sampling pass
+    if (sample_env || !(list_flags & SG_LISTS_SORTED))
+      bfs_union_kernel<1><<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, start_len, n,
+                                                                      list_flags & SG_LISTS_SORTED,
+                                                                      list_flags & SG_LISTS_RADIUS,
+                                                                      w.parent, w.asym_nodes, w.counters);
+    else
+      bfs_hook_min_kernel<<<grid, 256, 0, stream>>>(bq_idxs, start_len, n, list_flags & SG_LISTS_SORTED,
+                                                   list_flags & SG_LISTS_RADIUS, w.parent);
+    bfs_compress_kernel<<<grid, 256, 0, stream>>>(n, w.parent);
+  }
+  bfs_union_kernel<0><<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(bq_idxs, start_len, n,
+                                                                  list_flags & SG_LISTS_SORTED,
+                                                                  list_flags & SG_LISTS_RADIUS,
+                                                                  w.parent, w.asym_nodes, w.counters);
   bfs_flatten_kernel<<<grid, 256, 0, stream>>>(n, w.parent, w.lab);
   bfs_store_root_kernel<<<grid, 256, 0, stream>>>(n, w.lab, w.parent);  // parent := root_of
 
