@@ -17,6 +17,7 @@ import functools
 import ctypes
 import os
 import threading
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -113,6 +114,7 @@ class SoftGroup(nn.Module):
         self.use_executor = True     # native U-Net executor for inference (same kernels as the modules)
         # train() mode U-Nets as one autograd node each (csrc/unet_train.hip); SG_TRAIN_EXEC=0: the modules
         self.use_train_executor = os.environ.get('SG_TRAIN_EXEC', '1') != '0'
+        self.scan_result_hook = None      # callable(result dict) run by the scan worker before the result is handed back (scan_contexts > 1)
         self.use_fused_heads = os.environ.get('SG_FUSED_HEADS', '1') != '0'   # devoxelize + point-wise heads + arg-max as one kernel (inference)
         self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
@@ -234,7 +236,11 @@ class SoftGroup(nn.Module):
                     st.wait_event(ready)
                     out = self.forward_test(**batch, _inline_results=True)
                     st.synchronize()
-            return dict(out)
+            out = dict(out)
+            hook = self.scan_result_hook
+            if hook is not None:       # on the worker: a consumer-side pass over the results (a digest, a
+                hook(out)              # metric) does not have to win the interpreter lock from the workers
+            return out
 
         with _POOL_LOCK:
             pool = self.__dict__.get('_scan_pool')
