@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { env "$@" python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$*', d['ms_per_step'], d['ms_per_step_windows'], d['timed_results_identical'])"; }
-run A=1; run A=1; run A=1; run A=1; run A=1; run A=1
+python -m pytest tests/test_ops_gpu.py tests/test_spconv_gpu.py tests/test_native_scan_gpu.py tests/test_scan_contexts_gpu.py -x -q > gpurun_out/c21_pytest.log 2>&1; grep -E "passed|failed" gpurun_out/c21_pytest.log | tail -2
+python tools/scan_only.py 30 2>&1 | tail -1
+python tools/scan_only.py 20 150000 kitti 2>&1 | tail -1
+python tools/scan_only.py 12 150000 stpls3d_pp 2>&1 | tail -1
