@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_ops_gpu.py tests/test_spconv_gpu.py tests/test_native_scan_gpu.py tests/test_scan_contexts_gpu.py -x -q > gpurun_out/c21_pytest.log 2>&1; grep -E "passed|failed" gpurun_out/c21_pytest.log | tail -2
-python tools/scan_only.py 30 2>&1 | tail -1
-python tools/scan_only.py 20 150000 kitti 2>&1 | tail -1
-python tools/scan_only.py 12 150000 stpls3d_pp 2>&1 | tail -1
+python -m pytest tests/test_ops_gpu.py -x -q -k "pointwise_heads" 2>&1 | grep -E "passed|failed"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o r -- python $GRAFT_REPO_ROOT/tools/scan_only.py 12 > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/scan_sequence.py /tmp/prof $GRAFT_REPO_ROOT/gpurun_out/c22_scan pointwise_heads_kernel
+grep "pointwise_heads\|GPU busy\|scan_block_sums\|scan_apply\|scan_reduce" $GRAFT_REPO_ROOT/gpurun_out/c22_scan_top.txt | cut -c1-125
