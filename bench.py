@@ -841,9 +841,13 @@ def main():
         for _ in range(2):
             for r in [model(batches[i % n_scenes]) for i in range(contexts)]:
                 r.resolve()
-        # the digest of a result is computed by the scan worker that produced it (scan_result_hook) and
-        # compared by the consumer inside the timed region
-        model.scan_result_hook = lambda res: res.__setitem__('result_digest', result_digest(res))
+        # the digest of every result is computed and compared by the consumer inside the timed region
+        # (SG_BENCH_DIGEST=worker: the digest computed by the scan worker through model.scan_result_hook instead
+        # of by the consumer -- measured within the run-to-run noise of the consumer-side check at 20 steps and
+        # worse at 160 steps with 5 workers, profiles/README.md)
+        digest_on_worker = os.environ.get('SG_BENCH_DIGEST', 'main') == 'worker'
+        if digest_on_worker and not os.environ.get('SG_BENCH_SKIP_DIGEST'):
+            model.scan_result_hook = lambda res: res.__setitem__('result_digest', result_digest(res))
         for r in [model(batches[i % n_scenes]) for i in range(max(args.warmup, 1))]:
             r.resolve()
         # the interpreter's cyclic garbage collector pauses every thread of the process while it walks
@@ -864,7 +868,7 @@ def main():
             r.resolve()
             if os.environ.get('SG_BENCH_SKIP_DIGEST'):      # developer diagnosis only: what the check costs
                 return next(checked) >= 0
-            return r['result_digest'] == alone[next(checked) % n_scenes]
+            return (r['result_digest'] if digest_on_worker else result_digest(r)) == alone[next(checked) % n_scenes]
 
         elapsed, rets, windows = timed_steps(step, consume, args.steps, sync_all)
     model.scan_result_hook = None

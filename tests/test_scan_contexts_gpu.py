@@ -114,6 +114,25 @@ def test_cache_invalidation_and_weight_update_between_submissions(setup):
         model.scan_contexts = 1
 
 
+def test_scan_result_hook_runs_on_the_worker(setup):
+    """model.scan_result_hook(result) is called by the scan worker before the result is handed back"""
+    import threading
+    model, scenes, refs = setup
+    seen = []
+    model.scan_contexts = 3
+    model.scan_result_hook = lambda res: (seen.append(threading.current_thread().name),
+                                          res.__setitem__('digest', result_digest(res)))
+    try:
+        with torch.no_grad():
+            rets = [model(scenes[i]) for i in (1, 3, 5)]
+            for r, i in zip(rets, (1, 3, 5)):
+                assert r['digest'] == result_digest(refs[i])
+    finally:
+        model.scan_result_hook = None
+        model.scan_contexts = 1
+    assert len(seen) == 3 and all(n.startswith('softgroup-scan') for n in seen)
+
+
 def test_pool_retirement_releases_stream_arenas(setup):
     from softgroup_amd.model import native_scan as NS
     from softgroup_amd.spconv import unet_exec as UE

@@ -1,7 +1,13 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_ops_gpu.py -x -q -k "pointwise_heads" 2>&1 | grep -E "passed|failed"
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o r -- python $GRAFT_REPO_ROOT/tools/scan_only.py 12 > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/tools/scan_sequence.py /tmp/prof $GRAFT_REPO_ROOT/gpurun_out/c22_scan pointwise_heads_kernel
-grep "pointwise_heads\|GPU busy\|scan_block_sums\|scan_apply\|scan_reduce" $GRAFT_REPO_ROOT/gpurun_out/c22_scan_top.txt | cut -c1-125
+run() { env "$@" python bench.py $ARGS --no-legs --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$ARGS $*', d['ms_per_step'], d['ms_per_step_windows'])"; }
+for rep in 1 2; do
+ARGS="--contexts 5" run SG_BENCH_DIGEST=main
+ARGS="--contexts 4" run SG_BENCH_DIGEST=main
+ARGS="--contexts 4" run SG_BENCH_DIGEST=worker
+ARGS="--contexts 4 --switch-interval-us 200" run SG_BENCH_DIGEST=main
+ARGS="--contexts 5 --switch-interval-us 200" run SG_BENCH_DIGEST=main
+ARGS="--contexts 3" run SG_BENCH_DIGEST=main
+done
