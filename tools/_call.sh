@@ -1,13 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { env "$@" python bench.py $ARGS --no-legs --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$ARGS $*', d['ms_per_step'], d['ms_per_step_windows'])"; }
-for rep in 1 2; do
-ARGS="--contexts 5" run SG_BENCH_DIGEST=main
-ARGS="--contexts 4" run SG_BENCH_DIGEST=main
-ARGS="--contexts 4" run SG_BENCH_DIGEST=worker
-ARGS="--contexts 4 --switch-interval-us 200" run SG_BENCH_DIGEST=main
-ARGS="--contexts 5 --switch-interval-us 200" run SG_BENCH_DIGEST=main
-ARGS="--contexts 3" run SG_BENCH_DIGEST=main
-done
+python -m pytest tests/test_scan_contexts_gpu.py -x -q 2>&1 | grep -E "passed|failed"
+python bench.py > gpurun_out/r05_bench.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_shape.json 2>/dev/null
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-roofline 2>/dev/null > gpurun_out/r05_bench_driver_shape_$i.json; done
