@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_scan_contexts_gpu.py -x -q 2>&1 | grep -E "passed|failed"
-python bench.py > gpurun_out/r05_bench.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_shape.json 2>/dev/null
-for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-roofline 2>/dev/null > gpurun_out/r05_bench_driver_shape_$i.json; done
+for w in 8 16 32; do
+echo "SG_BFS_BIG_WGS=$w kitti: $(SG_BFS_BIG_WGS=$w python tools/scan_only.py 16 150000 kitti 2>&1 | tail -1)"
+echo "SG_BFS_BIG_WGS=$w stpls3d: $(SG_BFS_BIG_WGS=$w python tools/scan_only.py 10 150000 stpls3d_pp 2>&1 | tail -1)"
+done
