@@ -40,7 +40,18 @@ struct BfsWs {
   int32_t *counters;  // [0] #asym source nodes  [1] changed flag  [2] nCluster  [3] sumNPoint
   void *scan_ws;
   size_t scan_bytes;
+  // frontier staging of the multi-workgroup replay of giant clusters (bfs_emit_big_kernel<true>): per
+  // level parity the shared pool (n entries) followed by the workgroups' private slices
+  int32_t *big_stage[2];
+  unsigned long long *big_rec[2];
 };
+
+constexpr int kBigFastWgs = 16;        // most workgroups the FAST replay is launched with
+constexpr int kBigSlice = 8192;        // = kBigEdges: winners of one cached level of one workgroup
+constexpr int kBigClusterMin = 16384;  // = kBigMin = kOwnCap: no giant cluster among fewer points
+inline size_t big_stage_entries(int n) {
+  return n > kBigClusterMin ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
+}
 
 static bool bfs_carve(void *ws, size_t ws_bytes, int n, int64_t n_edges, BfsWs *w) {
   Workspace a(ws, ws_bytes);
@@ -60,7 +71,14 @@ static bool bfs_carve(void *ws, size_t ws_bytes, int n, int64_t n_edges, BfsWs *
   w->scan_bytes = scan_workspace_bytes(n);
   w->scan_ws = a.take<char>(w->scan_bytes);
   w->erec = a.take<int2>(static_cast<size_t>(n_edges > 0 ? n_edges : 1));
-  return w->scan_ws != nullptr && w->erec != nullptr;
+  bool ok = w->scan_ws != nullptr && w->erec != nullptr;
+  const size_t be = big_stage_entries(n);
+  for (int i = 0; i < 2; ++i) {
+    w->big_stage[i] = be ? a.take<int32_t>(be) : nullptr;
+    w->big_rec[i] = be ? a.take<unsigned long long>(be) : nullptr;
+    ok = ok && (be == 0 || (w->big_stage[i] != nullptr && w->big_rec[i] != nullptr));
+  }
+  return ok;
 }
 
 // ---------------------------------------------------------------- A. union-find
@@ -674,6 +692,9 @@ constexpr int kBigWgsMax = 256;
 constexpr int kBigMin = kOwnCap;        // clusters above this size take this path
 constexpr int kBigNodes = 1024;         // frontier nodes / edges of a workgroup's range that the cached level holds
 constexpr int kBigEdges = 8192;
+constexpr int kBigDirectDegree = 32;    // FAST: mean list length of a level up to which claims are not filtered
+static_assert(kBigSlice == kBigEdges && kBigClusterMin == kBigMin, "staging sizes follow the kernel's constants");
+static_assert(kBigNodes <= 65535, "c_j holds node indices of a range as 16-bit");
 
 // Everything the workgroups exchange (frontier regions, claims, records) is written with
 // device-scope write-through stores / atomics and read with sc1 loads that bypass the CU's L1
@@ -709,10 +730,29 @@ __device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *f
 // region offset and region length
 constexpr int kBigRecAt = 64;
 
+//
+// FAST (the default; SG_BFS_BIG_FAST=0 selects the round-4 form): a level is a chain of dependent memory
+// round trips between 16 workgroups on 8 XCDs (~0.8 us each through the fabric) and nothing else, so
+// three of them are taken out of the cached level:
+//   * a frontier entry carries its node record -- (list start, list length), which the edge record of the
+//     winning edge already holds -- in a second staging array, so the next level's claim needs ONE load
+//     per node (staged record) instead of two dependent ones (staged id -> node_rec[id]);
+//   * the claim of a level with short lists issues its atomicMin straight away (no filtering load of the
+//     claim word before it);
+//   * a workgroup's region of the next frontier of a cached level (<= kBigEdges winners) is a fixed
+//     private slice behind the shared pool, so no atomicAdd on the pool head sits between deciding the
+//     winners and writing them, and ONE sweep decides, ranks and writes.
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 pack_rec(int z, int w) {
+  return static_cast<u64>(static_cast<unsigned>(z)) | (static_cast<u64>(static_cast<unsigned>(w)) << 32);
+}
+
+template <bool FAST>
 __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
-    int32_t *owner_g, int32_t *wcnt, int32_t *stage0, int32_t *stage1, int32_t *cluster_idxs, int32_t *sync) {
+    int32_t *owner_g, int32_t *wcnt, int32_t *stage0, int32_t *stage1, u64 *srec0, u64 *srec1, int priv_base,
+    int32_t *cluster_idxs, int32_t *sync) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int lds_flag, lds_off;
   __shared__ int node_off[kEmitThreads];
@@ -722,6 +762,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
   // the claim sweep to the emit sweep, which then costs ONE memory round trip (the claim words)
   __shared__ int c_st[kBigNodes], c_eb[kBigNodes + 1];
   __shared__ int c_t[kBigEdges];
+  __shared__ unsigned short c_j[FAST ? kBigEdges : 1];       // FAST: the node (index in the range) of every edge
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int G = gridDim.x, b = blockIdx.x;
   int32_t *bar = sync, *fail = sync + 1, *pool = sync + 2;
@@ -740,6 +781,10 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     if (threadIdx.x == 0) {
       if (b == 0) {
         SG_ST(&stage0[0], seed);
+        if constexpr (FAST) {
+          const int4 r = node_rec[seed];
+          SG_ST(&srec0[0], pack_rec(r.z, r.w));
+        }
         SG_ST(&Q[0], c);
         SG_ST(&Q[1], seed);
         SG_ST(&owner_g[seed], -1);
@@ -795,6 +840,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       const int L = pre[G];
       const int my_pos = pre[b], my_len = pre[b + 1] - pre[b];
       int32_t *cur = par ? stage1 : stage0, *nxt = par ? stage0 : stage1;
+      u64 *curr = par ? srec1 : srec0, *nxtr = par ? srec0 : srec1;      // FAST: node records of the entries
       // ---- this workgroup's region of the current frontier goes to the output queue
       for (int i = threadIdx.x; i < my_len; i += kEmitThreads) {
         SG_ST(&Q[2 * (tail + my_pos + i)], c);
@@ -804,13 +850,22 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       if (L == 0) break;                                           // cluster complete (uniform)
       const int lo = static_cast<int>(static_cast<long long>(L) * b / G);
       const int hi = static_cast<int>(static_cast<long long>(L) * (b + 1) / G);
-      auto node_at = [&](int q) {                                  // frontier rank -> point id
+      auto rec_at = [&](int q, int &st, int &ln) {                 // frontier rank -> (list start, list length)
         int w0 = 0, w1 = G;                                        // last w with pre[w] <= q
         while (w1 - w0 > 1) {
           const int mid = (w0 + w1) >> 1;
           if (pre[mid] <= q) w0 = mid; else w1 = mid;
         }
-        return SG_LD(&cur[offs[w0] + (q - pre[w0])]);
+        const int at = offs[w0] + (q - pre[w0]);
+        if constexpr (FAST) {
+          const u64 r = SG_LD(&curr[at]);
+          st = static_cast<int>(r & 0xffffffffu);
+          ln = static_cast<int>(r >> 32);
+        } else {
+          const int4 r = node_rec[SG_LD(&cur[at])];
+          st = r.z;
+          ln = r.w;
+        }
       };
       // ---- claim
       const int nn = hi - lo;
@@ -821,9 +876,9 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
           const int i = i0 + threadIdx.x;
           int ln = 0;
           if (i < nn) {
-            const int4 r = node_rec[node_at(lo + i)];
-            c_st[i] = r.z;
-            ln = r.w;
+            int st;
+            rec_at(lo + i, st, ln);
+            c_st[i] = st;
           }
           int tot;
           const int ex = wg_excl_scan(ln, lds_scan, &tot);
@@ -843,6 +898,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         return j0;
       };
       if (E >= 0) {
+        const bool direct = E <= kBigDirectDegree * nn;
         for (int e = threadIdx.x; e < E; e += kEmitThreads) {      // flat over the range's edges
           const int jn = edge_node(e);
           const int p = e - c_eb[jn], g = c_st[jn] + p;
@@ -850,14 +906,21 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
           if ((erec[g].x & 0xffff) != 0xffff) {                    // else: target in another cluster
             t = idx[g];
             const int pos = ((lo + jn) << 10) | p;
-            if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+            // (sparse lists: the atomic goes out unfiltered, one round trip less; dense lists send most of
+            //  their edges to visited nodes, ~100 per node and level: there the filtering load stays)
+            if (FAST && direct) {
+              atomicMin(&owner_g[t], pos);
+            } else {
+              if (SG_LD(&owner_g[t]) > pos) atomicMin(&owner_g[t], pos);
+            }
           }
           c_t[e] = t;
+          if constexpr (FAST) c_j[e] = static_cast<unsigned short>(jn);
         }
       } else {
         for (int q = lo + wave; q < hi; q += kEmitWaves) {
-          const int v = node_at(q);
-          const int4 r = node_rec[v];
+          int4 r;
+          rec_at(q, r.z, r.w);
           for (int p = lane; p < r.w; p += 64) {
             const int g = r.z + p;
             if ((erec[g].x & 0xffff) == 0xffff) continue;          // target in another cluster
@@ -870,9 +933,51 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       if (b == 0 && threadIdx.x == 0) SG_ST(&pool[par ^ 1], 0);   // next level's pool (idle since two levels)
       if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
       if (E >= 0) {
-        // ---- emit of a cached level: one sweep over the claim words decides the winners (losers and
-        //      foreign targets become -1 in LDS), one atomicAdd takes the region, one LDS-only sweep
-        //      writes the winners in edge order = (node, position) order
+        // ---- emit of a cached level
+        if constexpr (FAST) {
+          // one sweep: the claim word and the winning edge's record (= the target's list) travel together,
+          // winners are ranked in edge order = (node, position) order and written to the private slice
+          const int base = priv_base + b * kBigEdges;
+          int carry = 0;
+          for (int e0 = 0; e0 < E; e0 += kEmitThreads) {
+            const int e = e0 + threadIdx.x;
+            bool win = false;
+            int t = -1;
+            int2 er = make_int2(0, 0);
+            if (e < E) {
+              t = c_t[e];
+              if (t >= 0) {
+                const int jn = c_j[e];
+                const int p = e - c_eb[jn];
+                er = erec[c_st[jn] + p];
+                win = SG_LD(&owner_g[t]) == (((lo + jn) << 10) | p);
+              }
+            }
+            int tot;
+            const int ex = wg_excl_scan(win ? 1 : 0, lds_scan, &tot);
+            if (win) {
+              SG_ST(&nxt[base + carry + ex], t);
+              SG_ST(&nxtr[base + carry + ex], pack_rec(er.y, static_cast<int>(static_cast<unsigned>(er.x) >> 16)));
+              SG_ST(&owner_g[t], -1);                              // only this edge matches pos
+            }
+            carry += tot;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          ++tag;
+          par ^= 1;
+          if (threadIdx.x == 0) {
+            __hip_atomic_store(&rec[(par * G + b) * 2], (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(base),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rec[(par * G + b) * 2 + 1],
+                               (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(carry),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          continue;
+        }
+        // round-4 form: one sweep over the claim words decides the winners (losers and foreign targets
+        // become -1 in LDS), one atomicAdd takes the region out of the shared pool, one LDS-only sweep
+        // writes the winners in edge order = (node, position) order
         int total = 0;
         for (int e0 = 0; e0 < E; e0 += kEmitThreads) {
           const int e = e0 + threadIdx.x;
@@ -926,8 +1031,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       // ---- emit, pass 1: winners per node of this workgroup's range
       int my_total = 0;
       for (int q = lo + wave; q < hi; q += kEmitWaves) {
-        const int v = node_at(q);
-        const int4 r = node_rec[v];
+        int4 r;
+        rec_at(q, r.z, r.w);
         int wins = 0;
         for (int p0 = 0; p0 < r.w; p0 += 64) {
           const int p = p0 + lane;
@@ -965,16 +1070,18 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         const int n_here = min(kEmitThreads, hi - c0);
         for (int jn = wave; jn < n_here; jn += kEmitWaves) {
           const int q = c0 + jn;
-          const int v = node_at(q);
-          const int4 r = node_rec[v];
+          int4 r;
+          rec_at(q, r.z, r.w);
           int o = node_off[jn];
           for (int p0 = 0; p0 < r.w; p0 += 64) {
             const int p = p0 + lane;
             bool win = false;
             int t = 0;
+            int2 er = make_int2(0, 0);
             if (p < r.w) {
               const int g = r.z + p;
-              if ((erec[g].x & 0xffff) != 0xffff) {
+              er = erec[g];
+              if ((er.x & 0xffff) != 0xffff) {
                 t = idx[g];
                 win = SG_LD(&owner_g[t]) == ((q << 10) | p);
               }
@@ -982,6 +1089,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
             const uint64_t bal = __ballot(win);
             if (win) {
               SG_ST(&nxt[o + mask_prefix(bal)], t);
+              if constexpr (FAST)
+                SG_ST(&nxtr[o + mask_prefix(bal)], pack_rec(er.y, static_cast<int>(static_cast<unsigned>(er.x) >> 16)));
               SG_ST(&owner_g[t], -1);                            // only this edge matches pos
             }
             o += __popcll(bal);
@@ -1017,8 +1126,9 @@ extern "C" {
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges) {
   const size_t nn = static_cast<size_t>(n > 0 ? n : 1);
   const size_t ne = static_cast<size_t>(n_edges > 0 ? n_edges : 1);
+  const size_t be = big_stage_entries(n);
   return 14 * align_up(nn * 4) + align_up(64 * 4) + align_up(scan_workspace_bytes(n)) +
-         align_up(ne * sizeof(int2)) + 256;
+         align_up(ne * sizeof(int2)) + 2 * (align_up(be * 4) + align_up(be * 8)) + 256;
 }
 
 // Synchronises `stream` (the cluster count decides the size of the outputs).
@@ -1145,9 +1255,18 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
         if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
       // frontier staging pools (one per level parity, at most a cluster's points each): the union-find
       // arrays of the labelling, idle by now
-      bfs_emit_big_kernel<<<big_wgs, kEmitThreads, 0, stream>>>(bq_idxs, w.label, w.erec, w.seeds,
-                                                              cluster_offsets, n_cluster, w.owner,
-                                                              w.wcnt, w.parent, w.lab, cluster_idxs, sync);
+      // SG_BFS_BIG_FAST=0 (developer knob): the round-4 form of the replay (see the kernel's header)
+      // (read per call -- only scans with a giant cluster get here -- so that one test process compares both)
+      const char *fast_env = getenv("SG_BFS_BIG_FAST");
+      const bool fast_on = !(fast_env && atoi(fast_env) == 0);
+      if (fast_on && big_wgs <= kBigFastWgs && w.big_stage[0] != nullptr)
+        bfs_emit_big_kernel<true><<<big_wgs, kEmitThreads, 0, stream>>>(
+            bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.big_stage[0],
+            w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync);
+      else
+        bfs_emit_big_kernel<false><<<big_wgs, kEmitThreads, 0, stream>>>(
+            bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.parent, w.lab,
+            nullptr, nullptr, 0, cluster_idxs, sync);
       // sync[1] != 0: the replay gave up somewhere (see big_barrier) -- redo the giant clusters on
       // the per-cluster kernel (same output, slower); both launches are no-ops otherwise
       bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin,

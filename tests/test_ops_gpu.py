@@ -231,6 +231,35 @@ def test_bfs_cluster_bigger_than_the_lds_claim_array():
     assert np.array_equal(co2.cpu().numpy(), rco) and np.array_equal(ci2.cpu().numpy(), rci)
 
 
+def test_bfs_cluster_giant_with_fat_levels_both_replay_forms():
+    """one 40 000-point slab whose BFS levels have 10^5..10^6 edges (a workgroup's share exceeds the
+    cached level: the multi-workgroup replay takes its chunked path, frontier regions come out of the
+    shared pool) and the thin sheet above (always the cached level, private slices): membership and BFS
+    order exact, in the default form of the replay and in the round-4 form (SG_BFS_BIG_FAST=0)."""
+    import os
+    rng = np.random.default_rng(29)
+    slab = rng.random((40000, 3)) * np.array([1.0, 1.0, 0.02])
+    g = np.stack(np.meshgrid(np.arange(150), np.arange(150), indexing='ij'), -1).reshape(-1, 2)
+    sheet = np.concatenate([g * 0.02 + 3.0, np.zeros((len(g), 1))], 1)
+    xyz = np.concatenate([slab, sheet]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    n = len(xyz)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(np.zeros(n, np.int32)), t(np.array([0, n], np.int32)),
+                                    0.04, 300)
+    assert float(sl[:, 1].float().mean()) > 60
+    mean = torch.tensor([-1.0])
+    rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 50.0, 0)
+    assert sorted(np.diff(rco).tolist()) == [22500, 40000]
+    for form in ('1', '0'):
+        os.environ['SG_BFS_BIG_FAST'] = form
+        try:
+            ci, co = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
+        finally:
+            del os.environ['SG_BFS_BIG_FAST']
+        assert np.array_equal(co.cpu().numpy(), rco), form
+        assert np.array_equal(ci.cpu().numpy(), rci), form
+
+
 def test_bfs_cluster_empty_and_all_dropped():
     mean = torch.tensor([-1.0])
     ci, co = ops.bfs_cluster(mean, torch.zeros(0, dtype=torch.int32, device=DEV),
