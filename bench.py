@@ -83,10 +83,12 @@ def host_thread_plan(contexts, world):
     cores = os.cpu_count() or 1
     per_rank_budget = max(3, (cores // 2) // max(world, 1))
     used = max(1, min(contexts, per_rank_budget - 2))
-    # page-locked result staging of one rank: one ~12 MB block per scan in flight, twice (a block is
-    # handed back when the consumer lets go of the previous result) -- what the timed region can hold
-    # at most; beyond SG_PINNED_RESULTS_MB results are copied to pageable memory (util/cast.py)
-    pinned_mb = 12 * used * 2
+    # page-locked result staging of one rank: the region submits all its scans up front, so a consumer that
+    # lags keeps as many results alive as the cap allows -- SG_PINNED_RESULTS_MB (256) of ~12 MB blocks (16 MB
+    # in the host allocator) plus the one being filled; beyond the cap results are copied to pageable memory
+    # (util/cast.py).  Measured: 5 blocks page-locked inside a 160-scan region when the consumer keeps up, 17
+    # when results complete out of order (profiles/r05_inflight_modes.txt).
+    pinned_mb = int(os.environ.get('SG_PINNED_RESULTS_MB', '256')) + 16
     return used, {'scan_threads': used, 'results_thread': 1, 'main_thread': 1, 'per_rank': used + 2,
                   'all_ranks': world * (used + 2), 'host_cores': cores, 'intra_op_threads': 1,
                   'pinned_staging_mb_per_rank_bound': pinned_mb}
@@ -692,10 +694,12 @@ def timed_steps(step, resolve, steps, sync_all):
     the window's last step are resolved) -- the rate of a run with several scans in flight wanders
     between windows, the median says how representative the whole-region figure is."""
     sync_all()
+    diag = [] if os.environ.get('SG_BENCH_DIAG') else None      # developer: completion time of every step
+    if diag is not None and torch.cuda.is_available():           # ... and what the allocators did in the region
+        d0 = (torch.cuda.memory_stats().get('num_device_alloc', 0), torch._C._cuda_hostMemoryStats()['num_host_alloc'])
     t0 = time.perf_counter()
     rets = [step() for _ in range(steps)]
     marks, cuts = [], [steps * (i + 1) // 3 for i in range(3)]
-    diag = [] if os.environ.get('SG_BENCH_DIAG') else None      # developer: completion time of every step
     if diag is not None:
         diag.append(round((time.perf_counter() - t0) * 1e3, 1))   # submission done
     for i in range(steps):
@@ -712,6 +716,12 @@ def timed_steps(step, resolve, steps, sync_all):
     elapsed = time.perf_counter() - t0
     if diag is not None:
         sys.stderr.write(f'[bench diag] submitted at {diag[0]} ms, resolved at {diag[1:]}\n')
+        if torch.cuda.is_available():
+            from softgroup_amd.util.cast import pinned_result_bytes
+            sys.stderr.write(f'[bench diag] in the region: device allocations '
+                             f'{torch.cuda.memory_stats().get("num_device_alloc", 0) - d0[0]}, pinned host allocations '
+                             f'{torch._C._cuda_hostMemoryStats()["num_host_alloc"] - d0[1]}, pinned result bytes alive '
+                             f'{pinned_result_bytes()}\n')
     windows, prev_t, prev_n = [], t0, 0
     for m, c in zip(marks, cuts):
         if c > prev_n:

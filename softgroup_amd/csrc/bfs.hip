@@ -49,8 +49,14 @@ struct BfsWs {
 constexpr int kBigFastWgs = 16;        // most workgroups the FAST replay is launched with
 constexpr int kBigSlice = 8192;        // = kBigEdges: winners of one cached level of one workgroup
 constexpr int kBigClusterMin = 16384;  // = kBigMin = kOwnCap: no giant cluster among fewer points
+// SG_BFS_BIG_FAST=0 (developer knob, read per call so that one test process compares both forms): the
+// round-4 form of the replay, without its staging arrays
+inline bool big_fast_on() {
+  const char *e = getenv("SG_BFS_BIG_FAST");
+  return !(e && atoi(e) == 0);
+}
 inline size_t big_stage_entries(int n) {
-  return n > kBigClusterMin ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
+  return n > kBigClusterMin && big_fast_on() ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
 }
 
 static bool bfs_carve(void *ws, size_t ws_bytes, int n, int64_t n_edges, BfsWs *w) {
@@ -1255,11 +1261,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
         if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
       // frontier staging pools (one per level parity, at most a cluster's points each): the union-find
       // arrays of the labelling, idle by now
-      // SG_BFS_BIG_FAST=0 (developer knob): the round-4 form of the replay (see the kernel's header)
-      // (read per call -- only scans with a giant cluster get here -- so that one test process compares both)
-      const char *fast_env = getenv("SG_BFS_BIG_FAST");
-      const bool fast_on = !(fast_env && atoi(fast_env) == 0);
-      if (fast_on && big_wgs <= kBigFastWgs && w.big_stage[0] != nullptr)
+      if (big_fast_on() && big_wgs <= kBigFastWgs && w.big_stage[0] != nullptr)
         bfs_emit_big_kernel<true><<<big_wgs, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.big_stage[0],
             w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync);

@@ -99,7 +99,7 @@ def test_n_gt_1_line_carries_the_ddp_leg_and_the_rank_core_slices():
     assert len(d['train_ms_per_step_per_rank']) == 2 and d['train_ms_per_step_min'] <= d['train_ms_per_step_max']
     assert d['trainable_bytes'] == 2919208
     ht = out['host_threads']
-    assert ht['pinned_staging_mb_per_rank_bound'] == 12 * ht['scan_threads'] * 2
+    assert ht['pinned_staging_mb_per_rank_bound'] == 256 + 16        # the cap of util/cast.py + the block being filled
     slices = out['rank_core_slices']
     assert len(slices) == 2
     if hasattr(os, 'sched_setaffinity') and all(s is not None for s in slices):
