@@ -70,6 +70,8 @@ def parse():
                     help="'gloo' + --stub: the launch / sharding / timing plumbing on CPU (tests)")
     ap.add_argument('--stub', action='store_true',
                     help='replace the scan by a fixed host-side delay (plumbing test, no GPU)')
+    ap.add_argument('--stub-ddp-hang-rank', type=int, default=-1,
+                    help='with --stub: this rank never joins the DDP leg (tests the deadline that protects the line)')
     ap.add_argument('--stub-fail-rank', type=int, default=-1,
                     help='(tests) this rank raises before the first barrier: the job must exit non-zero')
     return ap.parse_args()
@@ -92,6 +94,49 @@ def host_thread_plan(contexts, world):
     return used, {'scan_threads': used, 'results_thread': 1, 'main_thread': 1, 'per_rank': used + 2,
                   'all_ranks': world * (used + 2), 'host_cores': cores, 'intra_op_threads': 1,
                   'pinned_staging_mb_per_rank_bound': pinned_mb}
+
+
+def finish_n_gt_1(out, args, rank, world, local_rank, stub):
+    """N > 1: the DDP leg, the JSON line and the common exit, with the line GUARANTEED.  `out` is complete
+    when this is called (the headline was measured and max-reduced over the ranks); the DDP leg only adds
+    `ddp` and `rank_core_slices`.  A collective of the leg that never completes (a rank lost, ranks taking
+    different branches) must not cost the job its line: a watchdog thread -- it runs while the main thread
+    sits in a collective, which releases the interpreter lock -- prints the line with the reason after
+    SG_BENCH_DDP_DEADLINE_S (180) seconds and ends the process; the other ranks end the same way."""
+    import threading
+    import torch.distributed as dist
+    deadline = float(os.environ.get('SG_BENCH_DDP_DEADLINE_S', '180'))
+    done = threading.Event()
+    printed = threading.Lock()
+
+    def emit():
+        if rank == 0 and printed.acquire(blocking=False):
+            out['legs'] = 'skipped (N>1)'           # nothing is skipped silently: no single-GPU legs with N > 1
+            out.setdefault('cpu_baseline', 'skipped (N>1)')
+            print(json.dumps(out), flush=True)
+
+    def watchdog():
+        if not done.wait(deadline):
+            out.setdefault('ddp', {'error': f'the DDP leg / the common exit did not finish within {deadline:.0f} s '
+                                            f'(rank {rank}); headline unaffected'})
+            emit()
+            sys.stderr.write(f'[bench] rank {rank}: DDP leg deadline passed, leaving\n')
+            sys.stderr.flush()
+            os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        ddp = ddp_leg(args, rank, world, local_rank, stub)
+        cores = [None] * world
+        dist.all_gather_object(cores, args._core_slice)
+        out['ddp'] = ddp
+        out['rank_core_slices'] = cores
+    except Exception as e:      # (the same error on every rank: the line still goes out)
+        out['ddp'] = {'error': f'{type(e).__name__}: {e}'}
+    emit()
+    dist.barrier()              # leave together
+    done.set()
+    dist.destroy_process_group()
 
 
 def bind_rank_to_cores(local_rank, world):
@@ -152,6 +197,8 @@ def ddp_leg(args, rank, world, local_rank, stub):
            'algbw_GBps': round(n_bytes / (ts[len(ts) // 2] * 1e-3) / 1e9, 3)}
     # ---- DDP training steps
     steps = 6
+    if stub and rank == getattr(args, 'stub_ddp_hang_rank', -1):      # plumbing test: this rank never joins the leg
+        time.sleep(3600)
     if stub:
         torch.manual_seed(0)
         net = torch.nn.Linear(n_bytes // 4 - 1, 1)          # weight + bias = n_bytes / 4 parameters
@@ -748,22 +795,18 @@ def stub_main(args, rank, world, devices):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ddp = ddp_leg(args, rank, world, int(os.environ.get('LOCAL_RANK', '0')), True) if world > 1 else None
-    cores = [None] * world
+    out = {'metric': 'stub steps/s (plumbing test)', 'value': round(world * args.steps / elapsed, 3),
+           'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub',
+           'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices,
+           'host_threads': host_thread_plan(args.contexts, world)[1],
+           'rank_core_slices': [None] * world, 'ddp': None, 'legs': 'skipped (stub)'}
     if world > 1:
-        dist.all_gather_object(cores, args._core_slice)
+        del out['ddp']
+        return finish_n_gt_1(out, args, rank, world, int(os.environ.get('LOCAL_RANK', '0')), True)
     if rank == 0:
-        print(json.dumps({'metric': 'stub steps/s (plumbing test)', 'value': round(world * args.steps / elapsed, 3),
-                          'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'stub',
-                          'config': {'workload': 'stub'}, 'ranks_seen': world, 'devices': devices,
-                          'host_threads': host_thread_plan(args.contexts, world)[1],
-                          'rank_core_slices': cores, 'ddp': ddp,
-                          'legs': 'skipped (N>1)' if world > 1 else 'skipped (stub)'}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out))
 
 
 def main():
@@ -1093,21 +1136,12 @@ def main():
 
     if dist_on:
         # N > 1: the training side's per-step exchange on this node -- gradient all-reduce of the
-        # trainable heads over the job's RCCL group -- and a short DDP training leg on every rank
+        # trainable heads over the job's RCCL group -- and a short DDP training leg on every rank; then
+        # the line and the common exit (the line does not depend on the leg finishing)
         model.scan_contexts = 1
-        ddp = ddp_leg(args, rank, world, local_rank, False)
-        cores = [None] * world
-        dist.all_gather_object(cores, args._core_slice)
-        out['ddp'] = ddp
-        out['rank_core_slices'] = cores
+        return finish_n_gt_1(out, args, rank, world, local_rank, False)
     if rank == 0:
-        if world > 1:           # nothing is skipped silently: the single-GPU legs do not run with N > 1
-            out['legs'] = 'skipped (N>1)'
-            out.setdefault('cpu_baseline', 'skipped (N>1)')
         print(json.dumps(out))
-    if dist_on:
-        dist.barrier()          # leave together: rank 0 was still measuring its extras
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

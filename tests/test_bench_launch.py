@@ -105,3 +105,17 @@ def test_n_gt_1_line_carries_the_ddp_leg_and_the_rank_core_slices():
     if hasattr(os, 'sched_setaffinity') and all(s is not None for s in slices):
         (a0, a1), (b0, b1) = slices
         assert a1 < b0 or b1 < a0, slices              # disjoint
+
+
+def test_n_gt_1_line_survives_a_rank_that_never_joins_the_ddp_leg():
+    """the headline is complete before the DDP leg starts; a leg whose collectives never complete (here:
+    rank 1 never joins) must not cost the job its line: after the deadline rank 0 prints the line with the
+    reason in `ddp.error`, every rank leaves, the launcher returns 0"""
+    import time
+    t0 = time.time()
+    out = _run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1', '--backend', 'gloo',
+                '--stub', '--stub-ddp-hang-rank', '1'], env={'SG_BENCH_DDP_DEADLINE_S': '8'})
+    assert time.time() - t0 < 120
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['value'] > 0
+    assert 'did not finish within 8 s' in out['ddp']['error']
+    assert out['legs'] == 'skipped (N>1)'
