@@ -166,6 +166,9 @@ int sg_octree_ballquery_fill(const float *points, const float *boxes, const int3
  *   label : min-ancestor labelling (directed reachability), sizes, kept clusters
  *   emit  : cluster_idxs int32 [sumNPoint,2] = (cluster_id, point_idx), cluster_offsets [nCluster+1]
  * ---------------------------------------------------------------------------------------- */
+/* (14 n-word arrays, the scan workspace, one 8-byte record per edge and -- for n > 16 384, where a cluster
+ * too large for one workgroup's replay can exist -- the frontier staging of the multi-workgroup replay:
+ * 24 bytes x (n + 131 072)) */
 size_t sg_bfs_workspace_bytes(int n, int64_t n_edges);
 /* list_flags: SG_LISTS_SORTED  every list is strictly ascending (sg_ballquery_* output);
  *             SG_LISTS_RADIUS  lists come from a radius query, i.e. u in list(v) <=> v in list(u)
