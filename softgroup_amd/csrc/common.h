@@ -81,6 +81,10 @@ template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ int dpp_or_zero(int v) {      // lanes without a source read 0
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
 }
+// CONTRACT: all 64 lanes active (EXEC full) at the call -- an inactive source lane contributes 0 to the
+// scan and an inactive lane 63 leaves wave_sum's readlane with a stale register.  Every caller in this
+// library calls them from wave-uniform control flow; divergent code must use wave_max's shuffle form (or
+// ballot + popcount).  row_bcast:15 / :31 are GFX9-family DPP controls (this library targets gfx950 only).
 // inclusive scan across the wave
 __device__ __forceinline__ int wave_incl_scan(int v) {
   v += dpp_or_zero<0x111>(v);                 // row_shr:1

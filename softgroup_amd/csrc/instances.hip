@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(kFuseThreads) panoptic_walk_dense_kernel(
           ids[w * 32 + bb] = static_cast<uint32_t>(next_id);
         }
       }
-
+      ++next_id;      // (uniform: every thread takes the same decision from the same sums)
     }
   }
 }
@@ -632,7 +632,9 @@ int sg_panoptic_fusion(const uint32_t *bits, int n_inst, int n_points, const int
   int32_t *label_of_id = a.take<int32_t>(static_cast<size_t>(n_inst) + 2);
   uint32_t *summary = a.take<uint32_t>(static_cast<size_t>(n_inst > 0 ? n_inst : 1) * sum_words);
   uint32_t *id_of_rank = a.take<uint32_t>(static_cast<size_t>(n_inst) + 2);
-  static const bool dense_env = getenv("SG_PANOPTIC_DENSE") != nullptr;      // developer A/B knob: round 4's walk
+  // developer A/B knob, read per call so that a test can run both walks in one process: round 4's dense walk
+  const char *dense_s = getenv("SG_PANOPTIC_DENSE");
+  const bool dense_env = dense_s != nullptr && dense_s[0] != '\0' && dense_s[0] != '0';
   const bool sparse = n_inst > 0 && words <= kFuseTakenWords && !dense_env;
   hipMemsetAsync(ids, sparse ? 0xff : 0, static_cast<size_t>(n_points) * 4, stream);
   if (sparse) {

@@ -155,7 +155,6 @@ static __global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const uint3
 
 // Sorts by the low `num_bits` of the keys.  keys/vals are clobbered; the sorted result is in
 // (*keys_sorted, *vals_sorted), which alias either the inputs or the workspace buffers.
-static std::once_flag g_rs_lds_once;
 
 static inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int num_bits, void *ws,
                             size_t ws_bytes, hipStream_t stream, uint32_t **keys_sorted,
@@ -175,10 +174,26 @@ static inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int
   const int64_t tile = static_cast<int64_t>(items) * kRsBlock;
   const int nblk = static_cast<int>((n + tile - 1) / tile);
   const size_t lds = static_cast<size_t>(tile) * 8;       // the scatter kernel's tile staging (<= 128 KB)
-  std::call_once(g_rs_lds_once, [] {      // (per translation unit, like the static kernel it configures)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        64 * kRsBlock * 8);
-  });
+  // The tile staging needs up to 128 KB of dynamic LDS + ~7 KB static: gfx950's 160 KB per workgroup.
+  // The attribute is per device (and per translation unit, like the static kernel it configures):
+  // set once for every device this process sorts on, result checked.
+  {
+    static std::mutex mu;
+    static uint64_t done_mask = 0;      // bit d: device d configured
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64 || !((done_mask >> dev) & 1)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kRsBlock * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("radix_sort_pairs: %d bytes of dynamic LDS are not available on this device (gfx950: 160 KB "
+                  "per workgroup)", 64 * kRsBlock * 8);
+        return SG_ERR_LAUNCH;
+      }
+      if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+    }
+  }
   const int64_t hist_n = static_cast<int64_t>(nblk) * kRsBuckets;
   Workspace a(ws, ws_bytes);
   int32_t *hist = a.take<int32_t>(hist_n + 1);
@@ -199,6 +214,7 @@ static inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int
       int32_t *t = totals + pass * kRsBuckets;
       rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, t);
       rs_scatter_kernel<<<nblk, kRsBlock, lds, stream>>>(kin, vin, n, shift, nblk, items, hist, t, kout, vout);
+      if (const int rc = check_launch("radix_sort_pairs(scatter)"); rc != SG_OK) return rc;
     } else {
       rs_hist_kernel<<<nblk, kRsBlock, 0, stream>>>(kin, n, shift, nblk, items, hist, nullptr);
       int32_t *h = hist;
@@ -208,6 +224,7 @@ static inline int radix_sort_pairs(uint32_t *keys, int32_t *vals, int64_t n, int
       if (rc != SG_OK) return rc;
       rs_scatter_kernel<<<nblk, kRsBlock, lds, stream>>>(kin, vin, n, shift, nblk, items, hist, nullptr,
                                                          kout, vout);
+      if (const int rc = check_launch("radix_sort_pairs(scatter)"); rc != SG_OK) return rc;
     }
     uint32_t *tk = kin; kin = kout; kout = tk;
     int32_t *tv = vin; vin = vout; vout = tv;

@@ -86,6 +86,14 @@ __device__ __forceinline__ float bf16_f32(uint16_t b) {
   return __builtin_bit_cast(float, static_cast<uint32_t>(b) << 16);
 }
 
+// Timing-only what-if builds (tools/build_alt.sh <name> -DSG_WHATIF=<bits>; wrong numbers, never the
+// product): 1 = one weight plane loaded instead of three, 2 = no operand split conversions, 4 = one MFMA
+// per slice instead of six, 8 = no LDS transpose of the gathered lines, 16 = linear rows instead of the
+// gather table.  profiles/r06_conv_whatif.txt is the table they produced.
+#ifndef SG_WHATIF
+#define SG_WHATIF 0
+#endif
+
 constexpr int kTileRows = 32;
 constexpr int kWavesPerWg = 4;
 constexpr int kCk = 16;        // channels per pipeline slice (8 per half-wave)
@@ -477,7 +485,8 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
       // bits times the row pitch lie past the end of the buffer, and an out-of-range buffer load
       // returns 0 (the range check looks at this offset, not at the scalar slice offset added to it).
       for (int q = 0; q < 4; ++q) {
-        const unsigned src = static_cast<unsigned>(c.meta[(8 * q + (lane >> 3)) * p.K + k]);
+        unsigned src = static_cast<unsigned>(c.meta[(8 * q + (lane >> 3)) * p.K + k]);
+        if (SG_WHATIF & 16) src = static_cast<unsigned>(c.pair * 32 + 8 * q + (lane >> 3)) % static_cast<unsigned>(p.M_out);
         const unsigned v_a = __umul24(src, row_pitch) + lane_chunk;
         S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, 0));
       }
@@ -488,10 +497,12 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl)
+          for (int pl = 0; pl < NPL; ++pl) {
+            if ((SG_WHATIF & 1) && pl > 0) { S.b[n][sl * NPL + pl] = S.b[n][sl * NPL]; continue; }
             S.b[n][sl * NPL + pl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
                                                              rs_w, c.v_w + n * 512,
                                                              s_w + sl * (2 * p.Cout * 16) + pl * plane_bytes, 0));
+          }
       return;
     }
     const int src = c.meta[nbr_base + k];
@@ -607,14 +618,14 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 8 * q + (lane >> 3);
-        tr_lds[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = S.a[q];
+        if (!(SG_WHATIF & 8)) tr_lds[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = S.a[q];
       }
       f4 fr[2][2];
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          fr[sl][j] = tr_lds[arow * 8 + ((sl * 4 + ahalf * 2 + j) ^ ((arow >> 1) & 7))];
+          fr[sl][j] = (SG_WHATIF & 8) ? S.a[sl * 2 + j] : tr_lds[arow * 8 + ((sl * 4 + ahalf * 2 + j) ^ ((arow >> 1) & 7))];
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const float af[8] = {fr[sl][0][0], fr[sl][0][1], fr[sl][0][2], fr[sl][0][3],
@@ -628,12 +639,26 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
           continue;
         }
         bf16x8 ah, am, al;
-        split3(af, ah, am, al);
+        if (SG_WHATIF & 2) {
+          ah = __builtin_bit_cast(bf16x8, fr[sl][0]);
+          am = __builtin_bit_cast(bf16x8, fr[sl][1]);
+          al = ah;
+        } else {
+          split3(af, ah, am, al);
+        }
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 0]);
           const bf16x8 bm = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 1]);
           const bf16x8 bl = __builtin_bit_cast(bf16x8, S.b[n][sl * 3 + 2]);
+          if (SG_WHATIF & 4) {
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            const i4 ax = __builtin_bit_cast(i4, al) ^ __builtin_bit_cast(i4, am) ^ __builtin_bit_cast(i4, ah);
+            const i4 bx = __builtin_bit_cast(i4, bh) ^ __builtin_bit_cast(i4, bm) ^ __builtin_bit_cast(i4, bl);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax), __builtin_bit_cast(bf16x8, bx),
+                                                             acc[n], 0, 0, 0);
+            continue;
+          }
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
@@ -713,6 +738,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
   };
 
   // ---- prologue of the workgroup: metadata of its first unit
+  if (static_cast<int>(blockIdx.x) >= num_units) return;      // (grid rounded up to a multiple of 8)
   int round = 0, u = blockIdx.x, buf = 0;
   Unit du = decode(u);
   unsigned ticket = 0;                         // wave 0, lane 0: the last ticket drawn
@@ -1292,9 +1318,14 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   a.magic_nsl = magic(static_cast<unsigned>(a.Cin / v.ck));
   static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
   a.queue = dyn_env ? take_tickets(stream) : nullptr;
+  // grid: the resident workgroups, a multiple of 8 (unit u runs on XCD u % 8 in every round).  A layer
+  // with fewer units than that gets one workgroup per unit, rounded UP to the next multiple of 8 --
+  // the surplus workgroups leave at once.  (Rounded down, as until round 5, 98 units ran on 96
+  // workgroups and two of them took a second unit: the 18-row layers spent 21.5 k instead of 10.5 k
+  // ticks, the 141-row layers 24.5 k instead of 15 k -- profiles/r06_conv_tail.txt.)
   long long g = static_cast<long long>(num_cu) * (b16 ? v.occ_b16 : v.occ);
-  if (g > units) g = units;
   if (g >= 8) g -= g % 8;
+  if (units < g) g = units >= 8 ? (units + 7) / 8 * 8 : units;
   const unsigned ib = static_cast<unsigned>(in_bytes), wb = static_cast<unsigned>(w_bytes);
   if (b16) {
     v.fn_b16<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
@@ -1539,8 +1570,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
     a.queue = dyn_env ? take_tickets(stream) : nullptr;          // (null: static snake, the default)
     long long g = static_cast<long long>(num_cu) * occ;
-    if (g > units) g = units;
     if (g >= 8) g -= g % 8;
+    if (units < g) g = units >= 8 ? (units + 7) / 8 * 8 : units;      // (see launch_persistent_split)
     const unsigned ib_ = static_cast<unsigned>(in_bytes_ll), wb_ = static_cast<unsigned>(w_bytes_ll);
     static const char *trace_env = getenv("SG_CONV_TRACE");     // developer tool: per-wave phase stamps
     if (trace_env) {

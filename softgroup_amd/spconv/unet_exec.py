@@ -38,6 +38,7 @@ class _Desc(C.Structure):
 
 
 _VERSION = operator.attrgetter('_version')
+_DATA_PTR = torch.Tensor.data_ptr
 _desc_lock = threading.Lock()
 _ERR_WORKSPACE = -2     # SG_ERR_WORKSPACE (include/softgroup_hip.h)
 _arena = {}      # (device, stream) -> uint8 tensor, grow-only: concurrent scans on different
@@ -182,12 +183,14 @@ class UNetExecutor:
         return out
 
     def _state_key(self):
-        """(cache epoch, identity of every parameter / buffer, its version counter).  This runs once
-        per forward on ~400 tensors: identities by id() (the tensors a key was made from are kept
-        referenced next to it, so an id cannot be recycled while the key is alive), versions through
-        one C-level map -- 40 us instead of the 80 us of a (version, data_ptr) generator."""
+        """(cache epoch, identity, version counter and storage address of every parameter / buffer).
+        This runs once per forward on ~400 tensors, so each component is one C-level map.  The address
+        is part of the key because `param.data = x` -- which is what nn.Module._apply does for
+        `.to()` / `.cuda()` / `.float()` on ANY submodule -- keeps both the Parameter's id and its
+        version counter: without it a moved storage went unnoticed and the cached
+        descriptor kept raw pointers into the old one."""
         ts = self._tensors()
-        return (core.cache_epoch(), tuple(map(id, ts)), tuple(map(_VERSION, ts))), ts
+        return (core.cache_epoch(), tuple(map(id, ts)), tuple(map(_VERSION, ts)), tuple(map(_DATA_PTR, ts))), ts
 
     def _descriptor(self):
         with _desc_lock:          # concurrent scans share the executor: build the descriptor once

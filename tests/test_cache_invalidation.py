@@ -74,3 +74,22 @@ def test_executor_declines_channel_counts_that_are_not_multiples_of_4():
     assert UNetExecutor(ok.unet, ok.input_conv, ok.output_layer)._supported()
     odd = SoftGroup(**dict(synthetic.SCANNET_MODEL_CFG, channels=6))
     assert not UNetExecutor(odd.unet, odd.input_conv, odd.output_layer)._supported()
+
+
+def test_executor_key_sees_a_submodule_apply_that_moves_storage():
+    """`param.data = x` (nn.Module._apply on a SUBMODULE: .double().float(),
+    .cuda()) keeps the Parameter's id and version counter; the storage address in the key catches it."""
+    from softgroup_amd.spconv.unet_exec import UNetExecutor
+    m = _model().eval()
+    ex = UNetExecutor(m.unet, m.input_conv, m.output_layer)
+    k0, ts0 = ex._state_key()
+    k1, _ = ex._state_key()
+    assert k0 == k1
+    e0 = core.cache_epoch()
+    bn = m.output_layer[0]
+    ids, vers = id(bn.weight), bn.weight._version
+    bn.double().float()                                # submodule only: SoftGroup._apply is not involved
+    assert core.cache_epoch() == e0 and id(bn.weight) == ids and bn.weight._version == vers
+    k2, _ = ex._state_key()
+    assert k2 != k0, 'a storage move under an unchanged Parameter object must change the key'
+    del ts0

@@ -168,6 +168,61 @@ def test_panoptic_fusion_on_the_device_equals_the_reference_loop():
     assert (out_nat['panoptic_preds'] >> 16).max() > 3, 'sweep must paste several instances'
 
 
+def test_panoptic_fusion_dense_walk_equals_sparse_walk(monkeypatch):
+    """the dense walk (rows above 1 M points, or SG_PANOPTIC_DENSE) had lost its
+    `++next_id`.  Both walks over the same random, overlapping bit rows: identical words; the rows are
+    also replayed on the host with the reference's loop (softgroup.py:606-639)."""
+    from softgroup_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(7)
+    n, n_inst = 5000, 40
+    words = (n + 31) // 32
+    masks = np.zeros((n_inst, n), bool)
+    for k in range(n_inst):
+        a = int(rng.integers(0, n - 400))
+        masks[k, a:a + int(rng.integers(50, 400))] = True
+        masks[k] &= rng.random(n) < 0.8
+    bits = np.zeros((n_inst, words), np.uint32)
+    for k in range(n_inst):
+        idx = np.nonzero(masks[k])[0]
+        np.bitwise_or.at(bits[k], idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+    order = rng.permutation(n_inst).astype(np.int32)
+    labels = rng.integers(1, 9, n_inst).astype(np.int32)
+    sem = rng.integers(0, 19, n).astype(np.int64)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    bits_d, order_d, lab_d, sem_d = d(bits.view(np.int32)), d(order), d(labels), d(sem)
+
+    def run():
+        out = torch.empty(n, dtype=torch.int32, device='cuda')
+        ws = torch.empty(lib.sg_panoptic_fusion_workspace_bytes(n_inst, n), dtype=torch.uint8, device='cuda')
+        L.check(lib.sg_panoptic_fusion(L.ptr(bits_d), n_inst, n, L.ptr(order_d), L.ptr(lab_d), L.ptr(sem_d), 10, 0.5,
+                                       19, 11, L.ptr(out), L.ptr(ws), ws.numel(), L.stream()), 'sg_panoptic_fusion')
+        return out.cpu().numpy().view(np.uint32)
+
+    monkeypatch.delenv('SG_PANOPTIC_DENSE', raising=False)
+    sparse = run()
+    monkeypatch.setenv('SG_PANOPTIC_DENSE', '1')
+    dense = run()
+    # the reference's loop on the host
+    want = sem.astype(np.uint32).copy()
+    ids = np.zeros(n, np.uint32)
+    taken = np.zeros(n, bool)
+    nid = 1
+    for k in order:
+        m = masks[k]
+        if (m & taken).sum() / (m.sum() + 1e-5) > 0.5:
+            continue
+        paste = m & ~taken
+        want[paste], ids[paste] = labels[k] + 10, nid
+        taken |= paste
+        nid += 1
+    exp = (want & 0xFFFF) | (ids << 16)
+    exp[(want >= 11) & (ids == 0)] = 19
+    assert nid > 5
+    np.testing.assert_array_equal(sparse, exp)
+    np.testing.assert_array_equal(dense, exp)
+
+
 def test_panoptic_fusion_skips_overlapping_instances():
     """hand-made bit rows: the second instance overlaps the first by more than skip_iou and is
     skipped, the third is pasted on its free points only"""
