@@ -696,6 +696,92 @@ int sg_scan_instances(const sg_instances_cfg *cfg, const int32_t *proposals_idx,
                       sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One scan = one call (csrc/scan_forward.hip): the whole of SoftGroup.forward_test
+ * (softgroup/model/softgroup.py:299-361) for the plain SoftGroup configuration -- voxel feature pooling
+ * (:305), backbone (:307-309 -> forward_backbone :363-378), point-wise heads + arg-max, softmax of the
+ * semantic scores, grouping head and proposal voxelisation (:411-480, :655-709), tiny U-Net (:671-675),
+ * mask / class / IoU heads (:676-686), instance extraction + RLE text (:537-604) and the dense per-point
+ * results of get_point_wise_results / get_gt_instances (:641-653) -- chained on the caller's stream with
+ * nothing but kernel launches and the data-dependent read-backs in between.  The reference runs one scan
+ * per process at a time from its test loop (tools/test.py:145-150); a host thread that makes this ONE call
+ * holds no interpreter lock while the scan runs.  Same kernels and entry points as the calls above
+ * (sg_voxelize_fp's arithmetic, sg_unet_forward, sg_pointwise_heads, sg_scan_grouping, sg_scan_instances);
+ * the dense heads of the refinement (nn.Linear / MLP on <= a few thousand rows) are fp32 FMA chains in
+ * ascending channel order like sg_pointwise_heads.
+ *   arena: device scratch, carved in call order; SG_ERR_WORKSPACE + result->arena_needed when too small.
+ *   host_dense / host_inst: PINNED host memory for the dense results and for sg_scan_instances' image.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sg_linear {            /* nn.Linear: w [out][in], b [out] */
+  const float *w, *b;
+  int out, in;
+} sg_linear;
+/* row-wise softmax with torch's arithmetic for rows of <= 32 columns (softmax_warp_forward: maximum,
+ * exp(x - max) by expf, the sum as a 32-lane butterfly -- offsets 16, 8, 4, 2, 1 -- and one division per
+ * element): bit-identical to tensor.softmax(-1) on this build (tests/test_scan_forward_gpu.py) */
+int sg_softmax_rows(const float *x, int64_t rows, int cols, float *out, sg_stream_t stream);
+/* out[r, :] = mlp(feats[idx[r], :]) (idx NULL: identity); channels 16 or 32, mlp->out <= 32 */
+int sg_mlp_rows(const float *feats, const int32_t *idx, int64_t rows, int channels, const sg_mlp2 *mlp,
+                float *out, sg_stream_t stream);
+/* out[r, j] = b[j] + sum_c x[r, c] * w[j, c], ascending c (fmaf chain) */
+int sg_linear_rows(const float *x, int64_t rows, const sg_linear *lin, float *out, sg_stream_t stream);
+
+#define SG_SCAN_DENSE_MAX 16
+typedef struct sg_scan_dense_item {
+  int kind;            /* 0 = `ptr`/`bytes` (a device buffer passed through to the host block),
+                          1 = semantic_preds int64 [N], 2 = offset_preds f32 [N,3],
+                          3 = gt_instances int64 [N] (softgroup.py:641-653 from semantic_labels / instance_labels),
+                          4 = semantic_scores f32 [N, n_sem] (the logits) */
+  const void *ptr;
+  size_t bytes;
+} sg_scan_dense_item;
+typedef struct sg_scan_desc {
+  const sg_unet_desc *backbone;       /* input_conv + unet + output_layer */
+  const sg_unet_desc *tiny;           /* tiny_unet + tiny_unet_outputlayer */
+  sg_mlp2 semantic, offset, mask;     /* semantic_linear, offset_linear, mask_linear */
+  sg_linear cls, iou;                 /* cls_linear, iou_score_linear */
+  int channels;                       /* backbone output channels: 16 or 32 */
+  int with_coords;                    /* voxel features = [feats | coords_float] */
+  int semantic_classes, instance_classes;
+  sg_grouping_cfg grouping;           /* n_points / batch_size / feat_channels are filled per call */
+  float cls_score_thr, mask_score_thr;
+  int min_npoint;
+  int want_instances;                 /* 0: stop after the point-wise heads */
+} sg_scan_desc;
+typedef struct sg_scan_input {        /* one collated batch, device pointers (data/custom.py:240-256) */
+  int n_points, n_voxels, max_active; /* p2v_map is int32 [n_voxels, 1 + max_active] */
+  int batch_size;
+  int spatial_shape[3];
+  const float *feats;                 /* f32 [N, feat_dim] */
+  int feat_dim;
+  const float *coords_float;          /* f32 [N, 3] */
+  const int32_t *p2v_map;
+  const void *v2p_map;                /* [N] int32 or int64 */
+  int v2p_is_int64;
+  const void *voxel_coords;           /* [M, 4] int32 or int64 */
+  int voxel_coords_is_int64;
+  const int32_t *batch_idxs;          /* int32 [N] */
+  const int64_t *semantic_labels, *instance_labels;   /* for dense kind 3 (may be NULL) */
+  int n_dense;
+  sg_scan_dense_item dense[SG_SCAN_DENSE_MAX];
+} sg_scan_input;
+typedef struct sg_scan_result {       /* host */
+  sg_grouping_result grouping;        /* counts; its offsets are relative to `grouping_base` */
+  sg_instances_result instances;      /* offsets into host_inst / relative to `instances_base` */
+  size_t grouping_base, instances_base;               /* arena offsets of the two stages' sub-arenas */
+  size_t dense_offset[SG_SCAN_DENSE_MAX];             /* byte offsets into host_dense */
+  size_t dense_bytes;                                 /* bytes of host_dense in use */
+  /* arena offsets of the stage outputs (device; valid until the next call on this arena) */
+  size_t voxel_feats_in, backbone_out, output_feats, semantic_scores, semantic_prob, pt_offsets,
+      semantic_preds, tiny_out, mask_scores, cls_scores, cls_prob, iou_scores;
+  size_t arena_used, arena_needed, host_dense_needed, host_inst_needed;
+  int stage;                          /* how far the call got: 1 heads, 2 grouping, 3 refinement, 4 instances */
+} sg_scan_result;
+size_t sg_scan_arena_bytes(const sg_scan_desc *desc, int n_points, int n_voxels);
+int sg_scan_forward(const sg_scan_desc *desc, const sg_scan_input *in, void *arena, size_t arena_bytes,
+                    void *host_dense, size_t host_dense_bytes, void *host_inst, size_t host_inst_bytes,
+                    sg_scan_result *result_host, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Evaluation (ScanNetEval.assign_instances_for_scan, softgroup/evaluation/instance_eval.py:228-309):
  * counts[p*n_slots + s] = number of points of prediction p's mask whose ground-truth slot is s.
  * Masks come as runs: run r covers points run_start[r] .. run_start[r] + len(r) - 1 of prediction

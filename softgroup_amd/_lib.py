@@ -100,6 +100,11 @@ SIGNATURES = {
     'sg_panoptic_fusion': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.c_double, _i, _i, _vp, _vp, _sz, _vp]),
     'sg_scan_grouping': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'sg_scan_instances': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    'sg_softmax_rows': (_i, [_vp, _i64, _i, _vp, _vp]),
+    'sg_mlp_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    'sg_linear_rows': (_i, [_vp, _i64, _vp, _vp, _vp]),
+    'sg_scan_arena_bytes': (_sz, [_vp, _i, _i]),
+    'sg_scan_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     'sg_eval_intersections': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
     'sg_bn_relu_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     'sg_gather_rows_f32': (_i, [_vp, _vp, _i64, _i, _vp, _vp]),

@@ -28,6 +28,7 @@ SOURCES = [
     ('unet_train.hip', ['-ffp-contract=off']),
     ('instances.hip', ['-ffp-contract=off']),
     ('scan_exec.hip', ['-ffp-contract=off']),
+    ('scan_forward.hip', ['-ffp-contract=off']),
     ('heads.hip', ['-ffp-contract=off']),
     ('eval_ops.hip', ['-ffp-contract=off']),
     ('host_ops.cpp', ['-ffp-contract=off']),

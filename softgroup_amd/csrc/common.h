@@ -152,5 +152,6 @@ extern thread_local int t_conv_arith;
 // per-(device, stream) runtime state of the conv launches / the executors' index builds (sg_stream_release)
 void conv_release_stream(int dev, hipStream_t stream);
 void unet_release_stream(int dev, hipStream_t stream);
+void scan_release_stream(int dev, hipStream_t stream);
 
 }  // namespace sg

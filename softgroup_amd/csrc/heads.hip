@@ -15,34 +15,9 @@
 // (Tried: two points per thread, every scalar-loaded weight feeding two FMAs: 207 VGPRs, 81 us instead of
 // 58 us per 150 000 points -- the second wave per SIMD is worth more than the halved weight loads.)
 #include "common.h"
+#include "heads.h"
 
 namespace sg {
-
-struct Mlp2 {
-  const float *w1, *b1, *scale, *shift, *w2, *b2;   // w1 [C][C], w2 [out][C] (nn.Linear layout: [out, in])
-  int out;
-};
-
-template <int C, int OUT_MAX>
-__device__ __forceinline__ void mlp2(const float (&x)[C], const Mlp2 &m, float (&y)[OUT_MAX]) {
-  float h[C];
-#pragma unroll
-  for (int o = 0; o < C; ++o) {
-    float a = m.b1[o];
-#pragma unroll
-    for (int c = 0; c < C; ++c) a = fmaf(x[c], m.w1[o * C + c], a);
-    h[o] = fmaxf(fmaf(a, m.scale[o], m.shift[o]), 0.f);
-  }
-#pragma unroll
-  for (int o = 0; o < OUT_MAX; ++o) {
-    if (o < m.out) {       // uniform
-      float a = m.b2[o];
-#pragma unroll
-      for (int c = 0; c < C; ++c) a = fmaf(h[c], m.w2[o * C + c], a);
-      y[o] = a;
-    }
-  }
-}
 
 template <int C, int SEM_MAX, typename IdxT>
 __global__ void __launch_bounds__(256) pointwise_heads_kernel(const float *__restrict__ vox, const IdxT *__restrict__ v2p,

@@ -388,6 +388,11 @@ static int read_back(int32_t *host, const int32_t *dev, int words, hipStream_t s
     return SG_ERR_WORKSPACE;                                                                      \
   }
 
+// sg_scan_forward (scan_forward.hip) starts the dense results' device-to-host copy from here: called once,
+// on the calling thread, right before the ordered emission (one workgroup per cluster: the chip is idle)
+thread_local void (*t_scan_emit_hook)(void *) = nullptr;
+thread_local void *t_scan_emit_ctx = nullptr;
+
 }  // namespace sg
 
 using namespace sg;
@@ -460,6 +465,7 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
   SG_TAKE(pairs, int32_t, 2 * static_cast<size_t>(S));
   SG_TAKE(poff, int32_t, static_cast<size_t>(n_prop) + 1);
   hipMemsetAsync(poff, 0, sizeof(int32_t) * (n_prop + 1), stream);
+  if (t_scan_emit_hook != nullptr) t_scan_emit_hook(t_scan_emit_ctx);
   SG_TRY(sg_bfs_cluster_emit(bq_idx, start_len, n_sel, n_active, seg_of, cfg->seg_thr, n_prop, S, pairs, poff,
                              bfs_ws, bfs_bytes, stream_));
   proposal_map_kernel<<<grid_for(S, 256), 256, 0, stream>>>(pairs, S, obj);

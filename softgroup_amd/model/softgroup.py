@@ -55,6 +55,7 @@ def _retire_pool(pool, wait=True):
     if not wait:
         return
     from . import native_scan as NS
+    from . import scan_forward as SF
     from ..spconv import unet_exec as UE
     from .. import _lib as L
     for dev, st in getattr(pool, '_sg_streams', ()):
@@ -62,6 +63,7 @@ def _retire_pool(pool, wait=True):
             st.synchronize()
             raw = st.cuda_stream
             NS.release_stream(raw)
+            SF.release_stream(raw)
             UE.release_stream(raw)
             L.check(L.lib().sg_stream_release(raw), 'sg_stream_release')
     pool._sg_streams = []
@@ -116,6 +118,7 @@ class SoftGroup(nn.Module):
         self.use_train_executor = os.environ.get('SG_TRAIN_EXEC', '1') != '0'
         self.scan_result_hook = None      # callable(result dict) run by the scan worker before the result is handed back (scan_contexts > 1)
         self.use_fused_heads = os.environ.get('SG_FUSED_HEADS', '1') != '0'   # devoxelize + point-wise heads + arg-max as one kernel (inference)
+        self.use_scan_forward = os.environ.get('SG_SCAN_FORWARD', '1') != '0'   # the whole scan as ONE C call (csrc/scan_forward.hip)
         self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
@@ -167,7 +170,7 @@ class SoftGroup(nn.Module):
 
     # ---- derived state (packed weights, BatchNorm affines, native-executor descriptors, the
     #      results stream) is rebuilt on demand and never copied / pickled with the module
-    _DERIVED = ('_backbone_exec', '_tiny_exec', '_backbone_train_exec', '_tiny_train_exec', '_results_stream',
+    _DERIVED = ('_scan_forward', '_backbone_exec', '_tiny_exec', '_backbone_train_exec', '_tiny_train_exec', '_results_stream',
                 '_grouping_const', '_scan_pool')
 
     def invalidate_caches(self):
@@ -264,6 +267,25 @@ class SoftGroup(nn.Module):
                      semantic_labels, instance_labels, pt_offset_labels, spatial_shape, batch_size,
                      scan_ids, _inline_results=False, **kwargs):
         tcfg = self.test_cfg
+        # ---- the whole scan as ONE C call (csrc/scan_forward.hip) where the configuration allows: plain
+        #      SoftGroup grouping, fp32 inference, no panoptic fusion; anything else takes the stages below
+        tasks = _cfg(tcfg, 'eval_tasks')
+        if feats.is_cuda and 'panoptic' not in tasks:
+            sf = self.__dict__.get('_scan_forward')
+            if sf is None:
+                from .scan_forward import ScanForward
+                sf = self.__dict__['_scan_forward'] = ScanForward(self)
+            if sf.usable(self, tasks, _cfg(tcfg, 'lvl_fusion', False), _cfg(tcfg, 'x4_split', False)):
+                want = not self.semantic_only and 'instance' in tasks
+                out = sf(self, dict(feats=feats, coords_float=coords_float, p2v_map=p2v_map, v2p_map=v2p_map,
+                                    voxel_coords=voxel_coords, batch_idxs=batch_idxs, semantic_labels=semantic_labels,
+                                    instance_labels=instance_labels, pt_offset_labels=pt_offset_labels,
+                                    spatial_shape=spatial_shape, batch_size=batch_size, scan_ids=scan_ids),
+                         tasks, want)
+                if out is not None:
+                    ret = LazyResults(scan_id=scan_ids[0])
+                    ret.update(out)
+                    return ret
         color_feats = feats
         if self.with_coords:
             feats = torch.cat((feats, coords_float), 1)

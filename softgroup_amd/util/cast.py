@@ -159,6 +159,22 @@ def to_host_end(handle):
     return {k: out[k] for k in keys}
 
 
+def adopt_pinned_block(stage):
+    """numpy view of a pinned uint8 tensor that a C call has filled (sg_scan_forward's dense results), under
+    the same accounting as to_host_end: a view of the pinned block while fewer than SG_PINNED_RESULTS_MB of
+    such blocks are alive, a pageable copy beyond"""
+    nbytes = stage.numel()
+    with _pinned_lock:
+        keep_pinned = _pinned_live[0] + nbytes <= _PINNED_CAP
+        if keep_pinned:
+            _pinned_live[0] += nbytes
+    block = stage.numpy()
+    if keep_pinned:
+        weakref.finalize(block, _unpin, nbytes)
+        return block
+    return block.copy()
+
+
 def to_host(tensors):
     """dict of tensors -> dict of numpy arrays.  All CUDA tensors are packed on the device by ONE cat
     kernel and travel in ONE device-to-host copy into a pinned staging block (torch's caching host
