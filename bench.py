@@ -1037,9 +1037,23 @@ def main():
         torch.cuda.synchronize()
         ms, nl = _lib.C.c_double(0), _lib.C.c_int(0)
         _lib.check(lib.sg_spconv_profile_read(_lib.C.byref(ms), _lib.C.byref(nl)), 'sg_spconv_profile_read')
+        # one event pair per LAUNCH: a layer launched by itself (dims = M_out, K, Cin, Cout, input rows) or a
+        # multi-layer launch of the deep levels / the tiny U-Net (conv_chain_kernel; dims[0] = -(conv layers
+        # with K > 1 it carried), its 1x1 convs and skip concats are inside its time as well)
+        import numpy as np
+        d_ms = np.zeros(max(nl.value, 1), np.float32)
+        d_dims = np.zeros((max(nl.value, 1), 5), np.int32)
+        calls = _lib.C.c_int(0)
+        _lib.check(lib.sg_spconv_profile_detail(d_ms.ctypes.data, d_dims.ctypes.data, int(nl.value), _lib.C.byref(calls)),
+                   'sg_spconv_profile_detail')
         _lib.check(lib.sg_spconv_profile(0), 'sg_spconv_profile')
-        assert nl.value == s['launches'] * n_pass, (nl.value, s['launches'])
-        s = dict(launches=nl.value, ms=ms.value, bytes=s['bytes'] * n_pass, flops=s['flops'] * n_pass)
+        chained = d_dims[:nl.value, 0] < 0
+        layers = int(np.where(chained, -d_dims[:nl.value, 0], 1).sum())
+        assert layers == s['launches'] * n_pass, (layers, nl.value, s['launches'])
+        chain_info = {'launches_per_scan': int(chained.sum()) // n_pass,
+                      'layers_per_scan': int(-d_dims[:nl.value, 0][chained].sum()) // n_pass,
+                      'ms_per_scan': round(float(d_ms[:nl.value][chained].sum()) / n_pass, 3)}
+        s = dict(launches=nl.value, ms=ms.value, bytes=s['bytes'] * n_pass, flops=s['flops'] * n_pass, layers=layers)
         gbps = s['bytes'] / (s['ms'] * 1e-3) / 1e9
         tflops = s['flops'] / (s['ms'] * 1e-3) / 1e12
         launches = max(s['launches'], 1)
@@ -1082,14 +1096,18 @@ def main():
         bound = 'mfma' if issued['frac'] >= hbm['frac'] else 'hbm'
         bound_rec = hbm if bound == 'hbm' else {k: issued[k] for k in ('achieved', 'peak', 'unit', 'frac')}
         out['roofline'] = {
-            'kernel': 'gather_conv_persistent_kernel (SubM/strided/inverse sparse conv; fp32 products as six '
-                      'bf16 MFMAs on split operands, fp32 accumulate; bound = the larger of B_gs / 8 TB/s and '
-                      'issued MFMA flops / the peak of the pipe they issue on)',
+            'kernel': 'gather_conv_persistent_kernel + conv_chain_kernel (the same layer body: SubM/strided/inverse '
+                      'sparse conv, one launch per layer on the big levels, one launch per <= 22 layers on the deep '
+                      'levels and the tiny U-Net; fp32 products as six bf16 MFMAs on split operands, fp32 accumulate; '
+                      'bound = the larger of B_gs / 8 TB/s and issued MFMA flops / the peak of the pipe they issue on; '
+                      'achieved = algorithmic bytes of ALL conv layers / summed duration of ALL conv launches)',
             'mfma_issued': issued,
             'mfma_fp32_equivalent': mfma,
             'bound': bound, **bound_rec,
             'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_scan': s['launches'] // n_pass,
+            'layers_per_scan': s['layers'] // n_pass,
+            'multi_layer_launches': chain_info,
             'kernel_ms_per_scan': round(s['ms'] / n_pass, 3),
             'avg_launch_us': round(s['ms'] * 1e3 / launches, 2),
             'algorithmic_bytes_per_launch': s['bytes'] // launches,

@@ -376,6 +376,17 @@ int sg_spconv_set_arithmetic(int mode);
  * same order, identical results; -1 = back to the environment (SG_CONV_COMBINE). */
 int sg_spconv_set_combine(int mode);
 
+/* Multi-layer conv launches ("conv chain", csrc/spconv_conv.hip): inside sg_unet_forward the layers of
+ * the U-Net levels with at most SG_CONV_CHAIN_ROWS rows (default 6144) -- softgroup/model/blocks.py:82-143
+ * from the strided conv into such a level down to the deepest level and back up, and a whole U-Net that
+ * is that small (the tiny U-Net, softgroup/model/softgroup.py:93-95) -- run as ONE persistent launch per
+ * <= 22 layers, with a grid barrier between two layers, instead of one launch per layer.  mode 1 = on
+ * (the default), 0 = every layer its own launch (same decomposition, bit-identical results), -1 = back
+ * to the environment (SG_CONV_CHAIN).  Process-wide, not thread-safe: tests and A/B measurements.
+ * sg_spconv_chain_stats: chain launches and the steps (layers, concats) they carried since process start. */
+int sg_spconv_set_chain(int mode);
+int sg_spconv_chain_stats(int64_t *launches, int64_t *steps);
+
 /* Measurement hook (bench.py roofline): while enabled, every sg_spconv_gather_conv_f32 call -- from
  * Python or from inside sg_unet_forward -- is bracketed by a HIP event pair on its launch stream.
  * sg_spconv_profile_read waits for the events and returns the summed kernel time and the number of

@@ -144,11 +144,13 @@ def parity_report(model, batch, cfg, end_to_end=True, timed_path=False):
     rep['ok'] = bool(rep['float_stages_within_tol'] and rep['proposals_equal'] and rep['instances_equal'])
     if native is not None:
         # the timed call against (a) the operator path it is claimed equal to, (b) the oracle
-        rep['checked_call'] = 'model(batch): native scan driver + U-Net executor (the timed region\'s call)'
-        rep['timed_path_instances_equal_operator_path'] = bool(
-            len(native['pred_instances']) == len(g['preds']) and
-            all(a['label_id'] == c['label_id'] and a['conf'] == c['conf'] and a['pred_mask'] == c['pred_mask']
-                for a, c in zip(native['pred_instances'], g['preds'])))
+        rep['checked_call'] = 'model(batch): sg_scan_forward, one C call per scan (the timed region\'s call)'
+        # labels and RLE strings identical; confidences within 1e-6 (the timed call's class / IoU heads are
+        # fp32 FMA chains, sg_linear_rows, the operator path's a GEMM library: rounding order only)
+        rep['timed_path_instances_equal_operator_path'] = _instances_equal(native['pred_instances'], g['preds'])
+        if len(native['pred_instances']) == len(g['preds']) and len(g['preds']):
+            rep['timed_path_max_abs_conf_vs_operator_path'] = float(max(
+                abs(float(a['conf']) - float(c['conf'])) for a, c in zip(native['pred_instances'], g['preds'])))
         rep['timed_path_semantic_preds_equal_operator_path'] = bool(
             np.array_equal(native['semantic_preds'], n(g['sem']).argmax(1)))
         ok_no, rep['timed_path_max_abs_offsets_vs_oracle'] = _close(native['offset_preds'], off)

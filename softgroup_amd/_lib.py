@@ -64,6 +64,8 @@ SIGNATURES = {
     'sg_spconv_plan': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sg_spconv_set_arithmetic': (_i, [_i]),
     'sg_spconv_set_combine': (_i, [_i]),
+    'sg_spconv_set_chain': (_i, [_i]),
+    'sg_spconv_chain_stats': (_i, [_vp, _vp]),
     'sg_spconv_profile': (_i, [_i]),
     'sg_spconv_profile_read': (_i, [_vp, _vp]),
     'sg_spconv_profile_detail': (_i, [_vp, _vp, _i, _vp]),

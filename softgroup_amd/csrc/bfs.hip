@@ -55,6 +55,14 @@ inline bool big_fast_on() {
   const char *e = getenv("SG_BFS_BIG_FAST");
   return !(e && atoi(e) == 0);
 }
+// SG_BFS_THIN=1 (developer knob, read per call): single-wave replay of thin levels in bfs_emit_kernel.
+// Off by default: measured SLOWER than the workgroup-wide FAST levels (bfs_emit_kernel 520 us against
+// ~360 us on the bench scene, one scan 5.01 against 4.78 ms; profiles/r06_bfs_thin_ab.txt) -- one wave
+// walking the frontier's nodes with readlane loops costs more than the seven barriers it saves.
+inline bool thin_levels_on() {
+  const char *e = getenv("SG_BFS_THIN");
+  return e && atoi(e) != 0;
+}
 inline size_t big_stage_entries(int n) {
   return n > kBigClusterMin && big_fast_on() ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
 }
@@ -372,6 +380,9 @@ __device__ __forceinline__ int wg_excl_scan(int v, int *lds, int *total) {
 constexpr int kOwnCap = 16384;     // cluster sizes up to this keep their claim array in LDS (64 KB)
 constexpr int kFrontChunk = 1024;  // frontier nodes staged per chunk (st, len, edge base, winners)
 constexpr int kE2 = 4096;           // edges of a fast level (slot, list start/len, edge id cached in LDS: 48 KB)
+constexpr int kThinIter = 8;        // edges per lane of a thin level (one wave)
+constexpr int kThinEdges = 64 * kThinIter;
+static_assert(kThinEdges <= kFrontChunk, "a thin level's winners must fit the LDS frontier");
 
 // One workgroup per kept cluster.  The output segment doubles as the FIFO queue (column 1 of
 // cluster_idxs).  Per BFS level:
@@ -394,7 +405,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
     int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats, int skip_above, int only_above,
-    const int32_t *gate /* null, or a word that must be non-zero for the launch to do anything */) {
+    const int32_t *gate /* null, or a word that must be non-zero for the launch to do anything */,
+    bool thin_on /* thin levels on one wave (SG_BFS_THIN=0: the workgroup-wide FAST path only) */) {
   if (gate != nullptr && SG_LD(gate) == 0) return;
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
@@ -404,6 +416,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
   __shared__ int e_st[kE2], e_g[kE2];      //   target list start, global edge index
   __shared__ unsigned short e_ln[kE2];     //   target list length
   __shared__ int pf_sink[kEmitThreads];    // landing zone of the edge-record prefetches (never read)
+  __shared__ unsigned char thin_map[kThinEdges];   // thin levels: frontier node of every edge
+  __shared__ int thin_state[8];                    // what a thin run hands back to the workgroup
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned pf_dst = __builtin_amdgcn_readfirstlane(
       static_cast<unsigned>(reinterpret_cast<uintptr_t>(pf_sink + wave * 64)));
@@ -456,8 +470,110 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     };
     int cur = 0;            // which f_st/f_ln buffer holds the current frontier (if any)
     bool in_lds = true;     // frontier (start,len) of this level already in f_st/f_ln[cur]?
+    bool thin_ok = thin_on; // (false right after a thin run that stopped at a level it does not take)
     while (head < tail) {
       const int L = tail - head;
+      // ---------------- THIN levels: a run of them on ONE wave ----------------
+      // The bench scene's clusters are ~1 000 points over ~100 levels: a level is ~10 frontier nodes and
+      // a few hundred edges, and the FAST path below spends its 2.9 us per level on seven workgroup
+      // barriers and three 8-wave scans around ONE memory round trip.  While the frontier has <= 64
+      // nodes and <= kThinEdges edges, wave 0 replays level after level by itself -- scan by DPP, the
+      // edge -> node map and the claims in LDS (operations of one wave reach the LDS in order: no
+      // barrier), winners by ballot -- and the other seven waves wait at ONE barrier for the whole run.
+      // Same claims (atomicMin of the edge rank on the target's slot), same winners, same order.
+      if (thin_ok && own_in_lds && in_lds && L <= 64) {
+        if (wave == 0) {
+          int h = head, t = tail, cu = cur, cl = conv_lo, levels = 0, edges = 0;
+          while (true) {
+            const int Lw = t - h;
+            if (Lw <= 0 || Lw > 64) break;
+            const int ln = lane < Lw ? f_ln[cu][lane] : 0;
+            const int incl = wave_incl_scan(ln);
+            const int E = __builtin_amdgcn_readlane(incl, 63);
+            if (E > kThinEdges) break;
+            const int eb = incl - ln;
+            if (lane < Lw) f_eb[lane] = eb;
+            for (int q = 0; q < Lw; ++q) {                  // edge -> frontier node
+              const int ln_q = __builtin_amdgcn_readlane(ln, q), eb_q = __builtin_amdgcn_readlane(eb, q);
+              for (int p = lane; p < ln_q; p += 64) thin_map[eb_q + p] = static_cast<unsigned char>(q);
+            }
+            int2 r[kThinIter];
+            int g[kThinIter];
+#pragma unroll
+            for (int j = 0; j < kThinIter; ++j) {           // every edge record of the level in flight at once
+              const int e = j * 64 + lane;
+              g[j] = 0;
+              r[j] = make_int2(0xffff, 0);
+              if (e < E) {
+                const int q = thin_map[e];
+                g[j] = f_st[cu][q] + (e - f_eb[q]);
+                r[j] = erec[g[j]];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < kThinIter; ++j) {           // claims
+              const int e = j * 64 + lane;
+              const int slot = r[j].x & 0xffff;
+              if (e < E && slot != 0xffff) {
+                const int cur_owner = own_lds[slot];
+                if (cur_owner > e) atomicMin(&own_lds[slot], e);
+                if (cur_owner >= 0) {                       // candidate of the next frontier: its records' lines
+                  const int tl = r[j].x >> 16;
+                  const char *first = reinterpret_cast<const char *>(erec + r[j].y);
+                  const char *last = reinterpret_cast<const char *>(erec + r[j].y + max(tl, 1) - 1);
+                  const uintptr_t l0 = reinterpret_cast<uintptr_t>(first) & ~static_cast<uintptr_t>(127);
+                  const int nlines = static_cast<int>(((reinterpret_cast<uintptr_t>(last) & ~static_cast<uintptr_t>(127)) - l0) >> 7) + 1;
+                  for (int k = 0; k < 4; ++k)
+                    if (k < nlines) lds_prefetch_b32(reinterpret_cast<const void *>(l0 + 128u * k), pf_dst);
+                }
+              }
+            }
+            const int nxt = cu ^ 1;
+            int t_new = 0;
+#pragma unroll
+            for (int j = 0; j < kThinIter; ++j) {           // winners in edge order: j major, lane minor
+              const int e = j * 64 + lane;
+              const int slot = r[j].x & 0xffff;
+              const bool win = e < E && slot != 0xffff && own_lds[slot] == e;
+              const uint64_t bal = __ballot(win);
+              if (win) {
+                const int oo = t_new + mask_prefix(bal);
+                SG_ST(&Q[2 * (t + oo)], c);
+                SG_ST(&Q[2 * (t + oo) + 1], g[j]);          // edge index; point id = idx[edge]
+                f_st[nxt][oo] = r[j].y;                     // (t_new <= E <= kThinEdges <= kFrontChunk)
+                f_ln[nxt][oo] = r[j].x >> 16;
+                own_lds[slot] = -1;
+              }
+              t_new += __popcll(bal);
+            }
+            if (cl < 0 && t_new > 0) cl = t;
+            h = t;
+            t += t_new;
+            cu = nxt;
+            ++levels;
+            edges += E;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the queue entries are out before anyone reads them
+          if (lane == 0) {
+            thin_state[0] = h; thin_state[1] = t; thin_state[2] = cu; thin_state[3] = cl;
+            thin_state[4] = levels; thin_state[5] = edges;
+          }
+        }
+        __syncthreads();
+        const int levels = thin_state[4];
+        head = thin_state[0];
+        tail = thin_state[1];
+        cur = thin_state[2];
+        conv_lo = thin_state[3];
+        n_fast += levels;
+        sum_e += thin_state[5];
+        max_l = max(max_l, L);
+        __syncthreads();            // (thin_state is rewritten by the next run)
+        in_lds = true;              // a thin level's winners (<= kThinEdges) always fit the LDS frontier
+        thin_ok = false;            // the level the run stopped at is for the paths below
+        if (levels > 0) continue;
+      }
+      thin_ok = thin_on;
       // ---------------- FAST level ----------------
       // Flat over the level's edges: thread t owns edges t, t + 512, ... of the concatenated lists
       // (edge -> (frontier node, position) by a binary search over the nodes' edge bases in LDS),
@@ -1250,7 +1366,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
-      stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr);
+      stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr, thin_levels_on());
   if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
     static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 16;   // developer knob
     const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
@@ -1275,7 +1391,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
                                                                         sync + 1, w.owner);
       bfs_emit_kernel<<<min(n_cluster, 256), kEmitThreads, 0, stream>>>(
           bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner,
-          cluster_idxs, nullptr, 0x7fffffff, kBigMin, sync + 1);
+          cluster_idxs, nullptr, 0x7fffffff, kBigMin, sync + 1, thin_levels_on());
     }
   }
   if (want_stats) {

@@ -149,6 +149,16 @@ inline void fill_many(const FillList &f, hipStream_t stream) {
 
 // conv arithmetic requested by the calling thread (spconv_conv.hip); -1 = none
 extern thread_local int t_conv_arith;
+// multi-layer conv launches (spconv_conv.hip, "conv chain"): between _begin and _end on the calling thread
+// sg_spconv_gather_conv_f32 records the layers the chain kernel takes instead of launching them
+void conv_chain_begin(hipStream_t stream);
+bool conv_chain_recording();
+int conv_chain_end();       // launches what was recorded and closes the chain
+void conv_chain_abort();    // closes the chain, dropping what was recorded (error paths)
+int conv_chain_concat(const float *a, const float *b, int64_t rows, int ca, int cb, const float *scale,
+                      const float *shift, float *out, float *out_act);
+int conv_chain_bn_relu(const float *x, const float *scale, const float *shift, int64_t rows, int c, float *out);
+int conv_chain_check_abort(const char *who);   // SG_ERR_LAUNCH once after a barrier of an earlier chain timed out
 // per-(device, stream) runtime state of the conv launches / the executors' index builds (sg_stream_release)
 void conv_release_stream(int dev, hipStream_t stream);
 void unet_release_stream(int dev, hipStream_t stream);

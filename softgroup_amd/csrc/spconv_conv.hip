@@ -341,9 +341,14 @@ constexpr int kMetaInts = kMaskAt + 4;
 //     The fragment-shaped alternative (every lane 32 B of its own row) touches 32 different lines
 //     per load instruction, and it is the CU's vector-memory path, not the matrix pipe, that this
 //     kernel waits on once the products are bf16 MFMAs.
-template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0, int WV = 4, int AT = 0>
-__global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
-                                                                             unsigned w_bytes) {
+//   * CHAIN (conv_chain_kernel, below): the layer is one step of a multi-layer launch -- its inputs were
+//     written by OTHER workgroups of the SAME launch (possibly on another XCD), so every activation
+//     access goes past the CU's L1: sc1 loads of the gathered rows and the residual, sc1 (write-through)
+//     stores of the outputs.  The grid barrier between two steps then needs no fence at all
+//     (cdna_hip_programming.md, publish/consume recipe R1).  Same instructions otherwise: same numbers.
+template <int CK, int DEPTH, int TRACE, int NBW, int SPLIT, int WV, int AT, int CHAIN>
+__device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_bytes, unsigned w_bytes) {
+  constexpr int AUX = CHAIN ? 16 : 0;      // buffer-instruction aux bits of the activation accesses (16 = sc1)
   static_assert(!SPLIT || CK == 16 || AT, "split-precision path: 16-channel slices");
   static_assert(!AT || (SPLIT && CK == 32), "line-wise gather: split path, 32-channel items");
   // (Tried: reading the weights as fp32 -- 4 B instead of the 6 B of three bf16 planes -- and
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
         unsigned src = static_cast<unsigned>(c.meta[(8 * q + (lane >> 3)) * p.K + k]);
         if (SG_WHATIF & 16) src = static_cast<unsigned>(c.pair * 32 + 8 * q + (lane >> 3)) % static_cast<unsigned>(p.M_out);
         const unsigned v_a = __umul24(src, row_pitch) + lane_chunk;
-        S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, 0));
+        S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, AUX));
       }
       // weights: sub-slice sl = channel blocks 4s + 2sl + h of the three bf16 planes
       const int s_w = planes_at + (k * c8 + s * 4) * p.Cout * 16;
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     const int s_a = s * (CK * 4);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, 0));
+      S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a + q * 16, s_a, AUX));
     if constexpr (SPLIT) {
       // bf16 planes, layout [K][Cin/8][Cout][8]: lane (h, col) reads block (k, 2s + h) of its column
       const int s_w = planes_at + (k * c8 + s * 2) * p.Cout * 16;
@@ -590,7 +595,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
       c.o_off[rr] = off;   // kept for the epilogue: the unit's LDS block is not read after its loop
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
-        resv[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, n * 128, 0));
+        resv[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, n * 128, AUX));
     }
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
@@ -881,7 +886,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
-                                              o_base + n * 128, 0);
+                                              o_base + n * 128, AUX);
     }
     if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
 #pragma unroll
@@ -889,7 +894,7 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[n][rr]), rs_act, o_off[rr],
-                                                n * 128, 0);
+                                                n * 128, AUX);
     }
     if (combine) {      // uniform
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial stores are out
@@ -952,17 +957,17 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
         for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
           for (int n = 0; n < NBW; ++n)
-            res[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cres, o_off[rr], n * 128, 0));
+            res[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cres, o_off[rr], n * 128, AUX));
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
           for (int n = 0; n < NBW; ++n) {
             float x = t[n][rr] + res[n][rr];
             if (p.post_scale) x = fmaxf(fmaf(x, ps[n], pb[n]), 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs_cout, o_off[rr], n * 128, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs_cout, o_off[rr], n * 128, AUX);
             // (a zero-sized descriptor without a second output: the store is dropped)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(x, as[n], ab[n]), 0.f)),
-                                                  rs_cact, o_off[rr], n * 128, 0);
+                                                  rs_cact, o_off[rr], n * 128, AUX);
           }
       }
     }
@@ -982,6 +987,158 @@ __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(Co
     u = un;
     ++round;
     buf ^= 1;
+  }
+}
+
+template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0, int WV = 4, int AT = 0>
+__global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
+                                                                             unsigned w_bytes) {
+  conv_layer_body<CK, DEPTH, TRACE, NBW, SPLIT, WV, AT, 0>(p, in_bytes, w_bytes);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-layer launch ("conv chain"): the layers of the deep U-Net levels -- a few thousand rows and
+// fewer; 43 of the 65 conv launches of a backbone forward and the whole tiny U-Net, each 8-17 us of
+// launch for ~5 us of work in flight (profiles/r05_conv_by_grid.txt, r06_conv_trace_base.txt) -- run
+// as ONE persistent launch that walks a step list: conv layers (conv_layer_body, CHAIN form), the
+// skip concat and the stray BatchNorm+ReLU, with a grid barrier between two steps.  Topology walked:
+// softgroup/model/blocks.py:82-143 (unet_exec.hip records the steps in launch order).
+//   * one decomposition for every layer of a chain: 32-channel items, line-wise gather, 8 waves per
+//     unit, one 32-column block, offsets split over units exactly as the single launch splits them
+//     (ksplit, in-launch combine).  The single-launch path uses the SAME decomposition for these
+//     layers (t_chain.mode == 1), so a chain and the launches it replaces give the same bits.
+//   * grid = one 512-thread workgroup per CU; co-residency is what the barrier needs, so chain
+//     launches of one process never overlap each other (chain_launch orders them with events) and
+//     the barrier's wait is bounded: on a timeout every workgroup leaves, the launch's results are
+//     garbage and the next library call on that device reports it (g_chain_abort).
+//   * the step list travels in the kernel arguments (<= 4 KB: kChainMax steps per launch; a longer
+//     chain is cut into several launches -- a boundary costs what a barrier costs).
+//   * visibility between steps: activations are stored write-through (sc1) and loaded past the L1
+//     (sc1); every wave drains its stores before the workgroup arrives at the barrier; counters and
+//     generation words are agent-scope atomics.  No fences (cdna_hip_programming.md, recipe R1).
+// ---------------------------------------------------------------------------------------------
+struct ChainStep {
+  const float *in, *w, *post_scale, *post_shift, *residual, *act_scale, *act_shift;
+  float *out_act;
+  const int32_t *order;
+  const uint32_t *tile_mask;
+  const int32_t *nbr_tiles;
+  float *out;
+  unsigned *done;
+  float *out_final;
+  int M_out, K, Cin, Cout, col_units, ksplit, k_per_split, num_units;
+  unsigned magic_upt, magic_cu, magic_nsl, in_bytes, w_bytes;
+  int kind;        // 0 conv | 1 concat: out = [in | residual] (Cin | Cout channels), out_act = relu(out * act_scale + act_shift)
+                   // | 2 BatchNorm + ReLU: out = relu(in * post_scale + post_shift), Cin channels
+  int pad_[2];
+};
+constexpr int kChainMax = 22;
+struct ChainArgs {
+  ChainStep s[kChainMax];
+  unsigned *bar;           // zeroed barrier block (kChainBarWords)
+  unsigned *abort_host;    // pinned host word: set when a barrier timed out
+  int n;
+};
+static_assert(sizeof(ChainArgs) <= 4096, "the step list must fit the kernel-argument segment");
+constexpr int kChainWV = 8;                      // waves per workgroup
+constexpr int kChainBarWords = 18 * 32;          // 8 XCD counters, top counter, 8 generation words, abort: 128 B each
+constexpr unsigned long long kChainTimeout = 200000000ull;     // 2 s of the 100 MHz real-time counter
+
+// XCD-hierarchical grid barrier (MI355X_MICROARCH.md, row barrier-xcd): a workgroup arrives at the counter
+// of ITS group (blockIdx % 8: the XCD under the default dispatch order; any placement is correct), the
+// last of a group arrives at the top counter, the last of all publishes the epoch to every group's
+// generation word; everyone polls its own group's word with relaxed loads and a sleep.
+__device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned epoch, unsigned *abort_host, int *flag_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned x = blockIdx.x & 7, nx = (gridDim.x + 7u - x) >> 3;
+    int ok = 1;
+    const unsigned old = __hip_atomic_fetch_add(bar + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nx * epoch - 1u) {
+      const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+      const unsigned o2 = __hip_atomic_fetch_add(bar + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o2 == groups * epoch - 1u)
+        for (unsigned j = 0; j < groups; ++j)
+          __hip_atomic_store(bar + (9 + j) * 32, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar + (9 + x) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0u) {
+        if (__hip_atomic_load(bar + 17 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeout) {
+          __hip_atomic_store(bar + 17 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *flag_lds = ok;
+  }
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+// the elementwise steps of a chain (float4 granularity; activations past the L1 like the conv steps)
+__device__ __forceinline__ void chain_elementwise(const ChainStep &s) {
+  const int ca4 = s.Cin >> 2, cb4 = s.kind == 1 ? s.Cout >> 2 : 0, c4 = ca4 + cb4;
+  const unsigned total = static_cast<unsigned>(s.M_out) * c4;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(s.in), 0, static_cast<unsigned>(s.M_out) * ca4 * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(cb4 ? s.residual : s.in), 0, static_cast<unsigned>(s.M_out) * cb4 * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(s.out, 0, total * 16u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t roa = __builtin_amdgcn_make_buffer_rsrc(
+      s.out_act ? s.out_act : s.out, 0, s.out_act ? total * 16u : 0u, 0x00020000);
+  const float *sc = s.kind == 1 ? s.act_scale : s.post_scale, *sh = s.kind == 1 ? s.act_shift : s.post_shift;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const unsigned r = t / c4, c = t - r * c4;
+    f4 v;
+    if (c < static_cast<unsigned>(ca4))
+      v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, (r * ca4 + c) * 16u, 0, 16));
+    else
+      v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rb, (r * cb4 + (c - ca4)) * 16u, 0, 16));
+    f4 a = v;
+    if (sc != nullptr) {
+      const f4 k = *reinterpret_cast<const f4 *>(sc + 4 * c), h = *reinterpret_cast<const f4 *>(sh + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = fmaxf(fmaf(v[j], k[j], h[j]), 0.f);
+    }
+    if (s.kind == 1) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro, t * 16u, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, a), roa, t * 16u, 0, 16);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, a), ro, t * 16u, 0, 16);
+    }
+  }
+}
+
+template <int SPLIT>
+__global__ void __launch_bounds__(64 * kChainWV, 1) conv_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // (the word conv_layer_body leaves unused in its control block: red | meta[2] | ctl[4] | transpose blocks)
+  int *flag_lds = reinterpret_cast<int *>(smem_raw) + kChainWV * 16 * 64 + 2 * kMetaInts + 2;
+#pragma nounroll
+  for (int i = 0; i < a.n; ++i) {
+    const ChainStep &s = a.s[i];
+    if (s.kind == 0) {
+      ConvArgs p;
+      p.in = s.in; p.nbr = nullptr; p.w = s.w; p.post_scale = s.post_scale; p.post_shift = s.post_shift;
+      p.residual = s.residual; p.act_scale = s.act_scale; p.act_shift = s.act_shift; p.out_act = s.out_act;
+      p.order = s.order; p.tile_mask = s.tile_mask; p.nbr_tiles = s.nbr_tiles; p.out = s.out;
+      p.M_out = s.M_out; p.K = s.K; p.Cin = s.Cin; p.Cout = s.Cout;
+      p.col_units = s.col_units; p.blocks_per_unit = 1; p.ksplit = s.ksplit; p.k_per_split = s.k_per_split;
+      p.num_units = s.num_units;
+      p.magic_upt = s.magic_upt; p.magic_cu = s.magic_cu; p.magic_nsl = s.magic_nsl;
+      p.queue = nullptr; p.trace = nullptr; p.done = s.done; p.out_final = s.out_final;
+      conv_layer_body<32, 2, 0, 1, SPLIT, kChainWV, 1, 1>(p, s.in_bytes, s.w_bytes);
+    } else {
+      chain_elementwise(s);
+    }
+    if (i + 1 < a.n && !chain_barrier(a.bar, static_cast<unsigned>(i + 1), a.abort_host, flag_lds)) return;
   }
 }
 
@@ -1169,7 +1326,9 @@ static unsigned *take_done(hipStream_t stream, size_t count) {
 }
 
 // sg_stream_release: the caller's stream is idle and about to be destroyed
+static void chain_release_stream(int dev, hipStream_t stream);
 void conv_release_stream(int dev, hipStream_t stream) {
+  chain_release_stream(dev, stream);
   std::lock_guard<std::mutex> lock(g_ticket_mu);
   auto d = g_done_pools.find({dev, stream});
   if (d != g_done_pools.end()) {
@@ -1199,6 +1358,168 @@ static unsigned *take_tickets(hipStream_t stream) {
   return tp.dev + (8 * kTicketStride) * tp.next++;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Conv chains, host side.  While a chain is open on the calling thread (conv_chain_begin .. _end, the
+// U-Net executor around its deep levels) sg_spconv_gather_conv_f32 RECORDS the layers the chain kernel
+// can take (mode 2) instead of launching them, or -- chains switched off (SG_CONV_CHAIN=0 /
+// sg_spconv_set_chain(0)) -- launches them one by one with the chain's decomposition (mode 1): same
+// numbers either way.  A layer the chain cannot take (no line-wise gather, no in-launch combine)
+// flushes what was recorded and is launched as usual.
+// ---------------------------------------------------------------------------------------------
+struct ChainRec {
+  int mode = 0;            // 0 closed | 1 open, single launches | 2 open, recording
+  bool b16 = false;        // arithmetic of the recorded steps (one kernel instantiation per launch)
+  int conv_steps = 0;      // conv layers with K > 1 among the recorded steps (profile bookkeeping)
+  hipStream_t stream = nullptr;
+  ChainArgs args;
+};
+static thread_local ChainRec t_chain;
+static std::atomic<int> g_chain_override{-1};       // -1 = SG_CONV_CHAIN (default 1)
+static std::atomic<long long> g_chain_launches{0}, g_chain_steps{0};
+static std::mutex g_chain_mu;                                         // order of the chain launches of a device
+static std::map<int, hipEvent_t> g_chain_last;                        // device -> event behind its latest chain launch
+static std::map<std::pair<int, hipStream_t>, hipEvent_t> g_chain_events;
+static std::map<int, unsigned *> g_chain_abort;                       // device -> pinned word (set by a timed-out barrier)
+
+static void chain_release_stream(int dev, hipStream_t stream) {      // (the stream is idle)
+  std::lock_guard<std::mutex> lock(g_chain_mu);
+  auto it = g_chain_events.find({dev, stream});
+  if (it == g_chain_events.end()) return;
+  auto last = g_chain_last.find(dev);
+  if (last != g_chain_last.end() && last->second == it->second) last->second = nullptr;
+  if (it->second) hipEventDestroy(it->second);
+  g_chain_events.erase(it);
+}
+
+static bool chain_enabled() {
+  static const int env = getenv("SG_CONV_CHAIN") ? atoi(getenv("SG_CONV_CHAIN")) : 1;
+  const int ov = g_chain_override.load(std::memory_order_relaxed);
+  return (ov >= 0 ? ov : env) != 0;
+}
+
+// has a barrier of an earlier chain launch on this device timed out?  (reported once)
+int conv_chain_check_abort(const char *who) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_chain_mu);
+  auto it = g_chain_abort.find(dev);
+  if (it != g_chain_abort.end() && *static_cast<volatile unsigned *>(it->second) != 0u) {
+    *static_cast<volatile unsigned *>(it->second) = 0u;
+    set_error("%s: a grid barrier of an earlier multi-layer conv launch timed out (its workgroups were not "
+              "co-resident: another process on this GPU?); that forward's results are invalid. "
+              "SG_CONV_CHAIN=0 launches the layers one by one", who);
+    return SG_ERR_LAUNCH;
+  }
+  return SG_OK;
+}
+
+static int chain_flush() {
+  ChainRec &c = t_chain;
+  if (c.args.n == 0) return SG_OK;
+  int dev = 0;
+  hipGetDevice(&dev);
+  static int num_cu = 0;
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (num_cu <= 0) num_cu = 256;
+  });
+  c.args.bar = take_done(c.stream, kChainBarWords);
+  if (c.args.bar == nullptr) {
+    set_error("conv chain: no barrier block");
+    return SG_ERR_LAUNCH;
+  }
+  const size_t lds = static_cast<size_t>(kChainWV) * 16 * 64 * sizeof(float) + 2 * kMetaInts * sizeof(int32_t) + 16 +
+                     static_cast<size_t>(kChainWV) * 4096;
+  const int grid = num_cu >= 8 ? num_cu - num_cu % 8 : num_cu;
+  const bool prof = g_conv_prof.enabled && c.conv_steps > 0;
+  {
+    std::lock_guard<std::mutex> lock(g_chain_mu);
+    unsigned *&ab = g_chain_abort[dev];
+    if (ab == nullptr) {
+      if (hipHostMalloc(reinterpret_cast<void **>(&ab), 64, hipHostMallocMapped) != hipSuccess) {
+        ab = nullptr;
+        set_error("conv chain: pinned allocation failed");
+        return SG_ERR_LAUNCH;
+      }
+      *ab = 0u;
+    }
+    c.args.abort_host = ab;
+    hipEvent_t &mine = g_chain_events[{dev, c.stream}];
+    if (mine == nullptr && hipEventCreateWithFlags(&mine, hipEventDisableTiming) != hipSuccess) {
+      mine = nullptr;
+      set_error("conv chain: event creation failed");
+      return SG_ERR_LAUNCH;
+    }
+    hipEvent_t &last = g_chain_last[dev];
+    if (last != nullptr && last != mine) hipStreamWaitEvent(c.stream, last, 0);    // one chain at a time per device
+    if (prof) {
+      hipEventRecord(g_conv_prof.take(), c.stream);
+      for (int v : {-c.conv_steps, 0, 0, 0, 0}) g_conv_prof.dims.push_back(v);
+    }
+    if (c.b16)
+      conv_chain_kernel<2><<<grid, 64 * kChainWV, lds, c.stream>>>(c.args);
+    else
+      conv_chain_kernel<1><<<grid, 64 * kChainWV, lds, c.stream>>>(c.args);
+    if (prof) hipEventRecord(g_conv_prof.take(), c.stream);
+    hipEventRecord(mine, c.stream);
+    last = mine;
+  }
+  g_chain_launches.fetch_add(1, std::memory_order_relaxed);
+  g_chain_steps.fetch_add(c.args.n, std::memory_order_relaxed);
+  c.args.n = 0;
+  c.conv_steps = 0;
+  return check_launch("conv chain");
+}
+
+static int chain_push(const ChainStep &st, bool b16, bool counts) {
+  ChainRec &c = t_chain;
+  if (c.args.n > 0 && (c.args.n == kChainMax || c.b16 != b16)) {
+    const int rc = chain_flush();
+    if (rc != SG_OK) return rc;
+  }
+  c.b16 = b16;
+  c.args.s[c.args.n++] = st;
+  if (counts) ++c.conv_steps;
+  return SG_OK;
+}
+
+void conv_chain_begin(hipStream_t stream) {
+  ChainRec &c = t_chain;
+  c.mode = chain_enabled() ? 2 : 1;
+  c.stream = stream;
+  c.args.n = 0;
+  c.conv_steps = 0;
+}
+bool conv_chain_recording() { return t_chain.mode == 2; }
+int conv_chain_end() {
+  const int rc = t_chain.mode == 2 ? chain_flush() : SG_OK;
+  t_chain.mode = 0;
+  t_chain.args.n = 0;
+  return rc;
+}
+void conv_chain_abort() {
+  t_chain.mode = 0;
+  t_chain.args.n = 0;
+  t_chain.conv_steps = 0;
+}
+// the elementwise steps between the layers of a chain (call only while conv_chain_recording())
+int conv_chain_concat(const float *a, const float *b, int64_t rows, int ca, int cb, const float *scale,
+                      const float *shift, float *out, float *out_act) {
+  ChainStep st = {};
+  st.kind = 1;
+  st.in = a; st.residual = b; st.act_scale = scale; st.act_shift = shift; st.out = out; st.out_act = out_act;
+  st.M_out = static_cast<int>(rows); st.Cin = ca; st.Cout = cb;
+  return chain_push(st, t_chain.b16, false);
+}
+int conv_chain_bn_relu(const float *x, const float *scale, const float *shift, int64_t rows, int c, float *out) {
+  ChainStep st = {};
+  st.kind = 2;
+  st.in = x; st.post_scale = scale; st.post_shift = shift; st.out = out;
+  st.M_out = static_cast<int>(rows); st.Cin = c; st.Cout = 0;
+  return chain_push(st, t_chain.b16, false);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Launch of the split-precision persistent kernel.  Decomposition: unit = (32-row tile, one or
@@ -1307,6 +1628,13 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
       break;
     }
   }
+  // a layer of an open chain: the chain's decomposition (8 waves per unit, one column block, line-wise
+  // gather), whether it is recorded or launched by itself
+  const bool chain_layer = t_chain.mode != 0 && use_at != 0;
+  if (chain_layer) {
+    for (int i = 0; i < kSplitVariants; ++i)
+      if (g_split_variants[i].at == 1 && g_split_variants[i].nbw == 1 && g_split_variants[i].wv == kChainWV) pick = i;
+  }
   const SplitVariant &v = g_split_variants[pick];
   a.col_units = NB / v.nbw;
   a.blocks_per_unit = v.nbw;
@@ -1316,6 +1644,22 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   a.magic_upt = magic(static_cast<unsigned>(a.col_units * a.ksplit));
   a.magic_cu = magic(static_cast<unsigned>(a.col_units));
   a.magic_nsl = magic(static_cast<unsigned>(a.Cin / v.ck));
+  if (t_chain.mode == 2) {
+    if (chain_layer && (a.ksplit == 1 || a.done != nullptr) && stream == t_chain.stream) {
+      ChainStep st = {};
+      st.kind = 0;
+      st.in = a.in; st.w = a.w; st.post_scale = a.post_scale; st.post_shift = a.post_shift; st.residual = a.residual;
+      st.act_scale = a.act_scale; st.act_shift = a.act_shift; st.out_act = a.out_act; st.order = a.order;
+      st.tile_mask = a.tile_mask; st.nbr_tiles = a.nbr_tiles; st.out = a.out; st.done = a.done; st.out_final = a.out_final;
+      st.M_out = a.M_out; st.K = a.K; st.Cin = a.Cin; st.Cout = a.Cout; st.col_units = a.col_units;
+      st.ksplit = a.ksplit; st.k_per_split = a.k_per_split; st.num_units = a.num_units;
+      st.magic_upt = a.magic_upt; st.magic_cu = a.magic_cu; st.magic_nsl = a.magic_nsl;
+      st.in_bytes = static_cast<unsigned>(in_bytes); st.w_bytes = static_cast<unsigned>(w_bytes);
+      return chain_push(st, b16, a.K > 1);
+    }
+    const int rc = chain_flush();      // not a layer the chain kernel takes: what was recorded runs first
+    if (rc != SG_OK) return rc;
+  }
   static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
   a.queue = dyn_env ? take_tickets(stream) : nullptr;
   // grid: the resident workgroups, a multiple of 8 (unit u runs on XCD u % 8 in every round).  A layer
@@ -1371,6 +1715,18 @@ int sg_spconv_set_arithmetic(int mode) {
 int sg_spconv_set_combine(int mode) {
   SG_REQUIRE(mode >= -1 && mode <= 1, "sg_spconv_set_combine: mode must be -1, 0 or 1");
   g_combine_override = mode;
+  return SG_OK;
+}
+
+int sg_spconv_set_chain(int mode) {
+  SG_REQUIRE(mode >= -1 && mode <= 1, "sg_spconv_set_chain: mode must be -1, 0 or 1");
+  g_chain_override = mode;
+  return SG_OK;
+}
+
+int sg_spconv_chain_stats(int64_t *launches, int64_t *steps) {
+  if (launches) *launches = g_chain_launches.load(std::memory_order_relaxed);
+  if (steps) *steps = g_chain_steps.load(std::memory_order_relaxed);
   return SG_OK;
 }
 
@@ -1462,7 +1818,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     hipStream_t st;
     bool on;
     ProfScope(hipStream_t s, bool count, int m, int k, int ci, int co, int rows_in)
-        : st(s), on(g_conv_prof.enabled && count) {
+        : st(s), on(g_conv_prof.enabled && count && t_chain.mode != 2) {      // (a recorded layer is timed with its chain launch)
       if (on) {
         hipEventRecord(g_conv_prof.take(), st);
         for (int v : {m, k, ci, co, rows_in}) g_conv_prof.dims.push_back(v);
@@ -1473,6 +1829,10 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     }
   } prof_scope(stream, K > 1, M_out, K, Cin, Cout, num_in_rows);     // the 1x1 identity-branch convs are not part of the conv roofline
   if (Cout % 4 != 0) {
+    if (t_chain.mode == 2) {
+      const int rc = chain_flush();
+      if (rc != SG_OK) return rc;
+    }
     gather_conv_scalar_kernel<<<grid_for(static_cast<int64_t>(M_out) * Cout, 256, 256 * 32), 256, 0,
                                 stream>>>(in, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,
                                           residual, act_scale, act_shift, out_act, out);
@@ -1544,9 +1904,14 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.magic_cu = magic(static_cast<unsigned>(col_units));
   a.magic_nsl = 0;
 
+  if (!split && t_chain.mode == 2) {      // not a layer the chain kernel takes
+    const int rc = chain_flush();
+    if (rc != SG_OK) return rc;
+  }
   if (split) {
     const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream, split_on == 2);
     if (rc != SG_OK) return rc;
+    if (t_chain.mode == 2 && t_chain.args.n > 0) return SG_OK;      // recorded (an offset-split layer combines in the launch)
   } else if (persistent) {
     // fp32-MFMA kernel (SG_CONV_SPLIT=0 / sg_spconv_set_arithmetic(0), and layers below
     // SG_CONV_SPLIT_MIN_CIN): 16-channel slices, 2-deep operand ring, 4 waves per unit, one column

@@ -334,6 +334,42 @@ struct Exec {
   Exec(const sg_unet_desc *desc, void *arena, size_t bytes, sg_stream_t s, const LevelIdx *li)
       : d(desc), ar(arena, bytes), stream(s), idx(li) {}
 
+  // Conv chain (spconv_conv.hip): the levels from `l` down run as ONE multi-layer launch when level l has
+  // at most SG_CONV_CHAIN_ROWS rows (default 6144: below ~1 900 units per layer the single launches use the
+  // chain's decomposition anyway) and every level from l down has a multiple of 32 channels (32-channel
+  // items, line-wise gather).  Opened in front of the strided conv INTO level l, closed behind level l's
+  // last conv; with chains switched off the same layers are launched one by one, same decomposition.
+  bool chain_open = false;
+  bool chain_from(int l) const {
+    static const int max_rows = getenv("SG_CONV_CHAIN_ROWS") ? atoi(getenv("SG_CONV_CHAIN_ROWS")) : 6144;
+    if (chain_open || idx[l].rows > max_rows || idx[l].rows <= 0) return false;
+    for (int k = l; k < d->n_levels; ++k)
+      if (d->levels[k].planes % 32 != 0) return false;
+    return true;
+  }
+  struct ChainScope {      // closes the chain on every way out (an error path drops what was recorded)
+    Exec &e;
+    bool on;
+    ChainScope(Exec &ex, bool open) : e(ex), on(open) {
+      if (on) {
+        conv_chain_begin(as_stream(e.stream));
+        e.chain_open = true;
+      }
+    }
+    int close() {
+      if (!on) return SG_OK;
+      on = false;
+      e.chain_open = false;
+      return conv_chain_end();
+    }
+    ~ChainScope() {
+      if (on) {
+        conv_chain_abort();
+        e.chain_open = false;
+      }
+    }
+  };
+
   // BatchNorm1d + ReLU of a consumer, applied by the producer: (scale, shift) and where the
   // activated copy goes
   struct Act {
@@ -409,7 +445,10 @@ struct Exec {
       xa = x0a;
     } else if (xa == nullptr) {
       SG_ALLOC(x0a, float, feat);
-      SG_TRY(sg_bn_relu_f32(x, L.blocks[0].bn1_scale, L.blocks[0].bn1_shift, rows, c, 1, x0a, stream));
+      if (conv_chain_recording())
+        SG_TRY(conv_chain_bn_relu(x, L.blocks[0].bn1_scale, L.blocks[0].bn1_shift, rows, c, x0a));
+      else
+        SG_TRY(sg_bn_relu_f32(x, L.blocks[0].bn1_scale, L.blocks[0].bn1_shift, rows, c, 1, x0a, stream));
       xa = x0a;
     }
     // blocks: every conv2 also emits the activation its consumer wants
@@ -443,10 +482,14 @@ struct Exec {
       SG_ALLOC(y, float, feat2);
       SG_ALLOC(ya, float, feat2);
       const Act ay{L2.blocks[0].bn1_scale, L2.blocks[0].bn1_shift, ya};
-      SG_TRY(conv(cur_a, rows, down, c, c2, L.down_w, nullptr, nullptr, nullptr, ay, y));
-      // ---- inner UBlock; its last conv applies this level's deconv BatchNorm + ReLU in place
       SG_ALLOC(z, float, feat2);
-      SG_TRY(level(l + 1, y, ya, nullptr, 0, L.up_bn_scale, L.up_bn_shift, z));
+      {
+        ChainScope chain(*this, chain_from(l + 1));      // the strided conv and everything below it: one launch
+        SG_TRY(conv(cur_a, rows, down, c, c2, L.down_w, nullptr, nullptr, nullptr, ay, y));
+        // ---- inner UBlock; its last conv applies this level's deconv BatchNorm + ReLU in place
+        SG_TRY(level(l + 1, y, ya, nullptr, 0, L.up_bn_scale, L.up_bn_shift, z));
+        SG_TRY(chain.close());
+      }
       // ---- SparseInverseConv3d(c2, c): gather table = parent row per fine voxel (plan `up`, built
       //      on the index stream before the descent), then the skip concat (blocks.py:135-139)
       //      with the first tail block's BatchNorm + ReLU as a second output
@@ -456,7 +499,9 @@ struct Exec {
         const size_t m = ar.mark();
         SG_ALLOC(upf, float, feat);
         SG_TRY(conv(z, rows2, up, c2, c, L.up_w, nullptr, nullptr, nullptr, Act(), upf));
-        if (rows)
+        if (rows && conv_chain_recording())
+          SG_TRY(conv_chain_concat(cur, upf, rows, c, c, L.tail[0].bn1_scale, L.tail[0].bn1_shift, cat, cata));
+        else if (rows)
           concat2_kernel<<<grid_for(static_cast<int64_t>(rows) * (2 * c / 4), 256), 256, 0, as_stream(stream)>>>(
               reinterpret_cast<const float4 *>(cur), reinterpret_cast<const float4 *>(upf), rows, c / 4,
               c / 4, reinterpret_cast<const float4 *>(L.tail[0].bn1_scale),
@@ -542,6 +587,7 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
                "sg_unet_forward: level %d: planes must be a multiple of 4", l);
   SG_REQUIRE(d->arithmetic == 0 || d->arithmetic == 2, "sg_unet_forward: arithmetic must be 0 or 2");
   if (num_rows == 0) return SG_OK;
+  SG_TRY(conv_chain_check_abort("sg_unet_forward"));
   const int L = d->n_levels;
   struct ArithScope {      // this call's convolutions, on this thread only
     int keep;
@@ -614,8 +660,14 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   }
   Exec ex(d, rest + used, rest_bytes - used, stream, li);
   ex.perm = pre ? perm : nullptr;
-  int rc = ex.level(0, pre ? nullptr : feats_in, nullptr, pre ? feats : nullptr, d->input_cin,
-                    d->out_bn_scale, d->out_bn_shift, out_int);
+  int rc;
+  {
+    // a U-Net that is small from level 0 on (the tiny U-Net over the proposals' voxels): the whole forward
+    Exec::ChainScope chain(ex, !pre && ex.chain_from(0));
+    rc = ex.level(0, pre ? nullptr : feats_in, nullptr, pre ? feats : nullptr, d->input_cin,
+                  d->out_bn_scale, d->out_bn_shift, out_int);
+    if (rc == SG_OK) rc = chain.close();
+  }
   if (rc == SG_OK && morton) {      // back to the API's row order
     permute_rows_kernel<true><<<grid_for(static_cast<int64_t>(num_rows) * (c0 / 4), 256), 256, 0, as_stream(stream)>>>(
         reinterpret_cast<const float4 *>(out_int), perm, num_rows, c0 / 4, reinterpret_cast<float4 *>(out));

@@ -139,13 +139,22 @@ def test_forward_test_native_equals_operator_path_end_to_end():
     model = synthetic.build_model(seed=0)
     model.async_results = False
     with torch.no_grad():
-        out_nat = dict(model(b))
+        out_one = dict(model(b))                    # sg_scan_forward: one C call
+        model.use_scan_forward = False
+        out_nat = dict(model(b))                    # staged: sg_scan_grouping / sg_scan_instances + torch heads
         model.use_native_scan = False
-        out_op = dict(model(b))
+        out_op = dict(model(b))                     # operator surface
     assert len(out_nat['pred_instances']) == len(out_op['pred_instances']) > 0
     for a, c in zip(out_nat['pred_instances'], out_op['pred_instances']):
         assert a['label_id'] == c['label_id'] and a['conf'] == c['conf'] and a['pred_mask'] == c['pred_mask']
     np.testing.assert_array_equal(out_nat['semantic_preds'], out_op['semantic_preds'])
+    # the one-call scan: same labels and RLE strings; its class / IoU heads are FMA chains (sg_linear_rows),
+    # the staged path's a GEMM library -- confidences agree to rounding order
+    assert len(out_one['pred_instances']) == len(out_op['pred_instances'])
+    for a, c in zip(out_one['pred_instances'], out_op['pred_instances']):
+        assert a['label_id'] == c['label_id'] and a['pred_mask'] == c['pred_mask']
+        assert abs(float(a['conf']) - float(c['conf'])) <= 1e-6
+    np.testing.assert_array_equal(out_one['semantic_preds'], out_op['semantic_preds'])
 
 
 def test_panoptic_fusion_on_the_device_equals_the_reference_loop():

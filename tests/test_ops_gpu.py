@@ -178,6 +178,39 @@ def test_bfs_cluster_vs_oracle_large_and_order():
     assert len(rco) - 1 >= 40
 
 
+def test_bfs_cluster_thin_levels_on_one_wave_equal_the_workgroup_path(monkeypatch):
+    """bfs_emit_kernel replays runs of thin levels (<= 64 frontier nodes, <= 512 edges) on ONE wave: chains
+    (hundreds of levels of 1-3 nodes), small blobs, levels that alternate between thin and fat, a blob whose
+    middle levels exceed 512 edges -- membership and BFS order against the oracle, with the single-wave runs
+    (SG_BFS_THIN=1; measured slower, off by default) and without."""
+    rng = np.random.default_rng(31)
+    parts = []
+    # chains: points 1.5 cm apart along a wiggly line -> 2-4 neighbours each, ~400 levels
+    for k in range(3):
+        tt = np.arange(400 + 100 * k) * 0.015
+        parts.append(np.stack([tt, 0.02 * np.sin(7 * tt) + 2.0 * k, np.zeros_like(tt)], 1))
+    # small blobs (thin throughout), one dense blob (fat middle levels), dumbbells (thin - fat - thin)
+    for k in range(12):
+        parts.append(rng.normal(0, 0.02, (150 + 20 * k, 3)) + np.array([10.0 + k, 0, 0]))
+    parts.append(rng.normal(0, 0.03, (6000, 3)) + np.array([30.0, 0, 0]))
+    for k in range(3):
+        bar = np.stack([np.linspace(0, 0.6, 60), np.zeros(60), np.zeros(60)], 1)
+        ends = [rng.normal(0, 0.015, (800, 3)), rng.normal(0, 0.015, (800, 3)) + np.array([0.6, 0, 0])]
+        parts.append(np.concatenate([bar] + ends) + np.array([40.0 + 3 * k, 0, 0]))
+    xyz = np.concatenate(parts).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    n = len(xyz)
+    idx, sl = ops.ballquery_batch_p(t(xyz), t(np.zeros(n, np.int32)), t(np.array([0, n], np.int32)), 0.04, 300)
+    mean = torch.tensor([-1.0])
+    rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 20.0, 0)
+    assert len(rco) - 1 >= 15
+    for thin in ('1', '0'):
+        monkeypatch.setenv('SG_BFS_THIN', thin)
+        ci, co = ops.bfs_cluster(mean, idx, sl, 20.0, 0)
+        assert np.array_equal(co.cpu().numpy(), rco), thin
+        assert np.array_equal(ci.cpu().numpy(), rci), thin       # membership AND member order
+
+
 def test_bfs_cluster_directed_lists_capped():
     """cap-hit regime: lists keep the 1000 smallest indices -> asymmetric graph -> the reference
     semantics is directed reachability from ascending seeds."""

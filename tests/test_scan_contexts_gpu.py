@@ -143,8 +143,17 @@ def test_pool_retirement_releases_stream_arenas(setup):
             r.resolve()
     pool = model.__dict__['_scan_pool']
     raws = [st.cuda_stream for _, st in pool._sg_streams]
-    assert raws and any(k[2] in raws for k in NS._arenas) and any(k[1] in raws for k in UE._arena)
+    from softgroup_amd.model import scan_forward as SF
+    # the one-call scan keeps ONE arena per stream (scan_forward._arenas); the staged path two kinds
+    assert raws and any(k[1] in raws for k in SF._arenas)
+    model.use_scan_forward = False
+    with torch.no_grad():
+        for r in [model(scenes[i]) for i in (1, 3, 5)]:
+            r.resolve()
+    model.use_scan_forward = True
+    assert any(k[2] in raws for k in NS._arenas) and any(k[1] in raws for k in UE._arena)
     model.invalidate_caches()
+    assert not any(k[1] in raws for k in SF._arenas)
     assert not any(k[2] in raws for k in NS._arenas) and not any(k[1] in raws for k in UE._arena)
     model.scan_contexts = 1
     with torch.no_grad():
