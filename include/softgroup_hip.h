@@ -380,9 +380,10 @@ int sg_spconv_set_combine(int mode);
  * the U-Net levels with at most SG_CONV_CHAIN_ROWS rows (default 6144) -- softgroup/model/blocks.py:82-143
  * from the strided conv into such a level down to the deepest level and back up, and a whole U-Net that
  * is that small (the tiny U-Net, softgroup/model/softgroup.py:93-95) -- run as ONE persistent launch per
- * <= 22 layers, with a grid barrier between two layers, instead of one launch per layer.  mode 1 = on
- * (the default), 0 = every layer its own launch (same decomposition, bit-identical results), -1 = back
- * to the environment (SG_CONV_CHAIN).  Process-wide, not thread-safe: tests and A/B measurements.
+ * <= 22 layers, with a grid barrier between two layers, instead of one launch per layer.  mode 1 = on,
+ * 0 = every layer its own launch (same decomposition, bit-identical results; the default: measured
+ * neutral for one scan at a time and slower with several scans in flight, profiles/r06_conv_chain.txt),
+ * -1 = back to the environment (SG_CONV_CHAIN).  Process-wide, not thread-safe: tests and A/B measurements.
  * sg_spconv_chain_stats: chain launches and the steps (layers, concats) they carried since process start. */
 int sg_spconv_set_chain(int mode);
 int sg_spconv_chain_stats(int64_t *launches, int64_t *steps);
@@ -679,6 +680,26 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
                      const float *coords_float, const int32_t *batch_idxs, const float *point_feats,
                      void *arena, size_t arena_bytes, sg_grouping_result *result_host,
                      sg_stream_t stream);
+
+/* SoftGroup++ grouping (softgroup/model/softgroup.py:433-466 with with_pyramid / with_octree; per-class level
+ * get_level :485-489, pyramid_map :491-498, octree query softgroup/ops/functions.py:14-44, bfs_cluster :278-308,
+ * pyramid_inverse_map :500-507) as ONE C call: class selection of all classes at once (one read-back of the
+ * per-class counts), then class by class on the operators above -- level voxels and their pooled coordinates /
+ * offsets, octree or hashed-grid neighbour lists at radius * level, clusters, inverse map -- and the same
+ * proposal voxelisation as sg_scan_grouping.  base.radius is ignored: `radius` and `base_size` are the
+ * configuration's Python floats (the level's radius and voxel size are their double products rounded once,
+ * as the reference's Python computes them).  Same results as the per-class loop over the operator surface,
+ * bit for bit.  2 + 4 host read-backs per grouped class (voxel count, neighbour total, cluster count, rows). */
+typedef struct sg_grouping_pp_cfg {
+  sg_grouping_cfg base;
+  int with_pyramid, with_octree, lvl_fusion;
+  double radius;             /* grouping_cfg.radius */
+  double base_size;          /* grouping_cfg.pyramid_base_size */
+} sg_grouping_pp_cfg;
+int sg_scan_grouping_pp(const sg_grouping_pp_cfg *cfg, const float *scores, const float *pt_offsets,
+                        const float *coords_float, const int32_t *batch_idxs, const float *point_feats,
+                        void *arena, size_t arena_bytes, sg_grouping_result *result_host,
+                        sg_stream_t stream);
 
 typedef struct sg_instances_cfg {
   int n_proposals, n_classes;   /* instance classes (without the background column) */

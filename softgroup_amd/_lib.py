@@ -101,6 +101,7 @@ SIGNATURES = {
     'sg_panoptic_fusion_workspace_bytes': (_sz, [_i, _i]),
     'sg_panoptic_fusion': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.c_double, _i, _i, _vp, _vp, _sz, _vp]),
     'sg_scan_grouping': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'sg_scan_grouping_pp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'sg_scan_instances': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     'sg_softmax_rows': (_i, [_vp, _i64, _i, _vp, _vp]),
     'sg_mlp_rows': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),

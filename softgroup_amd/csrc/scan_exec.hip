@@ -345,6 +345,57 @@ __global__ void __launch_bounds__(1024) instance_keep_kernel(const float *__rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SoftGroup++ grouping, one class at a time (softgroup.py:443-463): the glue between the operators.
+// ------------------------------------------------------------------------------------------------
+// pyramid_map's inputs for the points of one class (softgroup.py:491-498): level voxel coordinates
+// (batch, trunc(coords / (base_size * level))) as int64 rows -- torch divides a CUDA tensor by a host
+// scalar as a multiplication with the scalar's fp32 reciprocal, `inv` -- and the gathered coordinates /
+// offsets that the level's voxel pooling averages
+__global__ void __launch_bounds__(256) pp_level_inputs_kernel(const int32_t *__restrict__ obj, int n,
+                                                             const float *__restrict__ coords,
+                                                             const float *__restrict__ offsets,
+                                                             const int32_t *__restrict__ batch_idxs, float inv,
+                                                             int64_t *__restrict__ vox, float *__restrict__ c3,
+                                                             float *__restrict__ o3) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int p = obj[i];
+  vox[4LL * i] = batch_idxs[p];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float c = coords[3LL * p + a];
+    c3[3LL * i + a] = c;
+    o3[3LL * i + a] = offsets[3LL * p + a];
+    vox[4LL * i + 1 + a] = static_cast<int64_t>(__fmul_rn(c, inv));      // .long(): toward zero
+  }
+}
+// query points of a level: pooled coordinates + pooled offsets (softgroup.py:447 on the level's voxels),
+// batch index = first column of the level's voxel coordinates
+__global__ void __launch_bounds__(256) pp_level_points_kernel(const float *__restrict__ cl, const float *__restrict__ ol,
+                                                             const int64_t *__restrict__ vc, int m,
+                                                             float *__restrict__ q, int32_t *__restrict__ qb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) q[3LL * i + a] = __fadd_rn(cl[3LL * i + a], ol[3LL * i + a]);
+  qb[i] = static_cast<int32_t>(vc[4LL * i]);
+}
+// a class's proposals appended to the scan's: proposal ids shifted by the proposals before, the class's
+// local point index -> scene point, offsets shifted by the rows before (softgroup.py:455-463)
+__global__ void __launch_bounds__(256) pp_append_kernel(const int32_t *__restrict__ pairs, int rows,
+                                                       const int32_t *__restrict__ offs, int n_prop,
+                                                       const int32_t *__restrict__ obj, int prop_base, int row_base,
+                                                       int32_t *__restrict__ out_pairs, int32_t *__restrict__ out_offs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows) {
+    out_pairs[2LL * (row_base + i)] = pairs[2LL * i] + prop_base;
+    out_pairs[2LL * (row_base + i) + 1] = obj[pairs[2LL * i + 1]];
+  }
+  if (i < n_prop) out_offs[prop_base + 1 + i] = offs[i + 1] + row_base;
+  if (i == 0 && prop_base == 0) out_offs[0] = 0;
+}
+
 // bump allocator over the caller's arena that keeps counting past the end, so that a failed call
 // can say how much it needed up to the point where it stopped
 struct ScanArena {
@@ -397,6 +448,52 @@ thread_local void *t_scan_emit_ctx = nullptr;
 
 using namespace sg;
 
+// proposal voxelisation (softgroup.py:655-709, rand_quantize = False) behind both grouping drivers: boxes,
+// voxel coordinates, voxel index, pooled features; one read-back (voxel count, max points per voxel)
+static int voxelise_proposals(const sg_grouping_cfg *cfg, const int32_t *pairs, const int32_t *poff, int n_prop, int S,
+                              const float *coords_float, const float *point_feats, ScanArena &ar, int32_t *meta,
+                              int32_t *host, sg_grouping_result *res, sg_stream_t stream_, const char *kWhat) {
+  hipStream_t stream = as_stream(stream_);
+  const int C = cfg->feat_channels;
+  SG_TAKE(cscale, float, n_prop);
+  SG_TAKE(lo_s, float, 3 * static_cast<size_t>(n_prop));
+  SG_TAKE(vox, int64_t, 4 * static_cast<size_t>(S));
+  SG_TAKE(bad, int32_t, 64);
+  hipMemsetAsync(bad, 0, sizeof(int32_t), stream);
+  const float inv_ss = 1.0f / static_cast<float>(cfg->voxel_shape);
+  proposal_box_kernel<<<n_prop < 1024 ? n_prop : 1024, 256, 0, stream>>>(pairs, poff, n_prop, coords_float, inv_ss,
+                                                                        cfg->voxel_scale, cscale, lo_s);
+  proposal_voxel_coords_kernel<<<grid_for(S, 256), 256, 0, stream>>>(pairs, S, coords_float, cscale, lo_s,
+                                                                    cfg->voxel_shape, vox, bad);
+  const size_t vx_bytes = sg_voxelize_idx_workspace_bytes(S);
+  SG_TAKE(vx_ws, char, vx_bytes);
+  SG_TAKE(inp_map, int32_t, S);
+  SG_TRY(sg_voxelize_idx_build(vox, S, 4, 4, inp_map, meta + 40, vx_ws, vx_bytes, stream_));
+  // meta[40] = voxels, meta[41] = max points per voxel, bad[0] = a coordinate left the grid
+  hipMemcpyAsync(meta + 42, bad, sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+  SG_TRY(read_back(host, meta + 40, 3, stream, kWhat));
+  const int M = host[0], mA = host[1];
+  SG_REQUIRE(host[2] == 0, "%s: a proposal voxel coordinate fell outside [0, %d) "
+             "(the reference asserts here, softgroup.py:698)", kWhat, cfg->voxel_shape);
+  res->n_voxels = M;
+  res->max_active = mA;
+  SG_TAKE(vc64, int64_t, 4 * static_cast<size_t>(M));
+  SG_TAKE(rules, int32_t, static_cast<size_t>(M) * (mA + 1));
+  SG_TRY(sg_voxelize_idx_fill(vox, S, 4, 4, inp_map, M, mA, vc64, rules, vx_ws, vx_bytes, stream_));
+  SG_TAKE(vc32, int32_t, 4 * static_cast<size_t>(M));
+  SG_TAKE(vox_off, int32_t, static_cast<size_t>(n_prop) + 1);
+  SG_TAKE(vfeat, float, static_cast<size_t>(M) * C);
+  proposal_voxel_pack_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vc64, M, n_prop, vc32, vox_off);
+  proposal_voxel_feats_kernel<<<grid_for(static_cast<int64_t>(M) * C, 256), 256, 0, stream>>>(
+      point_feats, pairs, rules, M, mA, C, vfeat);
+  res->voxel_coords = ar.at(vc32);
+  res->voxel_offsets = ar.at(vox_off);
+  res->voxel_feats = ar.at(vfeat);
+  res->point_to_voxel = ar.at(inp_map);
+  res->arena_used = ar.off;
+  return check_launch(kWhat);
+}
+
 extern "C" {
 
 int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const float *pt_offsets,
@@ -412,7 +509,7 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
   int32_t *host = pinned_words();
   SG_REQUIRE(host != nullptr, "sg_scan_grouping: no pinned host words");
   ScanArena ar(arena, arena_bytes);
-  const int n = cfg->n_points, n_seg = cfg->n_seg, C = cfg->feat_channels;
+  const int n = cfg->n_points, n_seg = cfg->n_seg;
   if (n == 0 || n_seg == 0) return SG_OK;
 
   // ---- 1. class selection
@@ -477,43 +574,185 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
   }
 
   // ---- 4. proposal voxelisation (softgroup.py:655-709, rand_quantize = False)
-  SG_TAKE(cscale, float, n_prop);
-  SG_TAKE(lo_s, float, 3 * static_cast<size_t>(n_prop));
-  SG_TAKE(vox, int64_t, 4 * static_cast<size_t>(S));
-  SG_TAKE(bad, int32_t, 64);
-  hipMemsetAsync(bad, 0, sizeof(int32_t), stream);
-  const float inv_ss = 1.0f / static_cast<float>(cfg->voxel_shape);
-  proposal_box_kernel<<<n_prop < 1024 ? n_prop : 1024, 256, 0, stream>>>(pairs, poff, n_prop, coords_float, inv_ss,
-                                                                        cfg->voxel_scale, cscale, lo_s);
-  proposal_voxel_coords_kernel<<<grid_for(S, 256), 256, 0, stream>>>(pairs, S, coords_float, cscale, lo_s,
-                                                                    cfg->voxel_shape, vox, bad);
-  const size_t vx_bytes = sg_voxelize_idx_workspace_bytes(S);
-  SG_TAKE(vx_ws, char, vx_bytes);
-  SG_TAKE(inp_map, int32_t, S);
-  SG_TRY(sg_voxelize_idx_build(vox, S, 4, 4, inp_map, meta + 40, vx_ws, vx_bytes, stream_));
-  // meta[40] = voxels, meta[41] = max points per voxel, bad[0] = a coordinate left the grid
-  hipMemcpyAsync(meta + 42, bad, sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
-  SG_TRY(read_back(host, meta + 40, 3, stream, kWhat));
-  const int M = host[0], mA = host[1];
-  SG_REQUIRE(host[2] == 0, "sg_scan_grouping: a proposal voxel coordinate fell outside [0, %d) "
-             "(the reference asserts here, softgroup.py:698)", cfg->voxel_shape);
-  res->n_voxels = M;
-  res->max_active = mA;
-  SG_TAKE(vc64, int64_t, 4 * static_cast<size_t>(M));
-  SG_TAKE(rules, int32_t, static_cast<size_t>(M) * (mA + 1));
-  SG_TRY(sg_voxelize_idx_fill(vox, S, 4, 4, inp_map, M, mA, vc64, rules, vx_ws, vx_bytes, stream_));
-  SG_TAKE(vc32, int32_t, 4 * static_cast<size_t>(M));
-  SG_TAKE(vox_off, int32_t, static_cast<size_t>(n_prop) + 1);
-  SG_TAKE(vfeat, float, static_cast<size_t>(M) * C);
-  proposal_voxel_pack_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vc64, M, n_prop, vc32, vox_off);
-  proposal_voxel_feats_kernel<<<grid_for(static_cast<int64_t>(M) * C, 256), 256, 0, stream>>>(
-      point_feats, pairs, rules, M, mA, C, vfeat);
-  res->voxel_coords = ar.at(vc32);
-  res->voxel_offsets = ar.at(vox_off);
-  res->voxel_feats = ar.at(vfeat);
-  res->point_to_voxel = ar.at(inp_map);
-  res->arena_used = ar.off;
-  return check_launch(kWhat);
+  return voxelise_proposals(cfg, pairs, poff, n_prop, S, coords_float, point_feats, ar, meta, host, res, stream_, kWhat);
+}
+
+int sg_scan_grouping_pp(const sg_grouping_pp_cfg *pcfg, const float *scores, const float *pt_offsets,
+                        const float *coords_float, const int32_t *batch_idxs, const float *point_feats,
+                        void *arena, size_t arena_bytes, sg_grouping_result *res, sg_stream_t stream_) {
+  static const char *kWhat = "sg_scan_grouping_pp";
+  SG_REQUIRE(pcfg != nullptr && res != nullptr, "sg_scan_grouping_pp: null descriptor");
+  const sg_grouping_cfg *cfg = &pcfg->base;
+  SG_REQUIRE(cfg->n_points >= 0 && cfg->n_sem_classes >= 1 && cfg->n_seg >= 0 && cfg->n_seg <= kMaxSeg &&
+                 cfg->batch_size >= 1 && cfg->feat_channels >= 1 && cfg->voxel_shape >= 0,
+             "sg_scan_grouping_pp: bad configuration (n_seg must be <= %d)", kMaxSeg);
+  SG_REQUIRE(pcfg->radius > 0 && (!pcfg->with_pyramid || pcfg->base_size > 0),
+             "sg_scan_grouping_pp: radius and pyramid_base_size must be positive");
+  memset(res, 0, sizeof(*res));
+  hipStream_t stream = as_stream(stream_);
+  int32_t *host = pinned_words();
+  SG_REQUIRE(host != nullptr, "sg_scan_grouping_pp: no pinned host words");
+  ScanArena ar(arena, arena_bytes);
+  const int n = cfg->n_points, n_seg = cfg->n_seg;
+  if (n == 0 || n_seg == 0) return SG_OK;
+
+  // ---- class selection of ALL classes (class-major, points ascending: what the reference's per-class
+  //      nonzero yields), ONE read-back of the per-class counts (classes below min_npoint read 0)
+  const int n_blocks = (n + kSelBlock - 1) / kSelBlock;
+  SG_TAKE(meta, int32_t, 128);
+  SG_TAKE(blk_cnt, int32_t, static_cast<size_t>(n_seg) * n_blocks);
+  SG_TAKE(blk_off, int32_t, static_cast<size_t>(n_seg) * n_blocks);
+  select_count_kernel<<<n_blocks, kSelBlock, 0, stream>>>(scores, n, cfg->n_sem_classes, cfg->seg_class, n_seg,
+                                                         cfg->score_thr, n_blocks, blk_cnt);
+  select_scan_kernel<<<1, 1024, 0, stream>>>(blk_cnt, n_seg, n_blocks, cfg->min_npoint, blk_off, meta);
+  SG_TRY(check_launch(kWhat));
+  SG_TRY(read_back(host, meta, 1 + n_seg, stream, kWhat));
+  const int n_sel = host[0];
+  int count[kMaxSeg];
+  for (int s = 0; s < n_seg; ++s) count[s] = host[1 + s];
+  res->n_selected = n_sel;
+  if (n_sel == 0) return SG_OK;
+  SG_TAKE(obj, int32_t, n_sel);
+  SG_TAKE(seg_of, int32_t, n_sel);
+  SG_TAKE(pts, float, 3 * static_cast<size_t>(n_sel));
+  SG_TAKE(key, int32_t, n_sel);
+  select_emit_kernel<<<n_blocks, kSelBlock, 0, stream>>>(scores, n, cfg->n_sem_classes, cfg->seg_class, n_seg,
+                                                        cfg->score_thr, n_blocks, blk_off, coords_float,
+                                                        pt_offsets, batch_idxs, cfg->batch_size, obj, seg_of,
+                                                        pts, key);
+  // the scan's proposals: a point belongs to at most one cluster of its class
+  SG_TAKE(pairs, int32_t, 2 * static_cast<size_t>(n_sel));
+  SG_TAKE(poff, int32_t, static_cast<size_t>(n_sel) + 2);
+  int n_prop = 0, S = 0;
+  int64_t n_nbr = 0;
+  const size_t loop_mark = ar.off;       // per-class temporaries: the same region for every class (stream order)
+  bool hook_pending = t_scan_emit_hook != nullptr;
+  int s0 = 0;
+  for (int s = 0; s < n_seg; s0 += count[s], ++s) {
+    const int nc_pts = count[s];
+    if (nc_pts == 0) continue;
+    ar.off = loop_mark;
+    // ---- level and radius of the class (softgroup.py:448-452, get_level :485-489)
+    int level = 1;
+    if (pcfg->with_pyramid) level = nc_pts > 1000000 ? 3 : nc_pts > 100000 ? 2 : 1;
+    const float radius = static_cast<float>(pcfg->with_pyramid ? pcfg->radius * level : pcfg->radius);
+    const bool mapped = pcfg->with_pyramid && (level > 1 || !pcfg->lvl_fusion);
+    const float *q = pts + 3 * static_cast<size_t>(s0);
+    const int32_t *qb = key + s0;      // (one class: the batch key separates scenes only)
+    int n_q = nc_pts, n_lvl = 0;
+    const int32_t *l2p = nullptr;
+    if (mapped) {      // pyramid_map (:491-498): level voxels, pooled coordinates and offsets
+      const float inv = 1.0f / static_cast<float>(pcfg->base_size * level);
+      SG_TAKE(vox, int64_t, 4 * static_cast<size_t>(nc_pts));
+      SG_TAKE(c3, float, 3 * static_cast<size_t>(nc_pts));
+      SG_TAKE(o3, float, 3 * static_cast<size_t>(nc_pts));
+      pp_level_inputs_kernel<<<grid_for(nc_pts, 256, 1 << 22), 256, 0, stream>>>(obj + s0, nc_pts, coords_float, pt_offsets,
+                                                                            batch_idxs, inv, vox, c3, o3);
+      const size_t vx_bytes = sg_voxelize_idx_workspace_bytes(nc_pts);
+      SG_TAKE(vx_ws, char, vx_bytes);
+      SG_TAKE(l2p_, int32_t, nc_pts);
+      SG_TRY(sg_voxelize_idx_build(vox, nc_pts, 4, 4, l2p_, meta + 40, vx_ws, vx_bytes, stream_));
+      SG_TRY(read_back(host, meta + 40, 2, stream, kWhat));
+      const int M = host[0], mA = host[1];
+      SG_TAKE(vc64, int64_t, 4 * static_cast<size_t>(M));
+      SG_TAKE(rules, int32_t, static_cast<size_t>(M) * (mA + 1));
+      SG_TRY(sg_voxelize_idx_fill(vox, nc_pts, 4, 4, l2p_, M, mA, vc64, rules, vx_ws, vx_bytes, stream_));
+      SG_TAKE(cl, float, 3 * static_cast<size_t>(M));
+      SG_TAKE(ol, float, 3 * static_cast<size_t>(M));
+      SG_TAKE(ql, float, 3 * static_cast<size_t>(M));
+      SG_TAKE(qbl, int32_t, M);
+      SG_TRY(sg_voxelize_fp(c3, rules, M, mA, 3, 1, cl, stream_));
+      SG_TRY(sg_voxelize_fp(o3, rules, M, mA, 3, 1, ol, stream_));
+      pp_level_points_kernel<<<grid_for(M, 256, 1 << 22), 256, 0, stream>>>(cl, ol, vc64, M, ql, qbl);
+      q = ql;
+      qb = qbl;
+      n_q = n_lvl = M;
+      l2p = l2p_;
+    }
+    // ---- neighbour lists (functions.py:7-44): octree walk or hashed grid; count, scan, ONE read-back, fill
+    SG_TAKE(start_len, int32_t, 2 * static_cast<size_t>(n_q));
+    const size_t sc_bytes = sg_scan_workspace_bytes(n_q);
+    SG_TAKE(sc_ws, char, sc_bytes);
+    hipMemsetAsync(start_len, 0, sizeof(int32_t) * 2 * n_q, stream);
+    int32_t *bq_idx = nullptr;
+    int n_active = 0, flags = 0;
+    if (pcfg->with_octree) {
+      SG_TAKE(boxes, float, (1 + 8 + 64 + 512) * 6);
+      SG_TAKE(pt_inds, int32_t, n_q);
+      SG_TAKE(pt_sl, int32_t, 512 * 2);
+      const size_t ob = sg_octree_build_workspace_bytes(n_q);
+      SG_TAKE(o_ws, char, ob);
+      SG_TRY(sg_octree_build(q, n_q, boxes, pt_inds, pt_sl, o_ws, ob, stream_));
+      SG_TRY(sg_octree_ballquery_count(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, stream_));
+      SG_TRY(sg_exclusive_scan_startlen(start_len, n_q, meta + 56, sc_ws, sc_bytes, stream_));
+      SG_TRY(read_back(host, meta + 56, 1, stream, kWhat));
+      n_active = host[0];
+      SG_TAKE(idx_, int32_t, n_active);
+      SG_TRY(sg_octree_ballquery_fill(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, idx_, stream_));
+      bq_idx = idx_;
+      flags = SG_LISTS_RADIUS;
+    } else {
+      const size_t bq_bytes = sg_ballquery_workspace_bytes(n_q);
+      SG_TAKE(bq_ws, char, bq_bytes);
+      SG_TRY(sg_ballquery_build_grid(q, qb, n_q, radius, bq_ws, bq_bytes, stream_));
+      SG_TRY(sg_ballquery_count(q, qb, n_q, radius, start_len, nullptr, bq_ws, bq_bytes, stream_));
+      SG_TRY(sg_exclusive_scan_startlen(start_len, n_q, meta + 56, sc_ws, sc_bytes, stream_));
+      SG_TRY(read_back(host, meta + 56, 1, stream, kWhat));
+      n_active = host[0];
+      SG_TAKE(idx_, int32_t, n_active);
+      SG_TRY(sg_ballquery_fill(q, qb, n_q, radius, start_len, idx_, bq_ws, bq_bytes, stream_));
+      bq_idx = idx_;
+      flags = SG_LISTS_SORTED | SG_LISTS_RADIUS;
+    }
+    n_nbr += n_active;
+    // ---- clusters of the class (functions.py:278-308; threshold of the class = seg_thr[s])
+    const size_t bfs_bytes = sg_bfs_workspace_bytes(n_q, n_active);
+    SG_TAKE(bfs_ws, char, bfs_bytes);
+    int32_t nc = 0, sp = 0;
+    SG_TRY(sg_bfs_cluster_label(bq_idx, start_len, n_q, n_active, flags, nullptr, cfg->seg_thr + s, 1, &nc, &sp, bfs_ws,
+                                bfs_bytes, stream_));
+    if (sp == 0) continue;
+    SG_TAKE(cidx, int32_t, 2 * static_cast<size_t>(sp));
+    SG_TAKE(coff, int32_t, static_cast<size_t>(nc) + 1);
+    hipMemsetAsync(coff, 0, sizeof(int32_t) * (nc + 1), stream);
+    if (hook_pending) {
+      t_scan_emit_hook(t_scan_emit_ctx);
+      hook_pending = false;
+    }
+    SG_TRY(sg_bfs_cluster_emit(bq_idx, start_len, n_q, n_active, nullptr, cfg->seg_thr + s, nc, sp, cidx, coff, bfs_ws,
+                               bfs_bytes, stream_));
+    const int32_t *src_idx = cidx, *src_off = coff;
+    int rows = sp;
+    if (mapped) {      // pyramid_inverse_map (:500-507): proposals over level voxels -> over the class's points
+      SG_TAKE(oidx, int32_t, 2 * static_cast<size_t>(nc_pts));
+      SG_TAKE(ooff, int32_t, static_cast<size_t>(nc) + 1);
+      const size_t ib = sg_pyramid_inverse_map_workspace_bytes(nc_pts, n_lvl, nc);
+      SG_TAKE(i_ws, char, ib);
+      SG_TRY(sg_pyramid_inverse_map(cidx, sp, nc, l2p, nc_pts, n_lvl, oidx, ooff, meta + 48, i_ws, ib, stream_));
+      SG_TRY(read_back(host, meta + 48, 1, stream, kWhat));
+      rows = host[0];
+      src_idx = oidx;
+      src_off = ooff;
+    }
+    if (rows == 0) continue;
+    SG_REQUIRE(S + rows <= n_sel, "sg_scan_grouping_pp: more proposal rows than selected points");
+    pp_append_kernel<<<grid_for(rows > nc ? rows : nc, 256, 1 << 22), 256, 0, stream>>>(src_idx, rows, src_off, nc, obj + s0,
+                                                                                    n_prop, S, pairs, poff);
+    n_prop += nc;
+    S += rows;
+  }
+  ar.off = loop_mark;
+  res->n_neighbours = static_cast<int>(n_nbr < 0x7fffffff ? n_nbr : 0x7fffffff);
+  res->n_proposals = n_prop;
+  res->sum_npoint = S;
+  if (S == 0) return check_launch(kWhat);
+  res->proposals_idx = ar.at(pairs);
+  res->proposals_offset = ar.at(poff);
+  if (cfg->voxel_shape == 0) {
+    res->arena_used = ar.off;
+    return check_launch(kWhat);
+  }
+  return voxelise_proposals(cfg, pairs, poff, n_prop, S, coords_float, point_feats, ar, meta, host, res, stream_, kWhat);
 }
 
 // ---- results -------------------------------------------------------------------------------------

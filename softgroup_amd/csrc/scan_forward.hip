@@ -21,6 +21,7 @@
 // BFS emission -- one workgroup per cluster, the rest of the chip idle -- instead of right after the
 // point-wise heads, where its 131 072-workgroup blit kept the one-workgroup class-selection scan waiting
 // for a slot for 0.2 ms (profiles/r05_kernel_stats.csv: select_scan_kernel min 20.6 / max 230 us).
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -40,6 +41,8 @@ namespace sg {
 
 // hook of sg_scan_grouping (scan_exec.hip): called once, right before the ordered emission
 extern thread_local void (*t_scan_emit_hook)(void *);
+extern thread_local void (*t_unet_conv_hook)(void *);
+extern thread_local void *t_unet_conv_ctx;
 extern thread_local void *t_scan_emit_ctx;
 
 // ---- voxel feature pooling over [a | b] (softgroup.py:302-305: torch.cat + ops.voxelization): the
@@ -187,8 +190,30 @@ __global__ void __launch_bounds__(256) pack_segments_kernel(PackList p, char *__
 // ---- per (device, caller stream): the side stream of the dense results' copy and its two events
 struct ScanStream {
   hipStream_t copy = nullptr;
-  hipEvent_t packed = nullptr, copied = nullptr;
+  hipEvent_t packed = nullptr, copied = nullptr, backbone_done = nullptr;
 };
+// Backbone token (SG_SCAN_TOKEN=1; off by default until measured): with several scans in flight on one
+// device (one host thread and stream each) only ONE of them is inside its backbone -- the part of a scan
+// whose kernels fill the whole chip and gain nothing from running next to another backbone -- while the
+// others' grouping / refinement stages (small grids, host read-backs) run in its shadow.  Scans that
+// start together no longer move through their phases in lock step.
+// Form 2 (SG_SCAN_TOKEN=2) orders the backbones on the GPU instead of on the host: the convolutions of a scan
+// wait (hipStreamWaitEvent) for the event behind the previous scan's backbone, whichever stream that ran on; the
+// mutex is held only while the backbone is being enqueued, nobody blocks on the device.
+static std::mutex g_backbone_mu[16];
+static hipEvent_t g_backbone_last[16];        // event behind the latest backbone enqueued on the device (under the mutex)
+struct BackboneToken {
+  int dev;
+  hipStream_t stream;
+  std::unique_lock<std::mutex> lock;
+  bool taken = false;
+};
+static void backbone_token_take(void *ctx) {      // (sg_unet_forward's pre-conv hook)
+  BackboneToken *t = static_cast<BackboneToken *>(ctx);
+  t->lock = std::unique_lock<std::mutex>(g_backbone_mu[t->dev]);
+  t->taken = true;
+  if (g_backbone_last[t->dev] != nullptr) hipStreamWaitEvent(t->stream, g_backbone_last[t->dev], 0);
+}
 static std::mutex g_scan_mu;
 static std::map<std::pair<int, hipStream_t>, ScanStream> g_scan_streams;
 
@@ -200,7 +225,8 @@ static ScanStream *scan_stream(hipStream_t stream) {
   if (s.copy == nullptr) {
     if (hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s.packed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.backbone_done, hipEventDisableTiming) != hipSuccess) {
       s = ScanStream();
       return nullptr;
     }
@@ -217,6 +243,11 @@ void scan_release_stream(int dev, hipStream_t stream) {
     hipStreamDestroy(it->second.copy);
     hipEventDestroy(it->second.packed);
     hipEventDestroy(it->second.copied);
+    if (dev >= 0 && dev < 16) {
+      std::lock_guard<std::mutex> b(g_backbone_mu[dev]);
+      if (g_backbone_last[dev] == it->second.backbone_done) g_backbone_last[dev] = nullptr;
+    }
+    hipEventDestroy(it->second.backbone_done);
   }
   g_scan_streams.erase(it);
 }
@@ -412,6 +443,26 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
   const size_t scratch0 = ar.off;
 
   // ---- 1. voxel feature pooling, backbone, point-wise heads, softmax
+  static const int token_env = getenv("SG_SCAN_TOKEN") ? atoi(getenv("SG_SCAN_TOKEN")) : 0;
+  int token_mode = 0;
+  int dev = 0;
+  if (token_env != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+    std::lock_guard<std::mutex> g(g_scan_mu);
+    int n = 0;
+    for (const auto &kv : g_scan_streams) n += kv.first.first == dev;
+    if (n > 1) token_mode = token_env;      // (a single caller stream: nothing to order)
+  }
+  const bool use_token = token_mode == 3;       // (3: host-held from before the index build, the first form measured)
+  std::unique_lock<std::mutex> token;
+  if (use_token) token = std::unique_lock<std::mutex>(g_backbone_mu[dev]);
+  BackboneToken bt{dev, stream, {}, false};
+  struct TokenHookScope {      // (the hook is cleared by sg_unet_forward when it runs; here for the error paths before that)
+    ~TokenHookScope() { t_unet_conv_hook = nullptr; t_unet_conv_ctx = nullptr; }
+  } token_hook_scope;
+  if (token_mode == 1 || token_mode == 2) {
+    t_unet_conv_hook = backbone_token_take;
+    t_unet_conv_ctx = &bt;
+  }
   voxelize_cat_kernel<<<grid_for(static_cast<int64_t>(M) * cin, 256), 256, 0, stream>>>(
       in->feats, in->feat_dim, d->with_coords ? in->coords_float : nullptr, d->with_coords ? 3 : 0, in->p2v_map, M,
       in->max_active, vfeat);
@@ -437,6 +488,14 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
     pack_segments_kernel<<<dim3(grid_for(static_cast<int64_t>(mx / 16 + 1), 256, 512), pl.n), 256, 0, stream>>>(pl, dense_dev);
   }
   SG_TRY_(check_launch(kWhat));
+  if (bt.taken) {       // behind this point of the stream the next scan's convolutions may run
+    if (hipEventRecord(ss->backbone_done, stream) == hipSuccess) {
+      g_backbone_last[dev] = ss->backbone_done;
+      if (token_mode == 1) hipEventSynchronize(ss->backbone_done);      // form 1: the host holds the token until then
+    }
+    bt.lock.unlock();
+    bt.taken = false;
+  }
   DenseCopy dc{ss, stream, dense_dev, host_dense, dense_total, false, false};
   struct DenseGuard {      // no return leaves a copy into the caller's host block in flight
     DenseCopy &d;
@@ -460,6 +519,13 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
     return SG_OK;
   }
   SG_TRY_(sg_softmax_rows(sem, N, ns, prob, stream_));
+  if (use_token) {      // the next scan's backbone may start when this one's has left the GPU
+    if (hipEventRecord(ss->backbone_done, stream) != hipSuccess || hipEventSynchronize(ss->backbone_done) != hipSuccess) {
+      set_error("%s: waiting for the backbone failed", kWhat);
+      return SG_ERR_LAUNCH;
+    }
+    token.unlock();
+  }
 
   // ---- 2. grouping head + proposal voxelisation (its sub-arena starts at the scratch mark)
   sg_grouping_cfg gc = d->grouping;

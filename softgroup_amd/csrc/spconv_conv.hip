@@ -1037,6 +1037,7 @@ struct ChainArgs {
   ChainStep s[kChainMax];
   unsigned *bar;           // zeroed barrier block (kChainBarWords)
   unsigned *abort_host;    // pinned host word: set when a barrier timed out
+  unsigned long long *trace;   // developer tracing (SG_CHAIN_TRACE): [step][workgroup][4] real-time stamps, or null
   int n;
 };
 static_assert(sizeof(ChainArgs) <= 4096, "the step list must fit the kernel-argument segment");
@@ -1048,10 +1049,12 @@ constexpr unsigned long long kChainTimeout = 200000000ull;     // 2 s of the 100
 // of ITS group (blockIdx % 8: the XCD under the default dispatch order; any placement is correct), the
 // last of a group arrives at the top counter, the last of all publishes the epoch to every group's
 // generation word; everyone polls its own group's word with relaxed loads and a sleep.
-__device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned epoch, unsigned *abort_host, int *flag_lds) {
+__device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned epoch, unsigned *abort_host, int *flag_lds,
+                                              unsigned long long *stamp) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
     const unsigned x = blockIdx.x & 7, nx = (gridDim.x + 7u - x) >> 3;
     int ok = 1;
     const unsigned old = __hip_atomic_fetch_add(bar + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1077,6 +1080,7 @@ __device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned epoch, uns
       }
     }
     *flag_lds = ok;
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
   }
   __syncthreads();
   return *flag_lds != 0;
@@ -1124,6 +1128,8 @@ __global__ void __launch_bounds__(64 * kChainWV, 1) conv_chain_kernel(ChainArgs 
 #pragma nounroll
   for (int i = 0; i < a.n; ++i) {
     const ChainStep &s = a.s[i];
+    unsigned long long *stamp = a.trace ? a.trace + (static_cast<size_t>(i) * gridDim.x + blockIdx.x) * 4 : nullptr;
+    if (stamp && threadIdx.x == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
     if (s.kind == 0) {
       ConvArgs p;
       p.in = s.in; p.nbr = nullptr; p.w = s.w; p.post_scale = s.post_scale; p.post_shift = s.post_shift;
@@ -1138,7 +1144,8 @@ __global__ void __launch_bounds__(64 * kChainWV, 1) conv_chain_kernel(ChainArgs 
     } else {
       chain_elementwise(s);
     }
-    if (i + 1 < a.n && !chain_barrier(a.bar, static_cast<unsigned>(i + 1), a.abort_host, flag_lds)) return;
+    if (stamp && threadIdx.x == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
+    if (i + 1 < a.n && !chain_barrier(a.bar, static_cast<unsigned>(i + 1), a.abort_host, flag_lds, stamp)) return;
   }
 }
 
@@ -1369,13 +1376,14 @@ static unsigned *take_tickets(hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 struct ChainRec {
   int mode = 0;            // 0 closed | 1 open, single launches | 2 open, recording
-  bool b16 = false;        // arithmetic of the recorded steps (one kernel instantiation per launch)
+  bool b16 = false;        // arithmetic of the recorded conv steps (one kernel instantiation per launch)
+  bool arith_set = false;  // ... once a conv step has been recorded
   int conv_steps = 0;      // conv layers with K > 1 among the recorded steps (profile bookkeeping)
   hipStream_t stream = nullptr;
   ChainArgs args;
 };
 static thread_local ChainRec t_chain;
-static std::atomic<int> g_chain_override{-1};       // -1 = SG_CONV_CHAIN (default 1)
+static std::atomic<int> g_chain_override{-1};       // -1 = SG_CONV_CHAIN (default 0)
 static std::atomic<long long> g_chain_launches{0}, g_chain_steps{0};
 static std::mutex g_chain_mu;                                         // order of the chain launches of a device
 static std::map<int, hipEvent_t> g_chain_last;                        // device -> event behind its latest chain launch
@@ -1392,8 +1400,14 @@ static void chain_release_stream(int dev, hipStream_t stream) {      // (the str
   g_chain_events.erase(it);
 }
 
+// Off by default (round 6 measurements, profiles/r06_conv_chain.txt): a chain step costs what a launch costs --
+// the barrier is cheap (1.1-1.4 us after the last arrival + 0.2-0.6 us of store drain), but a small layer's
+// 8-15 us are the chain of dependent memory round trips INSIDE the layer (metadata -> first operands -> items
+// -> partial sums out -> arrival counter -> partial sums in), which a chain walks exactly like a launch does;
+// and its co-resident workgroups keep 8 waves x 156 VGPRs on every CU for 0.8 ms per scan, which costs the
+// scans running next to it more than the ~45 launches it saves them (5 scans in flight: 2.84 -> 3.17 ms/scan).
 static bool chain_enabled() {
-  static const int env = getenv("SG_CONV_CHAIN") ? atoi(getenv("SG_CONV_CHAIN")) : 1;
+  static const int env = getenv("SG_CONV_CHAIN") ? atoi(getenv("SG_CONV_CHAIN")) : 0;
   const int ov = g_chain_override.load(std::memory_order_relaxed);
   return (ov >= 0 ? ov : env) != 0;
 }
@@ -1432,7 +1446,12 @@ static int chain_flush() {
   }
   const size_t lds = static_cast<size_t>(kChainWV) * 16 * 64 * sizeof(float) + 2 * kMetaInts * sizeof(int32_t) + 16 +
                      static_cast<size_t>(kChainWV) * 4096;
-  const int grid = num_cu >= 8 ? num_cu - num_cu % 8 : num_cu;
+  // (developer knobs: SG_CHAIN_GRID = workgroups of a chain launch, at most one per CU; SG_CHAIN_SERIAL=0 lets chain
+  // launches of different streams overlap -- only safe while all of them together fit the device)
+  static const int grid_env = getenv("SG_CHAIN_GRID") ? atoi(getenv("SG_CHAIN_GRID")) : 0;
+  static const bool serial = !(getenv("SG_CHAIN_SERIAL") && atoi(getenv("SG_CHAIN_SERIAL")) == 0);
+  int grid = num_cu >= 8 ? num_cu - num_cu % 8 : num_cu;
+  if (grid_env >= 8 && grid_env < grid) grid = grid_env - grid_env % 8;
   const bool prof = g_conv_prof.enabled && c.conv_steps > 0;
   {
     std::lock_guard<std::mutex> lock(g_chain_mu);
@@ -1453,10 +1472,17 @@ static int chain_flush() {
       return SG_ERR_LAUNCH;
     }
     hipEvent_t &last = g_chain_last[dev];
-    if (last != nullptr && last != mine) hipStreamWaitEvent(c.stream, last, 0);    // one chain at a time per device
+    if (serial && last != nullptr && last != mine) hipStreamWaitEvent(c.stream, last, 0);    // one chain at a time per device
     if (prof) {
       hipEventRecord(g_conv_prof.take(), c.stream);
       for (int v : {-c.conv_steps, 0, 0, 0, 0}) g_conv_prof.dims.push_back(v);
+    }
+    static const char *trace_env = getenv("SG_CHAIN_TRACE");      // developer tool: per-step, per-workgroup stamps
+    c.args.trace = nullptr;
+    const size_t trace_bytes = static_cast<size_t>(c.args.n) * grid * 4 * sizeof(unsigned long long);
+    if (trace_env) {
+      hipMalloc(&c.args.trace, trace_bytes);
+      hipMemsetAsync(c.args.trace, 0, trace_bytes, c.stream);
     }
     if (c.b16)
       conv_chain_kernel<2><<<grid, 64 * kChainWV, lds, c.stream>>>(c.args);
@@ -1465,21 +1491,43 @@ static int chain_flush() {
     if (prof) hipEventRecord(g_conv_prof.take(), c.stream);
     hipEventRecord(mine, c.stream);
     last = mine;
+    if (trace_env && c.args.trace) {
+      hipStreamSynchronize(c.stream);
+      std::vector<unsigned long long> h(trace_bytes / 8);
+      hipMemcpy(h.data(), c.args.trace, trace_bytes, hipMemcpyDeviceToHost);
+      hipFree(c.args.trace);
+      if (FILE *f = fopen(trace_env, "ab")) {
+        long long hdr[4] = {c.args.n, grid, 0, 0};
+        fwrite(hdr, 8, 4, f);
+        for (int i = 0; i < c.args.n; ++i) {
+          const ChainStep &st = c.args.s[i];
+          long long d[8] = {st.kind, st.M_out, st.K, st.Cin, st.Cout, st.num_units, st.ksplit, st.col_units};
+          fwrite(d, 8, 8, f);
+        }
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    }
   }
   g_chain_launches.fetch_add(1, std::memory_order_relaxed);
   g_chain_steps.fetch_add(c.args.n, std::memory_order_relaxed);
   c.args.n = 0;
   c.conv_steps = 0;
+  c.arith_set = false;
   return check_launch("conv chain");
 }
 
 static int chain_push(const ChainStep &st, bool b16, bool counts) {
   ChainRec &c = t_chain;
-  if (c.args.n > 0 && (c.args.n == kChainMax || c.b16 != b16)) {
+  const bool conv = st.kind == 0;      // (an elementwise step runs under either instantiation)
+  if (c.args.n > 0 && (c.args.n == kChainMax || (conv && c.arith_set && c.b16 != b16))) {
     const int rc = chain_flush();
     if (rc != SG_OK) return rc;
   }
-  c.b16 = b16;
+  if (conv) {
+    c.b16 = b16;
+    c.arith_set = true;
+  }
   c.args.s[c.args.n++] = st;
   if (counts) ++c.conv_steps;
   return SG_OK;
@@ -1491,6 +1539,7 @@ void conv_chain_begin(hipStream_t stream) {
   c.stream = stream;
   c.args.n = 0;
   c.conv_steps = 0;
+  c.arith_set = false;
 }
 bool conv_chain_recording() { return t_chain.mode == 2; }
 int conv_chain_end() {

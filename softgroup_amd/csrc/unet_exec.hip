@@ -324,6 +324,11 @@ __global__ void __launch_bounds__(256) pad_channels_kernel(const float *__restri
     return SG_ERR_WORKSPACE;                                                           \
   }
 
+// called by sg_unet_forward on the calling thread when the index build has been enqueued and the first
+// convolution is about to be (sg_scan_forward: the backbone token, scan_forward.hip); cleared by the call
+thread_local void (*t_unet_conv_hook)(void *) = nullptr;
+thread_local void *t_unet_conv_ctx = nullptr;
+
 struct Exec {
   const sg_unet_desc *d;
   Arena ar;             // features and conv scratch: caller's stream only
@@ -657,6 +662,11 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   if (rest_bytes <= used) {
     set_error("sg_unet_forward: arena too small (%zu bytes)", arena_bytes);
     return SG_ERR_WORKSPACE;
+  }
+  if (t_unet_conv_hook != nullptr) {
+    void (*hook)(void *) = t_unet_conv_hook;
+    t_unet_conv_hook = nullptr;
+    hook(t_unet_conv_ctx);
   }
   Exec ex(d, rest + used, rest_bytes - used, stream, li);
   ex.perm = pre ? perm : nullptr;

@@ -21,6 +21,12 @@ class GroupingCfg(C.Structure):
                 ('voxel_scale', C.c_float), ('voxel_shape', C.c_int), ('feat_channels', C.c_int)]
 
 
+class GroupingPPCfg(C.Structure):
+    """sg_grouping_pp_cfg: the SoftGroup++ grouping (pyramid levels / octree query), one class at a time in C"""
+    _fields_ = [('base', GroupingCfg), ('with_pyramid', C.c_int), ('with_octree', C.c_int), ('lvl_fusion', C.c_int),
+                ('radius', C.c_double), ('base_size', C.c_double)]
+
+
 class GroupingResult(C.Structure):
     _fields_ = [('n_selected', C.c_int), ('n_neighbours', C.c_int), ('n_proposals', C.c_int),
                 ('sum_npoint', C.c_int), ('n_voxels', C.c_int), ('max_active', C.c_int),
@@ -76,15 +82,19 @@ def grouping(cfg, scores, pt_offsets, coords_float, batch_idxs, point_feats):
     dev = scores.device
     res = GroupingResult()
     nbytes = max(_arenas.get(('g', dev, L.stream()), torch.empty(0)).numel(), 96 << 20)
+    pp = isinstance(cfg, GroupingPPCfg)      # SoftGroup++: sg_scan_grouping_pp, same result layout
+    call = lib.sg_scan_grouping_pp if pp else lib.sg_scan_grouping
     for _ in range(8):
         arena = _arena('g', nbytes, dev)
-        rc = lib.sg_scan_grouping(C.byref(cfg), L.ptr(scores), L.ptr(pt_offsets), L.ptr(coords_float),
-                                  L.ptr(batch_idxs), L.ptr(point_feats), L.ptr(arena), arena.numel(),
-                                  C.byref(res), L.stream())
+        rc = call(C.byref(cfg), L.ptr(scores), L.ptr(pt_offsets), L.ptr(coords_float),
+                  L.ptr(batch_idxs), L.ptr(point_feats), L.ptr(arena), arena.numel(),
+                  C.byref(res), L.stream())
         if rc != _ERR_WORKSPACE:
             break
         nbytes = max(int(res.arena_needed), 2 * arena.numel())
-    L.check(rc, 'sg_scan_grouping')
+    L.check(rc, 'sg_scan_grouping_pp' if pp else 'sg_scan_grouping')
+    if pp:
+        cfg = cfg.base
     if res.sum_npoint == 0:
         return None
     S, nP, M = res.sum_npoint, res.n_proposals, res.n_voxels

@@ -119,6 +119,7 @@ class SoftGroup(nn.Module):
         self.scan_result_hook = None      # callable(result dict) run by the scan worker before the result is handed back (scan_contexts > 1)
         self.use_fused_heads = os.environ.get('SG_FUSED_HEADS', '1') != '0'   # devoxelize + point-wise heads + arg-max as one kernel (inference)
         self.use_scan_forward = os.environ.get('SG_SCAN_FORWARD', '1') != '0'   # the whole scan as ONE C call (csrc/scan_forward.hip)
+        self.use_native_grouping_pp = os.environ.get('SG_NATIVE_GROUPING_PP', '1') != '0'   # SoftGroup++ grouping as one C call (sg_scan_grouping_pp)
         self.use_native_scan = os.environ.get('SG_NATIVE_SCAN', '1') != '0'   # grouping head + proposal voxelisation + instance extraction as
         #                              two C calls (csrc/scan_exec.hip) where the configuration allows
         self.async_results = True    # host-side result formatting overlaps the next forward
@@ -404,8 +405,8 @@ class SoftGroup(nn.Module):
         n_seg = self.semantic_classes - len(set(_cfg(g, 'ignore_classes')))
         return (self.use_native_scan and self.use_executor and semantic_scores.is_cuda
                 and output_feats.dtype == torch.float32 and not lvl_fusion and not x4_split
-                and not self.sem2ins_classes and not _cfg(g, 'with_pyramid', False)
-                and not _cfg(g, 'with_octree', False) and 0 < n_seg <= 32
+                and not self.sem2ins_classes and 0 < n_seg <= 32
+                and (self.use_native_grouping_pp or not (_cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False)))
                 and not _cfg(self.instance_voxel_cfg, 'rand_quantize', False))
 
     def _grouping_constants(self, dev):
@@ -468,6 +469,12 @@ class SoftGroup(nn.Module):
             seg_class=cls32.data_ptr(), seg_thr=seg_thr.data_ptr(), score_thr=_cfg(g, 'score_thr'),
             min_npoint=_cfg(self.test_cfg, 'min_npoint'), radius=_cfg(g, 'radius'), batch_size=int(batch_size),
             voxel_scale=_cfg(v, 'scale'), voxel_shape=_cfg(v, 'spatial_shape'), feat_channels=feats.size(1))
+        if _cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False):
+            # SoftGroup++: the per-class loop of _grouping_per_class (reference softgroup.py:443-463) inside C
+            cfg = NS.GroupingPPCfg(base=cfg, with_pyramid=int(bool(_cfg(g, 'with_pyramid', False))),
+                                   with_octree=int(bool(_cfg(g, 'with_octree', False))), lvl_fusion=0,
+                                   radius=float(_cfg(g, 'radius')),
+                                   base_size=float(_cfg(g, 'pyramid_base_size', 0.02)))
         r = NS.grouping(cfg, scores, offs, coords_float.contiguous(), batch_idxs.int().contiguous(), feats)
         if r is None:
             return None

@@ -25,7 +25,7 @@ def _mirrors():
         'sg_unet_block': UE._Block, 'sg_unet_level': UE._Level, 'sg_unet_desc': UE._Desc,
         'sg_train_bn': UT._TBn, 'sg_train_conv': UT._TConv, 'sg_unet_train_block': UT._TBlock,
         'sg_unet_train_level': UT._TLevel, 'sg_unet_train_desc': UT._TDesc,
-        'sg_grouping_cfg': NS.GroupingCfg, 'sg_grouping_result': NS.GroupingResult,
+        'sg_grouping_cfg': NS.GroupingCfg, 'sg_grouping_pp_cfg': NS.GroupingPPCfg, 'sg_grouping_result': NS.GroupingResult,
         'sg_instances_cfg': NS.InstancesCfg, 'sg_instances_result': NS.InstancesResult,
         'sg_mlp2': SGM._Mlp2, 'sg_linear': SF.Linear, 'sg_scan_dense_item': SF.DenseItem,
         'sg_scan_desc': SF.ScanDesc, 'sg_scan_input': SF.ScanInput, 'sg_scan_result': SF.ScanResult,

@@ -2,14 +2,14 @@
 U-Net levels (softgroup/model/blocks.py:82-143 from the strided conv into a level of <= 6144 rows down
 to the deepest level and back up) and a whole small U-Net (the tiny U-Net, softgroup/model/softgroup.py:93-95)
 run as ONE persistent launch per <= 22 layers with a grid barrier between two layers.
-  * chains on (default) against chains off (sg_spconv_set_chain(0): every layer its own launch, same
-    decomposition): BIT-identical U-Net outputs -- backbone of the ScanNet model (7 levels, chains cut into
+  * chains on (sg_spconv_set_chain(1)) against chains off (the default -- measured neutral to slower,
+    profiles/r06_conv_chain.txt: every layer its own launch, same decomposition): BIT-identical U-Net outputs -- backbone of the ScanNet model (7 levels, chains cut into
     several launches), a 3-level U-Net with an input conv at degenerate sizes, a U-Net that is one chain from
     its first layer on (with the stray BatchNorm+ReLU step), bf16-operand arithmetic;
   * against the module path (one Python call per layer, the decomposition of the single launches): conv tolerance;
   * the whole scan with chains on == chains off: every dense result and every instance bit-identical;
   * chains of concurrent scans (3 streams) never overlap (the launch orders them) and stay bit-identical:
-    tests/test_scan_contexts_gpu.py runs with chains on."""
+    test_concurrent_scans_with_chains below."""
 import ctypes as C
 import functools
 
@@ -190,3 +190,35 @@ def test_whole_scan_with_chains_equals_without(chain_modes):
         assert a['label_id'] == c['label_id'] and a['conf'] == c['conf'] and a['pred_mask'] == c['pred_mask']
     for k in ('semantic_preds', 'offset_preds'):
         np.testing.assert_array_equal(on[k], off[k])
+
+
+def test_concurrent_scans_with_chains():
+    """three scans in flight on three streams, chains on: chain launches of different streams are ordered by
+    the library (their workgroups must all be resident at once), results equal the one-at-a-time results"""
+    lib = L.lib()
+    scenes = []
+    for i in range(3):
+        xyz, rgb, inst = synthetic.scene_s2(seed=11 + i, n=50000, room_scale=0.55)
+        b = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+        scenes.append({k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    model = synthetic.build_model(seed=0)
+    try:
+        L.check(lib.sg_spconv_set_chain(1), 'sg_spconv_set_chain')
+        with torch.no_grad():
+            model.scan_contexts = 1
+            alone = [dict(model(b)) for b in scenes]
+            model.scan_contexts = 3
+            s0 = _stats()
+            rs = [model(scenes[i % 3]) for i in range(12)]
+            got = [dict(r) for r in rs]
+            assert _stats()[0] - s0[0] >= 12 * 3
+    finally:
+        lib.sg_spconv_set_chain(-1)
+        model.scan_contexts = 1
+    for i, g in enumerate(got):
+        a = alone[i % 3]
+        assert len(g['pred_instances']) == len(a['pred_instances'])
+        for x, y in zip(g['pred_instances'], a['pred_instances']):
+            assert x['label_id'] == y['label_id'] and x['conf'] == y['conf'] and x['pred_mask'] == y['pred_mask']
+        np.testing.assert_array_equal(g['semantic_preds'], a['semantic_preds'])
+        np.testing.assert_array_equal(g['offset_preds'], a['offset_preds'])

@@ -264,3 +264,54 @@ def test_panoptic_fusion_skips_overlapping_instances():
     exp = (want & 0xFFFF) | (ids << 16)
     exp[(want >= 11) & (ids == 0)] = 19
     np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize('points,scale', [(150000, 40.0), (60000, 25.0)])
+def test_softgroup_pp_grouping_in_c_equals_the_per_class_loop(points, scale):
+    """sg_scan_grouping_pp (SoftGroup++: per-class pyramid level from the class size, level voxels with pooled
+    coordinates / offsets, octree ball query at radius x level, clusters, inverse map; reference
+    softgroup.py:433-466, functions.py:14-44) against the per-class loop over the operator surface
+    (_grouping_per_class, which test_parity_at_size pins to the oracle): proposals, proposal voxels, pooled
+    features and the scan's instances bit-identical.  150 k points x 40: the big class takes level 2."""
+    import copy
+    xyz, rgb, inst = synthetic.scene_s2(seed=1, n=points)
+    xyz = (xyz * np.float32(scale)).astype(np.float32)
+    batch = synthetic.make_batch(xyz, rgb, scale=3, instance_labels=inst)
+    b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    cfg = copy.deepcopy(synthetic.STPLS3D_PP_MODEL_CFG)
+    model = synthetic.build_model(cfg, seed=0)
+    model.async_results = False
+    with torch.no_grad():
+        vf = ops.voxelization(b['feats'], b['p2v_map'])
+        x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], 1)
+        sem, off, feats = model.forward_backbone(x, b['v2p_map'])
+        bidx = b['batch_idxs'].int()
+        # (a) the grouping stage alone
+        pidx, poff = model.forward_grouping(sem, off, bidx, b['coords_float'], model.grouping_cfg, batch_size=1)
+        assert poff.numel() - 1 >= 20
+        from softgroup_amd.model import native_scan as NS
+        g, v = model.grouping_cfg, model.instance_voxel_cfg
+        _, seg_thr, _, cls32 = model._grouping_constants(sem.device)
+        scores = sem.float().softmax(-1)
+        base = NS.GroupingCfg(n_points=scores.size(0), n_sem_classes=scores.size(1), n_seg=cls32.numel(),
+                              seg_class=cls32.data_ptr(), seg_thr=seg_thr.data_ptr(), score_thr=g['score_thr'],
+                              min_npoint=model.test_cfg['min_npoint'], radius=g['radius'], batch_size=1,
+                              voxel_scale=v['scale'], voxel_shape=v['spatial_shape'], feat_channels=feats.size(1))
+        pp = NS.GroupingPPCfg(base=base, with_pyramid=1, with_octree=1, lvl_fusion=0, radius=float(g['radius']),
+                              base_size=float(g['pyramid_base_size']))
+        r = NS.grouping(pp, scores, off.float().contiguous(), b['coords_float'].contiguous(), bidx.contiguous(),
+                        feats.contiguous())
+        assert torch.equal(r['proposals_idx'], pidx) and torch.equal(r['proposals_offset'], poff)
+        inst_t, inst_map = model.clusters_voxelization(pidx, poff, feats, b['coords_float'], **v)
+        assert torch.equal(r['voxel_coords'], inst_t.indices) and torch.equal(r['voxel_feats'], inst_t.features)
+        assert torch.equal(r['point_to_voxel'].long(), inst_map.long())
+        # (b) the whole scan, C driver against the per-class loop
+        assert model.use_native_grouping_pp
+        out_c = dict(model(b))
+        model.use_native_grouping_pp = False
+        out_py = dict(model(b))
+    assert len(out_c['pred_instances']) == len(out_py['pred_instances']) > 0
+    for a, c in zip(out_c['pred_instances'], out_py['pred_instances']):
+        assert a['label_id'] == c['label_id'] and a['pred_mask'] == c['pred_mask']
+        assert abs(float(a['conf']) - float(c['conf'])) <= 1e-6
+    np.testing.assert_array_equal(out_c['semantic_preds'], out_py['semantic_preds'])
