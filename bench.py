@@ -614,12 +614,40 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
         torch.cuda.synchronize()
         ms_h2d = (time.perf_counter() - t0) / 10 * 1e3
         del rets
+        # where the extra time goes: the collate alone (host copies into pinned staging + async H2D + device
+        # voxel index, synchronised), its host part alone (the staging copies)
+        ts = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b_ = collate_device([sample])
+            t2 = time.perf_counter()
+            torch.cuda.synchronize()
+            ts.append(((t2 - t1) * 1e3, (time.perf_counter() - t1) * 1e3))
+            del b_
+        collate_host_ms = sorted(t[0] for t in ts)[3]
+        collate_ms = sorted(t[1] for t in ts)[3]
+        # the same loop with the NEXT scan's collate on a loader thread and stream (data.prefetch_device: what
+        # DataLoader workers do for the reference's test loop, tools/test.py:145)
+        from softgroup_amd.data import prefetch_device
+        for b_ in prefetch_device([[sample]] * 2):
+            model(b_).resolve()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rets = [model(b_) for b_ in prefetch_device([[sample]] * 10)]
+        for r in rets:
+            r.resolve()
+        torch.cuda.synchronize()
+        ms_h2d_prefetch = (time.perf_counter() - t0) / 10 * 1e3
+        del rets
         # the host link of this box, for reading the figure: pinned -> device copy rate
         hbuf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
         dbuf = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
         link_ms = _events_ms(lambda: dbuf.copy_(hbuf, non_blocking=True), reps=5, warm=1)
         scan_bytes = sum(v.numel() * v.element_size() for v in sample if isinstance(v, torch.Tensor))
         legs['with_h2d'] = {'ms_per_step_with_h2d': round(ms_h2d, 3),
+                            'ms_per_step_with_h2d_next_scan_prefetched': round(ms_h2d_prefetch, 3),
+                            'collate_ms': round(collate_ms, 3), 'collate_host_part_ms': round(collate_host_ms, 3),
                             'host_bytes_per_scan': int(scan_bytes),
                             'pinned_h2d_GBps_on_this_box': round((64 << 20) / link_ms / 1e6, 2),
                             'note': 'one scan at a time; raw points pinned on the host -> async H2D -> '

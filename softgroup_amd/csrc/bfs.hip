@@ -21,6 +21,10 @@
 //      exactly the order the sequential queue produces.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 #include "scan.h"
 
@@ -847,10 +851,45 @@ __device__ __forceinline__ bool big_barrier(int32_t *bar, int &epoch, int32_t *f
   return *lds_flag != 0;
 }
 
+// The same rendezvous without the arrival counter (SG_BFS_BIG_FLAGS=1; off by default, measured no faster): every workgroup
+// stores the level's tag into ITS flag word once its claims have drained, and polls all G flags with one
+// coalesced load -- store -> visible -> poll is ONE trip through the fabric where atomic arrive -> return ->
+// poll is two.  Flags only grow (a workgroup that is already a level ahead still satisfies the wait).
+__device__ __forceinline__ bool big_flags_barrier(unsigned *flags, unsigned tag, int32_t *fail, int *lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int G = gridDim.x;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (lane == 0) __hip_atomic_store(flags + blockIdx.x, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    for (int w0 = 0; w0 < G && ok; w0 += 64) {
+      const int w = w0 + lane;
+      unsigned spins = 0;
+      while (true) {
+        const bool ready = w >= G || __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tag;
+        if (__all(ready)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u &&
+            (spins > (1u << 24) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (lane == 0) *lds_flag = ok;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
 // sync words: [0] barrier counter, [1] fail, [2..3] staging pool heads (per parity),
 // [64 ..] records: rec[parity][workgroup] = two self-validating 64-bit words (tag << 32 | value):
 // region offset and region length
 constexpr int kBigRecAt = 64;
+constexpr int kBigFlagsAt = kBigRecAt + 8 * kBigWgsMax;      // claim-done flags, one word per workgroup
+constexpr int kBigSyncWords = kBigFlagsAt + kBigWgsMax;
 
 //
 // FAST (the default; SG_BFS_BIG_FAST=0 selects the round-4 form): a level is a chain of dependent memory
@@ -874,7 +913,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
     int32_t *owner_g, int32_t *wcnt, int32_t *stage0, int32_t *stage1, u64 *srec0, u64 *srec1, int priv_base,
-    int32_t *cluster_idxs, int32_t *sync) {
+    int32_t *cluster_idxs, int32_t *sync, bool flag_barrier, bool trace_on) {
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int lds_flag, lds_off;
   __shared__ int node_off[kEmitThreads];
@@ -891,6 +930,18 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
   unsigned long long *rec = reinterpret_cast<unsigned long long *>(sync + kBigRecAt);     // [2][G][2]
   int epoch = 0;
   unsigned tag = 0;            // level counter over the whole launch (never 0 in a record)
+  // developer phase trace (SG_BFS_STATS; workgroup 0, thread 0; 100 MHz ticks summed over the cached levels):
+  // [0] wait for the records  [1] ranks + own region to the queue + staged records  [2] claim sweep
+  // [3] claim rendezvous  [4] emit sweep + drain  [5] cached levels
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+  const bool tracing = trace_on && b == 0 && threadIdx.x == 0;
+  auto stamp = [&](int i) {
+    if (tracing) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      ph[i] += now - t_prev;
+      t_prev = now;
+    }
+  };
   for (int c = 0; c < n_cluster; ++c) {
     const int off = cluster_offsets[c];
     const int size = cluster_offsets[c + 1] - off;
@@ -921,6 +972,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     }
     int tail = 0;       // queue entries written so far (the seed is counted with its level below)
     while (true) {
+      if (tracing) t_prev = __builtin_amdgcn_s_memrealtime();
       // ---- wait for the G records of the current frontier, then ranks: pre[w] = nodes before workgroup w
       if (wave == 0) {
         int ok = 1;
@@ -954,6 +1006,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       }
       __syncthreads();
       if (!lds_flag) return;
+      stamp(0);
       if (threadIdx.x == 0) {
         pre[0] = 0;
         for (int w = 0; w < G; ++w) pre[w + 1] += pre[w];
@@ -969,7 +1022,11 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         SG_ST(&Q[2 * (tail + my_pos + i) + 1], SG_LD(&cur[offs[b] + i]));
       }
       tail += L;
-      if (L == 0) break;                                           // cluster complete (uniform)
+      if (L == 0) {                                                // cluster complete (uniform)
+        if (tracing)
+          for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long *>(sync + 16)[i] = ph[i];
+        break;
+      }
       const int lo = static_cast<int>(static_cast<long long>(L) * b / G);
       const int hi = static_cast<int>(static_cast<long long>(L) * (b + 1) / G);
       auto rec_at = [&](int q, int &st, int &ln) {                 // frontier rank -> (list start, list length)
@@ -1019,14 +1076,16 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         }
         return j0;
       };
+      stamp(1);
       if (E >= 0) {
         const bool direct = E <= kBigDirectDegree * nn;
         for (int e = threadIdx.x; e < E; e += kEmitThreads) {      // flat over the range's edges
           const int jn = edge_node(e);
           const int p = e - c_eb[jn], g = c_st[jn] + p;
           int t = -1;
-          if ((erec[g].x & 0xffff) != 0xffff) {                    // else: target in another cluster
-            t = idx[g];
+          const int ex = erec[g].x, tg = idx[g];                  // (both loads in flight together)
+          if ((ex & 0xffff) != 0xffff) {                           // else: target in another cluster
+            t = tg;
             const int pos = ((lo + jn) << 10) | p;
             // (sparse lists: the atomic goes out unfiltered, one round trip less; dense lists send most of
             //  their edges to visited nodes, ~100 per node and level: there the filtering load stays)
@@ -1053,7 +1112,13 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         }
       }
       if (b == 0 && threadIdx.x == 0) SG_ST(&pool[par ^ 1], 0);   // next level's pool (idle since two levels)
-      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      stamp(2);
+      if (flag_barrier) {
+        if (!big_flags_barrier(reinterpret_cast<unsigned *>(sync + kBigFlagsAt), tag, fail, &lds_flag)) return;
+      } else if (!big_barrier(bar, epoch, fail, &lds_flag)) {
+        return;
+      }
+      stamp(3);
       if (E >= 0) {
         // ---- emit of a cached level
         if constexpr (FAST) {
@@ -1086,6 +1151,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
+          stamp(4);
+          if (tracing) ++ph[5];
           ++tag;
           par ^= 1;
           if (threadIdx.x == 0) {
@@ -1239,6 +1306,49 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
   }
 }
 
+// ---- the giant clusters' replay runs NEXT TO the per-cluster kernel, on a side stream of the caller's
+//      stream (the two touch disjoint clusters): one side stream and two events per (device, caller stream)
+struct BfsSide {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static std::mutex g_bfs_mu;
+static std::map<std::pair<int, hipStream_t>, BfsSide> g_bfs_side;
+static BfsSide *bfs_side(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> g(g_bfs_mu);
+  BfsSide &b = g_bfs_side[{dev, stream}];
+  if (b.side == nullptr) {
+    if (hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b.join, hipEventDisableTiming) != hipSuccess) {
+      b = BfsSide();
+      return nullptr;
+    }
+  }
+  return &b;
+}
+void bfs_release_stream(int dev, hipStream_t stream) {      // sg_stream_release: the caller's stream is idle
+  std::lock_guard<std::mutex> g(g_bfs_mu);
+  auto it = g_bfs_side.find({dev, stream});
+  if (it == g_bfs_side.end()) return;
+  if (it->second.side) {
+    hipStreamSynchronize(it->second.side);
+    hipStreamDestroy(it->second.side);
+    hipEventDestroy(it->second.fork);
+    hipEventDestroy(it->second.join);
+  }
+  g_bfs_side.erase(it);
+}
+// what sg_bfs_cluster_label learned about the largest kept cluster, for the sg_bfs_cluster_emit call that
+// follows on the same thread with the same workspace (else: unknown, the emit assumes a giant cluster may exist)
+struct BfsLabelNote {
+  const void *ws = nullptr;
+  int max_kept = -1;
+};
+static thread_local BfsLabelNote t_bfs_note;
+
 }  // namespace sg
 
 using namespace sg;
@@ -1293,7 +1403,7 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
 
   int32_t *host_counters = pinned_words();      // [0..3] counters, [8] propagation flag
   SG_REQUIRE(host_counters != nullptr, "sg_bfs_cluster_label: pinned allocation failed");
-  for (int i = 0; i < 4; ++i) host_counters[i] = 0;
+  for (int i = 0; i < 5; ++i) host_counters[i] = 0;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1) {
       // asymmetric edges exist: propagate min labels to the fixed point, then redo the sizes
@@ -1319,19 +1429,27 @@ int sg_bfs_cluster_label(const int32_t *bq_idxs, const int32_t *start_len, int n
       const float thr = seg_thr[seg_of_point ? seg_of_point[i] : 0];
       return static_cast<float>(size[i]) >= thr ? 1 : 0;  // bfs_cluster.cpp:73-81
     };
-    auto keep_size = [keep, size] __device__(int64_t i) -> int { return keep(i) ? size[i] : 0; };
+    int32_t *max_kept = w.counters + 4;      // largest kept cluster, if above kBigMin (else 0): decides the emit's launch set
+    auto keep_size = [keep, size, max_kept] __device__(int64_t i) -> int {
+      const int s = keep(i) ? size[i] : 0;
+      if (s > kBigMin) atomicMax(max_kept, s);
+      return s;
+    };
     int rc = exclusive_scan(keep, [cid] __device__(int64_t i, int v) { cid[i] = v; }, n,
                             w.counters + 2, w.scan_ws, w.scan_bytes, stream);
     if (rc != SG_OK) return rc;
     rc = exclusive_scan(keep_size, [coff] __device__(int64_t i, int v) { coff[i] = v; }, n,
                         w.counters + 3, w.scan_ws, w.scan_bytes, stream);
     if (rc != SG_OK) return rc;
-    hipMemcpyAsync(host_counters, w.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+    hipMemcpyAsync(host_counters, w.counters, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
     if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("sg_bfs_cluster_label");
     if (host_counters[0] == 0) break;
+    if (pass == 0) hipMemsetAsync(w.counters + 4, 0, 4, stream);      // (sizes are redone after the propagation)
   }
   *n_cluster_host = host_counters[2];
   *sum_npoint_host = host_counters[3];
+  t_bfs_note.ws = ws;
+  t_bfs_note.max_kept = host_counters[4];
   return check_launch("sg_bfs_cluster_label");
 }
 
@@ -1364,15 +1482,34 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   // giant clusters (> kBigMin points) are replayed by many workgroups together; the per-cluster
   // kernel skips them.  SG_BFS_BIG=0 (developer knob) keeps everything on the per-cluster kernel.
   static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
+  // is there a giant cluster?  Known from the labelling call when it was this thread's last one on this workspace
+  const bool noted = t_bfs_note.ws == ws && t_bfs_note.max_kept >= 0;
+  const bool has_big = big_on && sum_npoint > kBigMin && (!noted || t_bfs_note.max_kept > kBigMin);
+  t_bfs_note.ws = nullptr;
+  // the giant clusters' replay (16 workgroups, milliseconds) next to the per-cluster kernel (one workgroup per
+  // cluster, the rest of the chip): fork a side stream here, join behind both (SG_BFS_BIG_SIDE=0: one after the other)
+  static const bool side_env = !(getenv("SG_BFS_BIG_SIDE") && atoi(getenv("SG_BFS_BIG_SIDE")) == 0);
+  BfsSide *side = has_big && side_env && !want_stats ? bfs_side(stream) : nullptr;
+  hipStream_t main_stream = stream;
+  if (side != nullptr) {
+    if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->side, side->fork, 0) != hipSuccess) {
+      set_error("sg_bfs_cluster_emit: forking the side stream failed");
+      return SG_ERR_LAUNCH;
+    }
+  }
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
       stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr, thin_levels_on());
-  if (big_on && sum_npoint > kBigMin) {        // a giant cluster can exist at all
+  if (side != nullptr) stream = side->side;      // everything of the giant clusters goes to the side stream
+  if (has_big) {
     static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 16;   // developer knob
     const int big_wgs = big_wgs_env < 8 ? 8 : big_wgs_env > kBigWgsMax ? kBigWgsMax : big_wgs_env;
     int32_t *sync = w.asym_nodes;               // free after labelling; >= 64 + 8 * kBigWgsMax ints
-    if (static_cast<size_t>(n) >= 64 + 8 * kBigWgsMax) {
-      hipMemsetAsync(sync, 0, (64 + 8 * kBigWgsMax) * 4, stream);
+    // (developer knob; measured: no gain -- kitti 9.47 against 9.42 ms, stpls3d_pp 11.4-11.8 against 11.3-11.5,
+    //  profiles/r06_bfs_big_flags_ab.txt -- the arrival atomic is not what a level waits for; off)
+    static const bool flags_on = getenv("SG_BFS_BIG_FLAGS") && atoi(getenv("SG_BFS_BIG_FLAGS")) != 0;
+    if (static_cast<size_t>(n) >= static_cast<size_t>(kBigSyncWords)) {
+      hipMemsetAsync(sync, 0, kBigSyncWords * 4, stream);
       if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))      // test hook: pretend the barrier gave up
         if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
       // frontier staging pools (one per level parity, at most a cluster's points each): the union-find
@@ -1380,11 +1517,11 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
       if (big_fast_on() && big_wgs <= kBigFastWgs && w.big_stage[0] != nullptr)
         bfs_emit_big_kernel<true><<<big_wgs, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.big_stage[0],
-            w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync);
+            w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync, flags_on, want_stats);
       else
         bfs_emit_big_kernel<false><<<big_wgs, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.parent, w.lab,
-            nullptr, nullptr, 0, cluster_idxs, sync);
+            nullptr, nullptr, 0, cluster_idxs, sync, false, false);
       // sync[1] != 0: the replay gave up somewhere (see big_barrier) -- redo the giant clusters on
       // the per-cluster kernel (same output, slower); both launches are no-ops otherwise
       bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin,
@@ -1393,6 +1530,22 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
           bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner,
           cluster_idxs, nullptr, 0x7fffffff, kBigMin, sync + 1, thin_levels_on());
     }
+  }
+  if (side != nullptr) {
+    stream = main_stream;
+    if (hipEventRecord(side->join, side->side) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
+      set_error("sg_bfs_cluster_emit: joining the side stream failed");
+      return SG_ERR_LAUNCH;
+    }
+  }
+  if (want_stats && has_big) {
+    unsigned long long ph[6];
+    hipStreamSynchronize(stream);
+    hipMemcpy(ph, w.asym_nodes + 16, sizeof(ph), hipMemcpyDeviceToHost);
+    const double lv = ph[5] ? static_cast<double>(ph[5]) : 1.0;
+    fprintf(stderr, "bfs giant clusters: %llu cached levels; us per level: wait records %.2f, ranks+queue+staged records %.2f, "
+            "claim sweep %.2f, claim rendezvous %.2f, emit sweep+drain %.2f\n", ph[5], ph[0] / lv / 100.0, ph[1] / lv / 100.0,
+            ph[2] / lv / 100.0, ph[3] / lv / 100.0, ph[4] / lv / 100.0);
   }
   if (want_stats) {
     int32_t h[256 * 8];

@@ -163,5 +163,6 @@ int conv_chain_check_abort(const char *who);   // SG_ERR_LAUNCH once after a bar
 void conv_release_stream(int dev, hipStream_t stream);
 void unet_release_stream(int dev, hipStream_t stream);
 void scan_release_stream(int dev, hipStream_t stream);
+void bfs_release_stream(int dev, hipStream_t stream);
 
 }  // namespace sg

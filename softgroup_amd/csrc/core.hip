@@ -79,6 +79,7 @@ int sg_stream_release(sg_stream_t stream) {
   sg::conv_release_stream(dev, sg::as_stream(stream));
   sg::unet_release_stream(dev, sg::as_stream(stream));
   sg::scan_release_stream(dev, sg::as_stream(stream));
+  sg::bfs_release_stream(dev, sg::as_stream(stream));
   return SG_OK;
 }
 

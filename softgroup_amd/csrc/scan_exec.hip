@@ -246,10 +246,23 @@ __global__ void __launch_bounds__(256) proposal_voxel_feats_kernel(const float *
     const int32_t *r = rules + static_cast<int64_t>(row) * (max_active + 1);
     const int cnt = r[0];
     const float m = cnt > 0 ? __fdiv_rn(1.0f, static_cast<float>(cnt)) : 1.0f;
-    // (rule -> pair -> feature row is three dependent loads per point: four points' chains are in
-    //  flight at a time, the sum keeps the reference's order)
+    // (rule -> pair -> feature row is three dependent loads per point: sixteen points' chains are in
+    //  flight at a time -- a voxel of a giant proposal holds hundreds of points and its 32 channel threads
+    //  walk them alone: 330 -> ~100 us on the KITTI sweep --, the sum keeps the reference's order)
     float acc = 0.0f;
     int i = 1;
+    for (; i + 15 <= cnt; i += 16) {
+      int a[16], q[16];
+      float f[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = r[i + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q[j] = pairs[2LL * a[j] + 1];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] = feats[static_cast<int64_t>(q[j]) * C + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc = __fadd_rn(acc, __fmul_rn(m, f[j]));
+    }
     for (; i + 3 <= cnt; i += 4) {
       const int a0 = r[i], a1 = r[i + 1], a2 = r[i + 2], a3 = r[i + 3];
       const int p0 = pairs[2LL * a0 + 1], p1 = pairs[2LL * a1 + 1], p2 = pairs[2LL * a2 + 1],

@@ -264,3 +264,58 @@ def collate_device(batch, min_spatial=128, device='cuda'):
     voxel_coords, v2p_map, p2v_map = ops.voxelization_idx(d_coords, batch_id)   # device path
     out.update(voxel_coords=voxel_coords, v2p_map=v2p_map, p2v_map=p2v_map)
     return out
+
+
+def prefetch_device(batches, collate=None, depth=1, device='cuda'):
+    """Generator over device-resident batch dicts with the NEXT batch's collate -- the copies into pinned
+    staging, the asynchronous H2D transfers and the device voxel index -- running on a loader thread and its
+    own stream while the consumer works on the current one: what the reference gets from DataLoader workers
+    (data/__init__.py:28-47 building data/custom.py:196-256's ``collate_fn`` ahead of the test loop,
+    tools/test.py:145).  ``batches`` yields lists of dataset items; ``collate`` defaults to collate_device.
+    The consumer's current stream is made to wait for the loader stream's work (an event per batch); tensors
+    are registered with the consumer's stream so the caching allocator does not hand them out early."""
+    import queue
+    collate = collate or collate_device
+    dev = torch.device(device)
+    q = queue.Queue(maxsize=max(1, int(depth)))
+    stop = threading.Event()
+
+    def loader():
+        try:
+            with torch.cuda.device(dev):
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side), torch.no_grad():
+                    for items in batches:
+                        if stop.is_set():
+                            break
+                        out = collate(items, device=device)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        q.put((out, ev))
+            q.put(None)
+        except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+            q.put(e)
+
+    t = threading.Thread(target=loader, name='sg-prefetch', daemon=True)
+    t.start()
+    try:
+        while True:
+            got = q.get()
+            if got is None:
+                return
+            if isinstance(got, BaseException):
+                raise got
+            out, ev = got
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            for v in out.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
+            yield out
+    finally:
+        stop.set()
+        while t.is_alive():
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                t.join(0.01)

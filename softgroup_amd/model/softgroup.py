@@ -406,7 +406,11 @@ class SoftGroup(nn.Module):
         return (self.use_native_scan and self.use_executor and semantic_scores.is_cuda
                 and output_feats.dtype == torch.float32 and not lvl_fusion and not x4_split
                 and not self.sem2ins_classes and 0 < n_seg <= 32
-                and (self.use_native_grouping_pp or not (_cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False)))
+                and (not (_cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False))
+                     # SoftGroup++ in C (sg_scan_grouping_pp) carries the reference's get_level thresholds: a model
+                     # whose get_level was replaced (tests force level 2 on small scenes) keeps the per-class loop
+                     or (self.use_native_grouping_pp and 'get_level' not in self.__dict__
+                         and type(self).get_level is SoftGroup.get_level))
                 and not _cfg(self.instance_voxel_cfg, 'rand_quantize', False))
 
     def _grouping_constants(self, dev):

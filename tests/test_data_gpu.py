@@ -110,3 +110,43 @@ def test_collate_x4_device_equals_the_reference_s3dis_test_collate():
         if ref.dtype.kind in 'fiu':
             assert got.dtype == ref.dtype, (k, got.dtype, ref.dtype)
         assert np.array_equal(got, ref), k
+
+
+def test_prefetch_device_hands_over_the_same_batches_and_results():
+    """data.prefetch_device: the next scan's collate on a loader thread / stream (the reference's DataLoader
+    workers ahead of tools/test.py:145) -- every batch equal to collate_device's key by key, the scans' results
+    equal to the ones computed from batches collated in line, an exception of the loader reaches the consumer"""
+    from softgroup_amd.data import prefetch_device
+    items = []
+    for i in range(4):
+        xyz, rgb, inst = synthetic.scene_s2(seed=20 + i, n=20000 + 3000 * i, room_scale=0.4)
+        items.append(make_item(xyz, rgb, 50, None, inst, f's{i}'))
+    model = synthetic.build_model(seed=0)
+    model.async_results = False
+    with torch.no_grad():
+        want = [collate_device([it]) for it in items]
+        ref = [dict(model(b)) for b in want]
+        got = []
+        for k, b in enumerate(prefetch_device([[it] for it in items])):
+            for key, v in want[k].items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(b[key], v), key
+                elif isinstance(v, np.ndarray):
+                    assert np.array_equal(b[key], v), key
+                else:
+                    assert b[key] == v, key
+            got.append(dict(model(b)))
+    assert len(got) == 4
+    for a, c in zip(got, ref):
+        assert len(a['pred_instances']) == len(c['pred_instances'])
+        for x, y in zip(a['pred_instances'], c['pred_instances']):
+            assert x['label_id'] == y['label_id'] and x['conf'] == y['conf'] and x['pred_mask'] == y['pred_mask']
+        np.testing.assert_array_equal(a['semantic_preds'], c['semantic_preds'])
+
+    def broken():
+        yield [items[0]]
+        raise RuntimeError('loader failed')
+
+    with pytest.raises(RuntimeError, match='loader failed'):
+        for _ in prefetch_device(broken()):
+            pass

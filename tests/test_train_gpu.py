@@ -389,8 +389,12 @@ def test_forward_train_gradients_match_reference(case):
           [(round(w[0], 7), w[1]) for w in worst[:3]])
 
 
-def test_bf16_autocast_losses_explained():
-    """bf16 autocast vs fp32 on the same batch, weights and seed (BASELINE config 3 precision).
+@pytest.mark.parametrize('case,rel,abs_tol,min_agree', [('scannet_frozen', 0.02, 5e-3, 0.9), ('scannet_full', 0.05, 2e-2, 0.5)])
+def test_bf16_autocast_losses_explained(case, rel, abs_tol, min_agree):
+    """bf16 autocast vs fp32 on the same batch, weights and seed (BASELINE config 3 precision), with the
+    backbone frozen (fine-tune configs) and with NOTHING frozen (`scannet_full`: training-mode BatchNorm through
+    the whole backbone; profiles/r05_train_step.txt shows total losses 12.5 fp32 vs 9.5 bf16 on such a step --
+    this is the decomposition of that gap).
     The two runs differ for two reasons that this test separates:
       (1) rounding: with the PROPOSALS of the fp32 run handed to the bf16 run, every loss term
           agrees within bf16 accuracy through ~60 layers (2 % of the term, 5e-3 absolute);
@@ -399,7 +403,7 @@ def test_bf16_autocast_losses_explained():
           clusters -- a different (equally valid) sample of proposals, which moves the instance
           losses by more than rounding does.  Reported, and bounded by the share of proposal
           points both runs agree on."""
-    model, batch, ref, seed = _train_case('scannet_frozen')
+    model, batch, ref, seed = _train_case(case)
     model.train()
     model.use_native_scan = False      # the proposals are intercepted at forward_grouping (the native
     #                                    driver returns the same ones, tests/test_native_scan_gpu.py)
@@ -427,16 +431,16 @@ def test_bf16_autocast_losses_explained():
     a = set(map(tuple, p32[0].cpu().numpy()[:, 1:2].tolist()))
     b = set(map(tuple, p16[0].cpu().numpy()[:, 1:2].tolist()))
     agree = len(a & b) / max(len(a | b), 1)
-    print('fp32            ', {k: round(v, 5) for k, v in fp32.items()})
-    print('bf16, fp32 props', {k: round(v, 5) for k, v in same.items()})
-    print('bf16, own props ', {k: round(v, 5) for k, v in own.items()},
+    print(case, 'fp32            ', {k: round(v, 5) for k, v in fp32.items()})
+    print(case, 'bf16, fp32 props', {k: round(v, 5) for k, v in same.items()})
+    print(case, 'bf16, own props ', {k: round(v, 5) for k, v in own.items()},
           f'proposal points shared {agree:.4f}; proposals {p32[1].numel() - 1} vs {p16[1].numel() - 1}')
     for k, want in fp32.items():
         if k.startswith('num_'):
             assert same[k] == want
         else:
-            assert abs(same[k] - want) <= 0.02 * abs(want) + 5e-3, (k, same[k], want)
-    assert agree >= 0.9
+            assert abs(same[k] - want) <= rel * abs(want) + abs_tol, (k, same[k], want)
+    assert agree >= min_agree
 
 
 def test_bench_ddp_leg_runs_on_rccl():
