@@ -1017,9 +1017,20 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
       int32_t *cur = par ? stage1 : stage0, *nxt = par ? stage0 : stage1;
       u64 *curr = par ? srec1 : srec0, *nxtr = par ? srec0 : srec1;      // FAST: node records of the entries
       // ---- this workgroup's region of the current frontier goes to the output queue
-      for (int i = threadIdx.x; i < my_len; i += kEmitThreads) {
-        SG_ST(&Q[2 * (tail + my_pos + i)], c);
-        SG_ST(&Q[2 * (tail + my_pos + i) + 1], SG_LD(&cur[offs[b] + i]));
+      // (the first kQueueRegs x 512 entries travel through registers: their loads are issued here, next to the
+      //  staged-record loads of the claim below, and stored behind the claim sweep -- one fabric round trip
+      //  less per level than load -> store -> load, profiles/r06_bfs_big_phases.txt)
+      constexpr int kQueueRegs = 4;
+      const int q_base = tail + my_pos;
+      int qv[kQueueRegs];
+#pragma unroll
+      for (int k = 0; k < kQueueRegs; ++k) {
+        const int i = threadIdx.x + k * kEmitThreads;
+        qv[k] = i < my_len ? SG_LD(&cur[offs[b] + i]) : 0;
+      }
+      for (int i = threadIdx.x + kQueueRegs * kEmitThreads; i < my_len; i += kEmitThreads) {
+        SG_ST(&Q[2 * (q_base + i)], c);
+        SG_ST(&Q[2 * (q_base + i) + 1], SG_LD(&cur[offs[b] + i]));
       }
       tail += L;
       if (L == 0) {                                                // cluster complete (uniform)
@@ -1112,6 +1123,14 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
         }
       }
       if (b == 0 && threadIdx.x == 0) SG_ST(&pool[par ^ 1], 0);   // next level's pool (idle since two levels)
+#pragma unroll
+      for (int k = 0; k < kQueueRegs; ++k) {
+        const int i = threadIdx.x + k * kEmitThreads;
+        if (i < my_len) {
+          SG_ST(&Q[2 * (q_base + i)], c);
+          SG_ST(&Q[2 * (q_base + i) + 1], qv[k]);
+        }
+      }
       stamp(2);
       if (flag_barrier) {
         if (!big_flags_barrier(reinterpret_cast<unsigned *>(sync + kBigFlagsAt), tag, fail, &lds_flag)) return;

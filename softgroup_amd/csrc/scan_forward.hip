@@ -187,6 +187,17 @@ __global__ void __launch_bounds__(256) pack_segments_kernel(PackList p, char *__
   }
 }
 
+// ---- device -> pinned host copy of the dense results as a SMALL kernel (SG_SCAN_D2H_WGS workgroups; 0 = hipMemcpyAsync).
+// The runtime's copy of 12 MB is a shader blit with one workgroup on every CU (__amd_rocclr_copyBuffer, 219 us =
+// the PCIe rate); whatever runs next to it is stretched to its end (bfs_seed_kernel 5 -> 130 us, select_scan_kernel
+// 20 -> 229 us in round 5's traces): its stalled system-memory stores sit in every CU's memory queue.  A few workgroups
+// move the same bytes at the same PCIe rate and leave the other CUs' queues alone.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) d2h_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull)
+    __builtin_nontemporal_store(src[i], dst + i);
+}
+
 // ---- per (device, caller stream): the side stream of the dense results' copy and its two events
 struct ScanStream {
   hipStream_t copy = nullptr;
@@ -265,11 +276,20 @@ static void start_dense_copy(void *ctx) {
   if (d->issued || d->bytes == 0) return;
   d->issued = true;
   // the copy waits for the point where the caller's stream is NOW (the packed block is long complete)
+  static const int d2h_wgs = getenv("SG_SCAN_D2H_WGS") ? atoi(getenv("SG_SCAN_D2H_WGS")) : 0;
   if (hipEventRecord(d->ss->packed, d->main) != hipSuccess ||
-      hipStreamWaitEvent(d->ss->copy, d->ss->packed, 0) != hipSuccess ||
-      hipMemcpyAsync(d->host_block, d->dev_block, d->bytes, hipMemcpyDeviceToHost, d->ss->copy) != hipSuccess ||
-      hipEventRecord(d->ss->copied, d->ss->copy) != hipSuccess)
+      hipStreamWaitEvent(d->ss->copy, d->ss->packed, 0) != hipSuccess) {
     d->failed = true;
+    return;
+  }
+  if (d2h_wgs > 0 && d->bytes % 16 == 0) {
+    d2h_copy_kernel<<<d2h_wgs, 256, 0, d->ss->copy>>>(static_cast<const u32x4 *>(d->dev_block),
+                                                      static_cast<u32x4 *>(d->host_block), d->bytes / 16);
+    if (hipGetLastError() != hipSuccess) d->failed = true;
+  } else if (hipMemcpyAsync(d->host_block, d->dev_block, d->bytes, hipMemcpyDeviceToHost, d->ss->copy) != hipSuccess) {
+    d->failed = true;
+  }
+  if (hipEventRecord(d->ss->copied, d->ss->copy) != hipSuccess) d->failed = true;
 }
 
 static Mlp2 as_mlp(const sg_mlp2 &m) { return Mlp2{m.w1, m.b1, m.bn_scale, m.bn_shift, m.w2, m.b2, m.out}; }

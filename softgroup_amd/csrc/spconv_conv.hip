@@ -142,6 +142,7 @@ struct ConvArgs {
   int k_per_split;
   int num_units;
   unsigned magic_upt, magic_cu, magic_nsl;   // reciprocals of units_per_tile, col_units, n_slices
+  int dyn_rounds;              // with `queue`: static rounds before the hand-out starts (1 or 2)
   unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per
                                // XCD, 128 B apart), or null = static hand-out
   unsigned long long *trace;   // developer tracing only (SG_CONV_TRACE): [units][4 waves][8] stamps
@@ -736,8 +737,12 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   //      end times spread 109-146 k ticks on the 64->64 x 77 k-row layer); now whoever is ahead
   //      takes the remaining (lightest) units.  Results do not depend on who computes a unit.
   const int xcd = blockIdx.x & 7;
-  const int dyn0 = 2 * G;                      // first handed-out unit (G is a multiple of 8 when > 8)
+  // p.dyn_rounds = rounds handed out statically before the tickets start: 2 (the snake's first two rounds) or 1
+  // (only a workgroup's FIRST unit is static, the first ticket is drawn in the prologue: list scheduling over the
+  // heaviest-first list; measured no faster, see launch_persistent_split)
+  const int dyn0 = (p.dyn_rounds == 1 ? 1 : 2) * G;     // first handed-out unit (G is a multiple of 8 when > 8)
   const bool draws = p.queue != nullptr && dyn0 < num_units;     // anything to hand out at all?
+  const bool draw_first = draws && p.dyn_rounds == 1;
   auto barrier = [] {                          // LDS-only rendezvous: must not drain the ticket atomic
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -749,6 +754,8 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   unsigned ticket = 0;                         // wave 0, lane 0: the last ticket drawn
   bool drawing = true;                         // wave 0: no out-of-range ticket seen yet
   if (wave == 0) {
+    if (lane == 0 && draw_first)
+      ticket = __hip_atomic_fetch_add(p.queue + xcd * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     dma_meta(du.tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -761,7 +768,7 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
     // wave 0: which unit comes after this one, and its metadata on the way into the other buffer
     int un_w0 = -1;
     if (wave == 0) {
-      if (round == 0 || !draws) {      // (no queue: the static snake all the way, A/B knob)
+      if ((round == 0 && !draw_first) || !draws) {      // (no queue: the static snake all the way, A/B knob)
         // (a reversed round mirrors the GROUP of 8 only: unit u stays on XCD u % 8 = blockIdx.x % 8,
         // which is what the tile plan's per-XCD ranges rely on; G is a multiple of 8 when > 8)
         const int r = round + 1;
@@ -1139,7 +1146,7 @@ __global__ void __launch_bounds__(64 * kChainWV, 1) conv_chain_kernel(ChainArgs 
       p.col_units = s.col_units; p.blocks_per_unit = 1; p.ksplit = s.ksplit; p.k_per_split = s.k_per_split;
       p.num_units = s.num_units;
       p.magic_upt = s.magic_upt; p.magic_cu = s.magic_cu; p.magic_nsl = s.magic_nsl;
-      p.queue = nullptr; p.trace = nullptr; p.done = s.done; p.out_final = s.out_final;
+      p.queue = nullptr; p.dyn_rounds = 2; p.trace = nullptr; p.done = s.done; p.out_final = s.out_final;
       conv_layer_body<32, 2, 0, 1, SPLIT, kChainWV, 1, 1>(p, s.in_bytes, s.w_bytes);
     } else {
       chain_elementwise(s);
@@ -1710,7 +1717,12 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
     if (rc != SG_OK) return rc;
   }
   static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
+  // (SG_CONV_DYN_ROUNDS=1 with SG_CONV_STATIC=0: tickets from a workgroup's second unit on.  Measured slower
+  //  than the static snake on every big layer -- 64->64 52.7 against 51.0 us, 32->32 27.8 against 24.8,
+  //  profiles/r06_conv_dyn_ab.txt: the spread of workgroup end times is contention inside a CU, not assignment)
+  static const int dyn_rounds_env = getenv("SG_CONV_DYN_ROUNDS") ? atoi(getenv("SG_CONV_DYN_ROUNDS")) : 2;
   a.queue = dyn_env ? take_tickets(stream) : nullptr;
+  a.dyn_rounds = dyn_rounds_env == 1 ? 1 : 2;
   // grid: the resident workgroups, a multiple of 8 (unit u runs on XCD u % 8 in every round).  A layer
   // with fewer units than that gets one workgroup per unit, rounded UP to the next multiple of 8 --
   // the surplus workgroups leave at once.  (Rounded down, as until round 5, 98 units ran on 96
@@ -1936,6 +1948,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.col_units = col_units; a.blocks_per_unit = bpu; a.ksplit = ksplit; a.k_per_split = k_per_split;
   a.trace = nullptr;
   a.queue = nullptr;
+  a.dyn_rounds = 2;
   // offset-split layers of the persistent kernel: partial sums combined inside the launch by the last
   // workgroup of each (tile, column unit) instead of by conv_reduce_kernel (the default; SG_CONV_COMBINE=0
   // / sg_spconv_set_combine(0): the separate reduce kernel, same numbers)
@@ -1983,6 +1996,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     a.magic_nsl = magic(static_cast<unsigned>(Cin / kSliceCh));
     static const bool dyn_env = getenv("SG_CONV_STATIC") && atoi(getenv("SG_CONV_STATIC")) == 0;   // hand-out A/B
     a.queue = dyn_env ? take_tickets(stream) : nullptr;          // (null: static snake, the default)
+    a.dyn_rounds = 2;
     long long g = static_cast<long long>(num_cu) * occ;
     if (g >= 8) g -= g % 8;
     if (units < g) g = units >= 8 ? (units + 7) / 8 * 8 : units;      // (see launch_persistent_split)
