@@ -1094,7 +1094,7 @@ def main():
         # which committed counter file the figure comes from and which FETCH_SIZE factor was applied.
         traffic, traffic_source = None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        for fn in ('r05_conv_pmc.json', 'r04_conv_pmc.json', 'r03_conv_pmc.json', 'r02_conv_pmc.json', 'r01_conv_pmc.json'):
+        for fn in ('r06_conv_pmc.json', 'r05_conv_pmc.json', 'r04_conv_pmc.json', 'r03_conv_pmc.json', 'r02_conv_pmc.json', 'r01_conv_pmc.json'):
             try:
                 rec = json.load(open(os.path.join(here, 'profiles', fn)))
                 pmc = rec['counters']

@@ -63,9 +63,9 @@ inline bool big_fast_on() {
 // Off by default: measured SLOWER than the workgroup-wide FAST levels (bfs_emit_kernel 520 us against
 // ~360 us on the bench scene, one scan 5.01 against 4.78 ms; profiles/r06_bfs_thin_ab.txt) -- one wave
 // walking the frontier's nodes with readlane loops costs more than the seven barriers it saves.
-inline bool thin_levels_on() {
+inline int thin_levels_on() {
   const char *e = getenv("SG_BFS_THIN");
-  return e && atoi(e) != 0;
+  return e ? atoi(e) : 0;
 }
 inline size_t big_stage_entries(int n) {
   return n > kBigClusterMin && big_fast_on() ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
@@ -410,7 +410,9 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
     int32_t *owner_g, int32_t *cluster_idxs, int32_t *stats, int skip_above, int only_above,
     const int32_t *gate /* null, or a word that must be non-zero for the launch to do anything */,
-    bool thin_on /* thin levels on one wave (SG_BFS_THIN=0: the workgroup-wide FAST path only) */) {
+    int thin_mode /* 0: FAST levels only (default); 1: runs of thin levels on one wave; 2: the same with the
+                     next level's record lines prefetched (SG_BFS_THIN) */) {
+  const bool thin_on = thin_mode != 0, thin_prefetch = thin_mode == 2;
   if (gate != nullptr && SG_LD(gate) == 0) return;
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int own_lds[kOwnCap];
@@ -521,7 +523,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_kernel(
               if (e < E && slot != 0xffff) {
                 const int cur_owner = own_lds[slot];
                 if (cur_owner > e) atomicMin(&own_lds[slot], e);
-                if (cur_owner >= 0) {                       // candidate of the next frontier: its records' lines
+                if (thin_prefetch && cur_owner >= 0) {      // candidate of the next frontier: its records' lines
                   const int tl = r[j].x >> 16;
                   const char *first = reinterpret_cast<const char *>(erec + r[j].y);
                   const char *last = reinterpret_cast<const char *>(erec + r[j].y + max(tl, 1) - 1);

@@ -159,6 +159,14 @@ int conv_chain_concat(const float *a, const float *b, int64_t rows, int ca, int 
                       const float *shift, float *out, float *out_act);
 int conv_chain_bn_relu(const float *x, const float *scale, const float *shift, int64_t rows, int c, float *out);
 int conv_chain_check_abort(const char *who);   // SG_ERR_LAUNCH once after a barrier of an earlier chain timed out
+// octree ball query whose count pass parks short lists for the fill pass (octree.hip; sg_scan_grouping_pp)
+size_t octree_stash_bytes(int n);
+int octree_ballquery_count_stash(const float *points, const float *boxes, const int32_t *pt_inds,
+                                 const int32_t *pt_start_len, int n, float radius, int32_t *start_len, int32_t *stash,
+                                 hipStream_t stream);
+int octree_ballquery_fill_stash(const float *points, const float *boxes, const int32_t *pt_inds,
+                                const int32_t *pt_start_len, int n, float radius, const int32_t *start_len,
+                                const int32_t *stash, int32_t *idx, hipStream_t stream);
 // per-(device, stream) runtime state of the conv launches / the executors' index builds (sg_stream_release)
 void conv_release_stream(int dev, hipStream_t stream);
 void unet_release_stream(int dev, hipStream_t stream);

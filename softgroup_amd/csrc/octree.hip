@@ -32,14 +32,19 @@ __device__ __forceinline__ bool box_hit(const float *__restrict__ b, float cx, f
   return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy))) <= __fmul_rn(r, r);
 }
 
-template <bool FILL>
+// STASH (sg_scan_grouping_pp: the count pass also parks the first kOctStash accepted ids of every query in
+// `stash[i][.]`, in list order; a list that short -- the usual case at SoftGroup++'s radii on level voxels -- is
+// then copied by octree_unstash_kernel instead of being walked a second time: 2 x 137 us -> 137 + ~15 us per class)
+constexpr int kOctStash = 64;
+template <bool FILL, bool STASH = false>
 __global__ void __launch_bounds__(256) octree_query_kernel(const float *__restrict__ points,
                                                           const float *__restrict__ boxes,
                                                           const int32_t *__restrict__ pt_inds,
                                                           const int32_t *__restrict__ pt_start_len,
                                                           int n, float radius,
                                                           int32_t *__restrict__ start_len,
-                                                          int32_t *__restrict__ idx_out) {
+                                                          int32_t *__restrict__ idx_out,
+                                                          int32_t *__restrict__ stash = nullptr) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float r2 = __fmul_rn(radius, radius);
   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
@@ -48,6 +53,7 @@ __global__ void __launch_bounds__(256) octree_query_kernel(const float *__restri
     const uint64_t a2 =
         __ballot(((a1 >> (lane >> 3)) & 1) && box_hit(boxes + (9 + lane) * 6, cx, cy, cz, radius));
     const int64_t out_start = FILL ? start_len[2 * i] : 0;
+    if (FILL && STASH && start_len[2 * i + 1] <= kOctStash) continue;      // (copied from the stash: wave-uniform)
     int count = 0;
     for (int r = 0; r < 8; ++r) {
       uint64_t leaves = __ballot(((a2 >> (r * 8 + (lane >> 3))) & 1) &&
@@ -72,6 +78,10 @@ __global__ void __launch_bounds__(256) octree_query_kernel(const float *__restri
             const int pos = count + mask_prefix(bal);
             if (ok && pos < kOctCap) idx_out[out_start + pos] = p;
           }
+          if (STASH && !FILL) {
+            const int pos = count + mask_prefix(bal);
+            if (ok && pos < kOctStash) stash[static_cast<int64_t>(i) * kOctStash + pos] = p;
+          }
           count += __popcll(bal);
         }
       }
@@ -80,6 +90,16 @@ __global__ void __launch_bounds__(256) octree_query_kernel(const float *__restri
   }
 }
 
+
+__global__ void __launch_bounds__(256) octree_unstash_kernel(const int32_t *__restrict__ stash,
+                                                            const int32_t *__restrict__ start_len, int n,
+                                                            int32_t *__restrict__ idx_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const int len = start_len[2 * i + 1];
+    if (len <= kOctStash && lane < len) idx_out[start_len[2 * i] + lane] = stash[static_cast<int64_t>(i) * kOctStash + lane];
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Octree build on the device (reference: host C++, octree_ball_query.cpp:8-147, reached through
@@ -244,6 +264,26 @@ __global__ void __launch_bounds__(256) pim_emit_kernel(const uint32_t *__restric
   }
   if (n == 0 && blockIdx.x == 0)
     for (int p = threadIdx.x; p <= n_prop; p += 256) out_off[p] = 0;
+}
+
+// sg_octree_ballquery_count / _fill with the stash (internal: sg_scan_grouping_pp); stash = int32 [n * 64]
+size_t octree_stash_bytes(int n) { return align_up(static_cast<size_t>(n > 0 ? n : 1) * kOctStash * sizeof(int32_t)); }
+int octree_ballquery_count_stash(const float *points, const float *boxes, const int32_t *pt_inds,
+                                 const int32_t *pt_start_len, int n, float radius, int32_t *start_len, int32_t *stash,
+                                 hipStream_t stream) {
+  if (n == 0) return SG_OK;
+  octree_query_kernel<false, true><<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(points, boxes, pt_inds, pt_start_len, n,
+                                                                                 radius, start_len, nullptr, stash);
+  return check_launch("octree_ballquery_count_stash");
+}
+int octree_ballquery_fill_stash(const float *points, const float *boxes, const int32_t *pt_inds,
+                                const int32_t *pt_start_len, int n, float radius, const int32_t *start_len,
+                                const int32_t *stash, int32_t *idx, hipStream_t stream) {
+  if (n == 0) return SG_OK;
+  octree_unstash_kernel<<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(stash, start_len, n, idx);
+  octree_query_kernel<true, true><<<grid_for(n, 4, 256 * 16), 256, 0, stream>>>(
+      points, boxes, pt_inds, pt_start_len, n, radius, const_cast<int32_t *>(start_len), idx, nullptr);
+  return check_launch("octree_ballquery_fill_stash");
 }
 
 }  // namespace sg

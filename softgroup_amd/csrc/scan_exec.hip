@@ -695,13 +695,15 @@ int sg_scan_grouping_pp(const sg_grouping_pp_cfg *pcfg, const float *scores, con
       SG_TAKE(pt_sl, int32_t, 512 * 2);
       const size_t ob = sg_octree_build_workspace_bytes(n_q);
       SG_TAKE(o_ws, char, ob);
+      SG_TAKE(stash, int32_t, octree_stash_bytes(n_q) / sizeof(int32_t));
       SG_TRY(sg_octree_build(q, n_q, boxes, pt_inds, pt_sl, o_ws, ob, stream_));
-      SG_TRY(sg_octree_ballquery_count(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, stream_));
+      // (the count pass parks lists of <= 64 neighbours; the fill pass copies those and walks only the longer ones)
+      SG_TRY(octree_ballquery_count_stash(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, stash, stream));
       SG_TRY(sg_exclusive_scan_startlen(start_len, n_q, meta + 56, sc_ws, sc_bytes, stream_));
       SG_TRY(read_back(host, meta + 56, 1, stream, kWhat));
       n_active = host[0];
       SG_TAKE(idx_, int32_t, n_active);
-      SG_TRY(sg_octree_ballquery_fill(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, idx_, stream_));
+      SG_TRY(octree_ballquery_fill_stash(q, boxes, pt_inds, pt_sl, n_q, radius, start_len, stash, idx_, stream));
       bq_idx = idx_;
       flags = SG_LISTS_RADIUS;
     } else {

@@ -23,6 +23,7 @@ import torch
 
 from .. import ops
 
+_STAGING_POOL, _STAGING_POOL_LOCK = [], threading.Lock()    # staging sets of finished prefetch_device loaders
 _local = threading.local()   # per thread: {(key, dtype) -> [pinned tensor (grow-only), event of the
 #                              last copy out of it]} -- loader threads never share a staging buffer
 
@@ -279,8 +280,13 @@ def prefetch_device(batches, collate=None, depth=1, device='cuda'):
     dev = torch.device(device)
     q = queue.Queue(maxsize=max(1, int(depth)))
     stop = threading.Event()
+    # the loader thread's pinned staging buffers outlive it (page-locking 11 MB costs tens of ms: a new set per
+    # generator made the first measurement of this path 32 ms per scan): taken from / returned to a module pool
+    with _STAGING_POOL_LOCK:
+        staging = _STAGING_POOL.pop() if _STAGING_POOL else {}
 
     def loader():
+        _local.staging = staging
         try:
             with torch.cuda.device(dev):
                 side = torch.cuda.Stream()
@@ -319,3 +325,8 @@ def prefetch_device(batches, collate=None, depth=1, device='cuda'):
                 q.get_nowait()
             except queue.Empty:
                 t.join(0.01)
+        for slot in staging.values():      # (copies out of the buffers have finished before they are reused)
+            if slot[1] is not None:
+                slot[1].synchronize()
+        with _STAGING_POOL_LOCK:
+            _STAGING_POOL.append(staging)

@@ -204,7 +204,7 @@ def test_bfs_cluster_thin_levels_on_one_wave_equal_the_workgroup_path(monkeypatc
     mean = torch.tensor([-1.0])
     rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 20.0, 0)
     assert len(rco) - 1 >= 15
-    for thin in ('1', '0'):
+    for thin in ("2", "1", "0"):
         monkeypatch.setenv('SG_BFS_THIN', thin)
         ci, co = ops.bfs_cluster(mean, idx, sl, 20.0, 0)
         assert np.array_equal(co.cpu().numpy(), rco), thin
