@@ -484,8 +484,11 @@ typedef struct sg_unet_desc {
                                         on the persistent MFMA kernel instead of the general one */
   int arithmetic;                    /* 0 = the process-wide conv arithmetic (fp32 products); 2 = bf16
                                         operands for this call's convolutions (sg_spconv_set_arithmetic's
-                                        mode 2, scoped to the call and the calling thread): what a
-                                        frozen backbone runs in under bf16 autocast */
+                                        mode 2, scoped to the call and the calling thread), activations
+                                        fp32 in memory; 3 = bf16 operands AND bf16 activations between the
+                                        layers (needs input_w and planes % 32 == 0 on every level, else
+                                        it runs as 2): what spconv does with a frozen backbone under the
+                                        reference's autocast (tools/train.py:47).  `feats` and `out` stay fp32 */
 } sg_unet_desc;
 /* upper bound of the arena sg_unet_forward needs for num_rows input voxels */
 size_t sg_unet_arena_bytes(const sg_unet_desc *desc, int num_rows);

@@ -159,6 +159,12 @@ int conv_chain_concat(const float *a, const float *b, int64_t rows, int ca, int 
                       const float *shift, float *out, float *out_act);
 int conv_chain_bn_relu(const float *x, const float *scale, const float *shift, int64_t rows, int c, float *out);
 int conv_chain_check_abort(const char *who);   // SG_ERR_LAUNCH once after a barrier of an earlier chain timed out
+// sg_spconv_gather_conv_f32 with bf16 rows on either side (spconv_conv.hip; the executor's arithmetic 3)
+int conv_gather_rows(const void *in, int num_in_rows, const int32_t *nbr, int M_out, int K, int Cin, int Cout,
+                     const float *w_k8, const float *post_scale, const float *post_shift, const void *residual,
+                     const float *act_scale, const float *act_shift, void *out_act, const int32_t *order,
+                     const uint32_t *tile_mask, const int32_t *nbr_tiles, void *out, void *ws, size_t ws_bytes,
+                     sg_stream_t stream, int in16, int out16, int res16);
 // octree ball query whose count pass parks short lists for the fill pass (octree.hip; sg_scan_grouping_pp)
 size_t octree_stash_bytes(int n);
 int octree_ballquery_count_stash(const float *points, const float *boxes, const int32_t *pt_inds,

@@ -142,6 +142,7 @@ struct ConvArgs {
   int k_per_split;
   int num_units;
   unsigned magic_upt, magic_cu, magic_nsl;   // reciprocals of units_per_tile, col_units, n_slices
+  int out16, res16;            // SPLIT == 2 kernels: outputs / the residual are bf16 rows (else fp32)
   int dyn_rounds;              // with `queue`: static rounds before the hand-out starts (1 or 2)
   unsigned *queue;             // persistent kernel: 8 zeroed ticket counters of this launch (one per
                                // XCD, 128 B apart), or null = static hand-out
@@ -347,8 +348,15 @@ constexpr int kMetaInts = kMaskAt + 4;
 //     access goes past the CU's L1: sc1 loads of the gathered rows and the residual, sc1 (write-through)
 //     stores of the outputs.  The grid barrier between two steps then needs no fence at all
 //     (cdna_hip_programming.md, publish/consume recipe R1).  Same instructions otherwise: same numbers.
-template <int CK, int DEPTH, int TRACE, int NBW, int SPLIT, int WV, int AT, int CHAIN>
+//   * R16 (with SPLIT == 2 and AT): the INPUT rows are bf16 in memory (arithmetic 3: bf16 activations between
+//     the layers of a frozen backbone under autocast, what spconv does under tools/train.py:47).  A 32-channel
+//     item of a row is 64 bytes: 4 lanes per row, 2 coalesced loads for the tile's 32 rows, a 2 KB transpose
+//     block, and the 16-byte chunks that come out of it ARE MFMA operands -- no conversion at all.  p.out16 /
+//     p.res16 (run-time, SPLIT == 2 only) say whether outputs / the residual are bf16 rows; sums stay fp32,
+//     results are rounded to nearest even when stored.
+template <int CK, int DEPTH, int TRACE, int NBW, int SPLIT, int WV, int AT, int CHAIN, int R16 = 0>
 __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_bytes, unsigned w_bytes) {
+  static_assert(!R16 || (SPLIT == 2 && AT), "bf16 rows: bf16-operand arithmetic, line-wise gather");
   constexpr int AUX = CHAIN ? 16 : 0;      // buffer-instruction aux bits of the activation accesses (16 = sc1)
   static_assert(!SPLIT || CK == 16 || AT, "split-precision path: 16-channel slices");
   static_assert(!AT || (SPLIT && CK == 32), "line-wise gather: split path, 32-channel items");
@@ -371,7 +379,8 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   const int G = gridDim.x;
   const int units_per_tile = p.col_units * p.ksplit;
   const int num_units = p.num_units;
-  const int n_slices = p.Cin / CK;
+  // (R16: an item is a whole 128-byte line of a bf16 row = 64 channels; a last item of 32 channels when Cin % 64 == 32)
+  const int n_slices = R16 ? (p.Cin + 63) / 64 : p.Cin / CK;
   const int c8 = p.Cin / 8;
   const int tileK = kTileRows * p.K;       // words of a tile's gather block (row-major, stride K)
   const int nbr_base = arow * p.K;
@@ -388,26 +397,47 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   // reducer; correct wherever the units of a tile run.
   const bool combine = p.done != nullptr && !final_out;
   const int num_tiles = (p.M_out + kTileRows - 1) / kTileRows;
-  const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;
+  const unsigned out_bytes = static_cast<unsigned>(p.M_out) * p.Cout * 4u;      // one fp32 tile set (partial sums)
+  const bool out16 = SPLIT == 2 && p.out16 != 0, res16 = SPLIT == 2 && p.res16 != 0;
+  const unsigned fin_bytes = out16 ? out_bytes >> 1 : out_bytes;      // the layer's real outputs
+  const unsigned res_bytes = res16 ? out_bytes >> 1 : out_bytes;
 
   const __amdgpu_buffer_rsrc_t rs_in =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(add_res ? p.residual : p.in), 0, add_res ? out_bytes : 0u, 0x00020000);
+      const_cast<float *>(add_res ? p.residual : p.in), 0, add_res ? res_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
+      p.out, 0, final_out ? fin_bytes : out_bytes * static_cast<unsigned>(p.ksplit), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
-      act ? p.out_act : p.out, 0, act ? out_bytes : 0u, 0x00020000);
+      act ? p.out_act : p.out, 0, act ? fin_bytes : 0u, 0x00020000);
   // the reducer's operands (zero-sized unless this launch combines)
   const bool c_res = combine && p.residual != nullptr, c_act = combine && p.out_act != nullptr;
   const __amdgpu_buffer_rsrc_t rs_cres = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(c_res ? p.residual : p.in), 0, c_res ? out_bytes : 0u, 0x00020000);
+      const_cast<float *>(c_res ? p.residual : p.in), 0, c_res ? res_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cout = __builtin_amdgcn_make_buffer_rsrc(
-      combine ? p.out_final : p.out, 0, combine ? out_bytes : 0u, 0x00020000);
+      combine ? p.out_final : p.out, 0, combine ? fin_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_cact = __builtin_amdgcn_make_buffer_rsrc(
-      c_act ? p.out_act : p.out, 0, c_act ? out_bytes : 0u, 0x00020000);
+      c_act ? p.out_act : p.out, 0, c_act ? fin_bytes : 0u, 0x00020000);
+  // 16-bit rows: element offsets are the fp32 byte offsets halved (the out-of-range sentinel stays out of range),
+  // a 32-column block is 64 bytes
+  auto ld_row = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, int n, bool h16) -> float {
+    if constexpr (SPLIT == 2) {
+      if (h16)
+        return bf16_f32(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rs, off >> 1, n * 64, AUX)));
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, n * 128, AUX));
+  };
+  auto st_row = [&](float v, const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned base, int n, bool h16) {
+    if constexpr (SPLIT == 2) {
+      if (h16) {
+        __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>(bf16_rne(v)), rs, off >> 1, base + n * 64, AUX);
+        return;
+      }
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, base + n * 128, AUX);
+  };
 
   // x / d for the few small wave-uniform divisors of the unit arithmetic: one s_mul_hi with a
   // host-made reciprocal (exact for x * d < 2^32; magic 0 means d == 1)
@@ -458,8 +488,8 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   // SPLIT == 2 ("bf16 operands", the autocast arithmetic): only the h plane = bf16(w) is read and the
   // gathered rows are rounded to bf16 once -- ONE MFMA per product instead of six, fp32 sums.
   constexpr int NPL = SPLIT == 2 ? 1 : 3;
-  constexpr int NB_ = AT ? 2 * NPL : SPLIT ? NPL : NQ;   // AT: two 16-channel sub-slices x the planes
-  struct Slice { f4 a[NQ]; f4 b[NBW][NB_]; };
+  constexpr int NB_ = R16 ? 4 : AT ? 2 * NPL : SPLIT ? NPL : NQ;   // AT: two 16-channel sub-slices x the planes; R16: four
+  struct Slice { f4 a[NQ]; f4 b[NBW][NB_]; int nsl; };      // nsl (R16): 16-channel sub-slices of the item (4, or 2 at the end of a row)
   const int plane_bytes = p.K * c8 * p.Cout * 16;          // one bf16 plane of the packed weights
   const int planes_at = 2 * plane_bytes;                   // they follow the fp32 copy
   // per-unit context (wave-uniform scalars + the lane's column)
@@ -483,6 +513,28 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   f4 *tr_lds = reinterpret_cast<f4 *>(ctl + 4) + wave * 256;       // AT: this wave's 32 x 128 B block
   const unsigned row_pitch = static_cast<unsigned>(p.Cin) * 4u, lane_chunk = static_cast<unsigned>(lane & 7) * 16u;
   auto load = [&](const Ctx &c, int k, int s, Slice &S) {
+    if constexpr (R16) {
+      // load q: row 8q + lane/8 of the tile, 16-byte chunk lane%8 of the item's 128-byte line (64 bf16 channels;
+      // of a 32-channel last item the upper four chunks belong to the next row and are not used)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned src = static_cast<unsigned>(c.meta[(8 * q + (lane >> 3)) * p.K + k]);
+        const unsigned v_a = __umul24(src, row_pitch >> 1) + lane_chunk;
+        S.a[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_a, s * 128, AUX));
+      }
+      // weights: sub-slice sl = channel blocks 8s + 2sl + h of the bf16 plane (a 32-channel last item re-reads its
+      // first two sub-slices for the unused ones: every load unconditional and in range)
+      const int s_w = planes_at + (k * c8 + s * 8) * p.Cout * 16;
+      const int nsl = s * 64 + 64 <= p.Cin ? 4 : 2;
+      S.nsl = nsl;
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+          S.b[n][sl] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rs_w, c.v_w + n * 512, s_w + (sl < nsl ? sl : sl - 2) * (2 * p.Cout * 16), 0));
+      return;
+    }
     if constexpr (AT) {
       // load q: row 8q + lane/8 of the tile, 16-byte chunk lane%8 of the item's 128-byte line
 #pragma unroll
@@ -596,7 +648,7 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
       c.o_off[rr] = off;   // kept for the epilogue: the unit's LDS block is not read after its loop
 #pragma unroll
       for (int n = 0; n < NBW; ++n)
-        resv[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, off, n * 128, AUX));
+        resv[n][rr] = ld_row(rs_res, off, n, res16);
     }
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
@@ -618,6 +670,28 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   // ~0.75 us per item on the ~200 instructions of the item -- gathers, LDS transpose, conversions,
   // MFMAs, address arithmetic -- at one issue per 4-5 cycles, not on any single dependency chain.)
   auto compute = [&](Slice &S) {
+    if constexpr (R16) {
+      // rows as loaded -> LDS (the fp32 line-wise layout: row r at r * 128 B, chunk c at position c ^ ((r >> 1) & 7));
+      // lane (h, i) then reads chunk 2 sl + h of row i: its 8 bf16 channels of sub-slice sl, an MFMA operand as it is
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + (lane >> 3);
+        tr_lds[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = S.a[q];
+      }
+      f4 fr[4];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) fr[sl] = tr_lds[arow * 8 + ((sl * 2 + ahalf) ^ ((arow >> 1) & 7))];
+      const int nsl = __builtin_amdgcn_readfirstlane(S.nsl);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        if (sl >= 2 && nsl == 2) break;      // (uniform: the 32-channel last item of a row)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[sl]),
+                                                           __builtin_bit_cast(bf16x8, S.b[n][sl]), acc[n], 0, 0, 0);
+      }
+      return;
+    }
     if constexpr (AT) {
       // rows as loaded -> LDS (row r at r * 128 B, chunk c at position c ^ ((r >> 1) & 7)), then
       // lane (h, i) reads the two chunks of its 8 channels of row i for each sub-slice
@@ -891,17 +965,13 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
-      for (int n = 0; n < NBW; ++n)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n][rr]), rs_out, o_off[rr],
-                                              o_base + n * 128, AUX);
+      for (int n = 0; n < NBW; ++n) st_row(v[n][rr], rs_out, o_off[rr], o_base, n, out16 && final_out);
     }
     if (act) {          // uniform; stores only (a zero-sized buffer would drop them anyway)
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
-        for (int n = 0; n < NBW; ++n)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[n][rr]), rs_act, o_off[rr],
-                                                n * 128, AUX);
+        for (int n = 0; n < NBW; ++n) st_row(va[n][rr], rs_act, o_off[rr], 0u, n, out16);
     }
     if (combine) {      // uniform
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial stores are out
@@ -964,17 +1034,16 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
         for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
           for (int n = 0; n < NBW; ++n)
-            res[n][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cres, o_off[rr], n * 128, AUX));
+            res[n][rr] = ld_row(rs_cres, o_off[rr], n, res16);
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
           for (int n = 0; n < NBW; ++n) {
             float x = t[n][rr] + res[n][rr];
             if (p.post_scale) x = fmaxf(fmaf(x, ps[n], pb[n]), 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs_cout, o_off[rr], n * 128, AUX);
+            st_row(x, rs_cout, o_off[rr], 0u, n, out16);
             // (a zero-sized descriptor without a second output: the store is dropped)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(fmaf(x, as[n], ab[n]), 0.f)),
-                                                  rs_cact, o_off[rr], n * 128, AUX);
+            st_row(fmaxf(fmaf(x, as[n], ab[n]), 0.f), rs_cact, o_off[rr], 0u, n, out16);
           }
       }
     }
@@ -997,10 +1066,10 @@ __device__ __forceinline__ void conv_layer_body(const ConvArgs &p, unsigned in_b
   }
 }
 
-template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0, int WV = 4, int AT = 0>
+template <int CK, int DEPTH, int TRACE, int WPE, int NBW = 1, int SPLIT = 0, int WV = 4, int AT = 0, int R16 = 0>
 __global__ void __launch_bounds__(64 * WV, WPE) gather_conv_persistent_kernel(ConvArgs p, unsigned in_bytes,
                                                                              unsigned w_bytes) {
-  conv_layer_body<CK, DEPTH, TRACE, NBW, SPLIT, WV, AT, 0>(p, in_bytes, w_bytes);
+  conv_layer_body<CK, DEPTH, TRACE, NBW, SPLIT, WV, AT, 0, R16>(p, in_bytes, w_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1146,7 +1215,7 @@ __global__ void __launch_bounds__(64 * kChainWV, 1) conv_chain_kernel(ChainArgs 
       p.col_units = s.col_units; p.blocks_per_unit = 1; p.ksplit = s.ksplit; p.k_per_split = s.k_per_split;
       p.num_units = s.num_units;
       p.magic_upt = s.magic_upt; p.magic_cu = s.magic_cu; p.magic_nsl = s.magic_nsl;
-      p.queue = nullptr; p.dyn_rounds = 2; p.trace = nullptr; p.done = s.done; p.out_final = s.out_final;
+      p.queue = nullptr; p.dyn_rounds = 2; p.out16 = 0; p.res16 = 0; p.trace = nullptr; p.done = s.done; p.out_final = s.out_final;
       conv_layer_body<32, 2, 0, 1, SPLIT, kChainWV, 1, 1>(p, s.in_bytes, s.w_bytes);
     } else {
       chain_elementwise(s);
@@ -1590,9 +1659,10 @@ typedef void (*PersistentFn)(ConvArgs, unsigned, unsigned);
 struct SplitVariant {
   PersistentFn fn, fn_trace;
   PersistentFn fn_b16;      // the same decomposition with bf16 operands (one MFMA per product)
+  PersistentFn fn_r16;      // ... and bf16 input rows (line-wise variants only, else null)
   int nbw, wv, ck, at;
   size_t lds;
-  int occ, occ_b16;      // resident workgroups per CU
+  int occ, occ_b16, occ_r16;      // resident workgroups per CU
 };
 #ifndef SG_B16_DEPTH
 #define SG_B16_DEPTH 2
@@ -1600,10 +1670,16 @@ struct SplitVariant {
 #ifndef SG_B16_WPE_PLUS
 #define SG_B16_WPE_PLUS 0
 #endif
+template <int CK, int WPE, int NBW, int WV, int AT>
+constexpr PersistentFn r16_variant() {
+  if constexpr (AT) return gather_conv_persistent_kernel<CK, SG_B16_DEPTH, 0, WPE + SG_B16_WPE_PLUS, NBW, 2, WV, 1, 1>;
+  else return nullptr;
+}
 #define SG_SPLIT_VARIANT(CK, DEPTH, WPE, NBW, WV, AT)                                            \
   {gather_conv_persistent_kernel<CK, DEPTH, 0, WPE, NBW, 1, WV, AT>,                              \
    gather_conv_persistent_kernel<CK, DEPTH, 1, WPE, NBW, 1, WV, AT>,                              \
-   gather_conv_persistent_kernel<CK, SG_B16_DEPTH, 0, WPE + SG_B16_WPE_PLUS, NBW, 2, WV, AT>, NBW, WV, CK, AT, 0, 0, 0}
+   gather_conv_persistent_kernel<CK, SG_B16_DEPTH, 0, WPE + SG_B16_WPE_PLUS, NBW, 2, WV, AT>,     \
+   r16_variant<CK, WPE, NBW, WV, AT>(), NBW, WV, CK, AT, 0, 0, 0, 0}
 constexpr int kSplitVariants = 9;
 static SplitVariant g_split_variants[kSplitVariants] = {
     SG_SPLIT_VARIANT(32, 2, 2, 2, 2, 1),  SG_SPLIT_VARIANT(32, 2, 3, 1, 2, 1),
@@ -1616,7 +1692,7 @@ static SplitVariant g_split_variants[kSplitVariants] = {
 // waits for is its own chain of dependent MFMAs and conversions, not its loads.)
 
 static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes, long long w_bytes,
-                                   hipStream_t stream, bool b16) {
+                                   hipStream_t stream, bool b16, bool in16) {
   static int num_cu = 0;
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1633,6 +1709,9 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
       o = 0;
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn_b16, 64 * v.wv, v.lds);
       v.occ_b16 = o < 1 ? 1 : o;
+      o = 0;
+      if (v.fn_r16) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, v.fn_r16, 64 * v.wv, v.lds);
+      v.occ_r16 = o < 1 ? 1 : o;
     };
     for (SplitVariant &v : g_split_variants) prepare(v);
   });
@@ -1645,9 +1724,15 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   // and an absent neighbour (-1 -> 0xffffff * row pitch, wrapped to 32 bits) must land past the end
   // of the buffer: row pitches that are not multiples of 256 B (Cin = 96, 160, 224) wrap to just
   // below 2^31, which is inside an input of a few million rows -- those take the fragment-shaped gather
-  const unsigned absent_at = static_cast<unsigned>((0xFFFFFFull * (4ull * a.Cin)) & 0xFFFFFFFFull);
-  const int use_at = (at_env != 0 && a.Cin % 32 == 0 && in_bytes / (4LL * a.Cin) < (1LL << 24) - 1 &&
+  const unsigned long long row_bytes = (in16 ? 2ull : 4ull) * a.Cin;
+  const unsigned absent_at = static_cast<unsigned>((0xFFFFFFull * row_bytes) & 0xFFFFFFFFull);
+  const int use_at = ((at_env != 0 || in16) && a.Cin % 32 == 0 && in_bytes / static_cast<long long>(row_bytes) < (1LL << 24) - 1 &&
                       static_cast<long long>(absent_at) >= in_bytes) ? 1 : 0;
+  if (in16 && (!use_at || !b16)) {
+    set_error("sg_unet_forward(bf16 rows): a layer with %d input channels / %lld input bytes cannot take the line-wise bf16 gather",
+              a.Cin, in_bytes);
+    return SG_ERR_ARG;
+  }
   int pick = -1;
   // tiny layers arrive with their offsets split over several units (ksplit > 1, partial sums to the
   // workspace, conv_reduce_kernel afterwards): measured faster than 16 waves on very few units
@@ -1679,7 +1764,7 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
     if (v.nbw == 2 && (a.Cout % 64 != 0 || nbw_env < 2)) continue;
     if (wv_env && v.wv != wv_env) continue;
     const long long units = static_cast<long long>(num_tiles) * (NB / v.nbw);
-    if (wv_env || units >= static_cast<long long>((v.wv == 2 ? w2_rounds : min_rounds) * num_cu * (b16 ? v.occ_b16 : v.occ))) {
+    if (wv_env || units >= static_cast<long long>((v.wv == 2 ? w2_rounds : min_rounds) * num_cu * (in16 ? v.occ_r16 : b16 ? v.occ_b16 : v.occ))) {
       pick = i;
       break;
     }
@@ -1699,9 +1784,9 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   auto magic = [](unsigned d) { return d <= 1 ? 0u : static_cast<unsigned>((1ULL << 32) / d) + 1u; };
   a.magic_upt = magic(static_cast<unsigned>(a.col_units * a.ksplit));
   a.magic_cu = magic(static_cast<unsigned>(a.col_units));
-  a.magic_nsl = magic(static_cast<unsigned>(a.Cin / v.ck));
+  a.magic_nsl = magic(static_cast<unsigned>(in16 ? (a.Cin + 63) / 64 : a.Cin / v.ck));
   if (t_chain.mode == 2) {
-    if (chain_layer && (a.ksplit == 1 || a.done != nullptr) && stream == t_chain.stream) {
+    if (chain_layer && !in16 && !a.out16 && !a.res16 && (a.ksplit == 1 || a.done != nullptr) && stream == t_chain.stream) {
       ChainStep st = {};
       st.kind = 0;
       st.in = a.in; st.w = a.w; st.post_scale = a.post_scale; st.post_shift = a.post_shift; st.residual = a.residual;
@@ -1727,11 +1812,15 @@ static int launch_persistent_split(ConvArgs a, int num_tiles, long long in_bytes
   // with fewer units than that gets one workgroup per unit, rounded UP to the next multiple of 8 --
   // the surplus workgroups leave at once.  (Rounded down, as until round 5, 98 units ran on 96
   // workgroups and two of them took a second unit: the 18-row layers spent 21.5 k instead of 10.5 k
-  // ticks, the 141-row layers 24.5 k instead of 15 k -- profiles/r06_conv_tail.txt.)
-  long long g = static_cast<long long>(num_cu) * (b16 ? v.occ_b16 : v.occ);
+  // ticks, the 141-row layers 24.5 k instead of 15 k -- profiles/r06_conv_trace_base.txt.)
+  long long g = static_cast<long long>(num_cu) * (in16 ? v.occ_r16 : b16 ? v.occ_b16 : v.occ);
   if (g >= 8) g -= g % 8;
   if (units < g) g = units >= 8 ? (units + 7) / 8 * 8 : units;
   const unsigned ib = static_cast<unsigned>(in_bytes), wb = static_cast<unsigned>(w_bytes);
+  if (in16) {
+    v.fn_r16<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
+    return check_launch("sg_spconv_gather_conv(bf16 rows)");
+  }
   if (b16) {
     v.fn_b16<<<static_cast<int>(g), 64 * v.wv, v.lds, stream>>>(a, ib, wb);
     return check_launch("sg_spconv_gather_conv_f32(bf16 operands)");
@@ -1860,12 +1949,15 @@ size_t sg_spconv_conv_workspace_bytes(int M_out, int Cout) {
   return static_cast<size_t>(kMaxK) * M_out * Cout * sizeof(float) + 256;
 }
 
-int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
-                              int K, int Cin, int Cout, const float *w_k8, const float *post_scale,
-                              const float *post_shift, const float *residual, const float *act_scale,
-                              const float *act_shift, float *out_act, const int32_t *order,
-                              const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
-                              void *ws, size_t ws_bytes, sg_stream_t stream_) {
+// in16 / out16 / res16: `in` / `out` + `out_act` / `residual` are bf16 rows (the executor's arithmetic 3; the
+// pointers are typed float for the fp32 case only).  Needs the bf16-operand arithmetic and, for in16, the
+// line-wise gather (Cin % 32 == 0); an offset-split layer combines in the launch.
+static int gather_conv_impl(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
+                            int K, int Cin, int Cout, const float *w_k8, const float *post_scale,
+                            const float *post_shift, const float *residual, const float *act_scale,
+                            const float *act_shift, float *out_act, const int32_t *order,
+                            const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
+                            void *ws, size_t ws_bytes, sg_stream_t stream_, int in16, int out16, int res16) {
   SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kMaxK && Cin >= 1 && Cout >= 1,
              "sg_spconv_gather_conv_f32: bad arguments (M_out=%d K=%d Cin=%d Cout=%d)", M_out, K,
              Cin, Cout);
@@ -1901,7 +1993,7 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   }
   const int NB = (Cout + 31) / 32;
   const int num_tiles = (M_out + kTileRows - 1) / kTileRows;
-  const long long in_bytes_ll = static_cast<long long>(num_in_rows) * Cin * 4;
+  const long long in_bytes_ll = static_cast<long long>(num_in_rows) * Cin * (in16 ? 2 : 4);
   const long long w_bytes_ll = static_cast<long long>(sg_spconv_packed_weight_elems(K, Cin, Cout)) * 4;
   const bool persistent = Cin % 16 == 0 && in_bytes_ll < (1LL << 31) && num_in_rows > 0 &&
                           static_cast<long long>(M_out) * Cout * 4 * kMaxK < (1LL << 32) &&
@@ -1949,6 +2041,8 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   a.trace = nullptr;
   a.queue = nullptr;
   a.dyn_rounds = 2;
+  a.out16 = out16;
+  a.res16 = res16;
   // offset-split layers of the persistent kernel: partial sums combined inside the launch by the last
   // workgroup of each (tile, column unit) instead of by conv_reduce_kernel (the default; SG_CONV_COMBINE=0
   // / sg_spconv_set_combine(0): the separate reduce kernel, same numbers)
@@ -1970,8 +2064,13 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
     const int rc = chain_flush();
     if (rc != SG_OK) return rc;
   }
+  if (in16 || out16 || res16) {
+    SG_REQUIRE(split && split_on == 2, "sg_unet_forward(bf16 rows): layer K=%d Cin=%d Cout=%d does not run on the bf16-operand "
+               "persistent kernel", K, Cin, Cout);
+    SG_REQUIRE(ksplit == 1 || a.done != nullptr, "sg_unet_forward(bf16 rows): an offset-split layer needs the in-launch combine");
+  }
   if (split) {
-    const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream, split_on == 2);
+    const int rc = launch_persistent_split(a, num_tiles, in_bytes_ll, w_bytes_ll, stream, split_on == 2, in16 != 0);
     if (rc != SG_OK) return rc;
     if (t_chain.mode == 2 && t_chain.args.n > 0) return SG_OK;      // recorded (an offset-split layer combines in the launch)
   } else if (persistent) {
@@ -2043,4 +2142,27 @@ int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *n
   return check_launch("sg_spconv_gather_conv_f32");
 }
 
+int sg_spconv_gather_conv_f32(const float *in, int num_in_rows, const int32_t *nbr, int M_out,
+                              int K, int Cin, int Cout, const float *w_k8, const float *post_scale,
+                              const float *post_shift, const float *residual, const float *act_scale,
+                              const float *act_shift, float *out_act, const int32_t *order,
+                              const uint32_t *tile_mask, const int32_t *nbr_tiles, float *out,
+                              void *ws, size_t ws_bytes, sg_stream_t stream_) {
+  return gather_conv_impl(in, num_in_rows, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift, residual, act_scale,
+                          act_shift, out_act, order, tile_mask, nbr_tiles, out, ws, ws_bytes, stream_, 0, 0, 0);
+}
+
 }  // extern "C"
+
+namespace sg {
+// the executor's conv with bf16 rows on either side (unet_exec.hip, arithmetic 3)
+int conv_gather_rows(const void *in, int num_in_rows, const int32_t *nbr, int M_out, int K, int Cin, int Cout,
+                     const float *w_k8, const float *post_scale, const float *post_shift, const void *residual,
+                     const float *act_scale, const float *act_shift, void *out_act, const int32_t *order,
+                     const uint32_t *tile_mask, const int32_t *nbr_tiles, void *out, void *ws, size_t ws_bytes,
+                     sg_stream_t stream, int in16, int out16, int res16) {
+  return gather_conv_impl(static_cast<const float *>(in), num_in_rows, nbr, M_out, K, Cin, Cout, w_k8, post_scale, post_shift,
+                          static_cast<const float *>(residual), act_scale, act_shift, static_cast<float *>(out_act), order,
+                          tile_mask, nbr_tiles, static_cast<float *>(out), ws, ws_bytes, stream, in16, out16, res16);
+}
+}  // namespace sg

@@ -115,6 +115,34 @@ __global__ void __launch_bounds__(256) concat2_kernel(const float4 *__restrict__
   }
 }
 
+// the same over bf16 rows (arithmetic 3), 4 channels = 8 bytes per thread; the activation in fp32, rounded to
+// nearest even when stored
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void __launch_bounds__(256) concat2_bf16_kernel(const uint2 *__restrict__ a, const uint2 *__restrict__ b,
+                                                          int64_t rows, int ca4, int cb4,
+                                                          const float4 *__restrict__ scale,
+                                                          const float4 *__restrict__ shift, uint2 *__restrict__ out,
+                                                          uint2 *__restrict__ out_act) {
+  const int c4 = ca4 + cb4;
+  const int64_t total = rows * c4;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
+    const int64_t r = t / c4;
+    const int c = static_cast<int>(t - r * c4);
+    const uint2 v = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+    out[t] = v;
+    if (out_act) {
+      const float4 s = scale[c], h = shift[c];
+      const float x0 = fmaxf(fmaf(bf16_to_f32(v.x & 0xffffu), s.x, h.x), 0.f), x1 = fmaxf(fmaf(bf16_to_f32(v.x >> 16), s.y, h.y), 0.f);
+      const float x2 = fmaxf(fmaf(bf16_to_f32(v.y & 0xffffu), s.z, h.z), 0.f), x3 = fmaxf(fmaf(bf16_to_f32(v.y >> 16), s.w, h.w), 0.f);
+      out_act[t] = make_uint2(f32_to_bf16(x0) | (f32_to_bf16(x1) << 16), f32_to_bf16(x2) | (f32_to_bf16(x3) << 16));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // index build shared with the training executor (unet_common.h)
 // ---------------------------------------------------------------------------------------------
@@ -344,10 +372,14 @@ struct Exec {
   // chain's decomposition anyway) and every level from l down has a multiple of 32 channels (32-channel
   // items, line-wise gather).  Opened in front of the strided conv INTO level l, closed behind level l's
   // last conv; with chains switched off the same layers are launched one by one, same decomposition.
+  // arithmetic 3: the activations between the layers are bf16 rows (half the floats of a buffer); the features
+  // handed in and the U-Net's output stay fp32
+  bool r16 = false;
+  size_t fsz(size_t n) const { return r16 ? (n + 1) / 2 : n; }
   bool chain_open = false;
   bool chain_from(int l) const {
     static const int max_rows = getenv("SG_CONV_CHAIN_ROWS") ? atoi(getenv("SG_CONV_CHAIN_ROWS")) : 6144;
-    if (chain_open || idx[l].rows > max_rows || idx[l].rows <= 0) return false;
+    if (r16 || chain_open || idx[l].rows > max_rows || idx[l].rows <= 0) return false;
     for (int k = l; k < d->n_levels; ++k)
       if (d->levels[k].planes % 32 != 0) return false;
     return true;
@@ -382,8 +414,11 @@ struct Exec {
     float *out = nullptr;
   };
 
+  // in_f32 / out_f32: this layer's input / output rows are fp32 although the executor runs on bf16 rows (the
+  // input conv reads the API's features, the U-Net's last conv writes the API's output)
   int conv(const float *in, int in_rows, const Plan &p, int cin, int cout, const float *w,
-           const float *post_s, const float *post_b, const float *residual, const Act &act, float *out) {
+           const float *post_s, const float *post_b, const float *residual, const Act &act, float *out,
+           bool in_f32 = false, bool out_f32 = false) {
     if (p.rows == 0) return SG_OK;
     const size_t m = ar.mark();
     const size_t nb = sg_spconv_conv_workspace_bytes(p.rows, cout);
@@ -391,9 +426,12 @@ struct Exec {
     if (nb > 256) {
       ws = ar.take<char>(nb);   // optional: without it the conv simply does not split offsets
     }
-    const int rc = sg_spconv_gather_conv_f32(in, in_rows, p.nbr, p.rows, p.kvol, cin, cout, w, post_s,
-                                             post_b, residual, act.scale, act.shift, act.out, p.order,
-                                             p.tile_mask, p.nbr_tiles, out, ws, ws ? nb : 0, stream);
+    const int rc = !r16 ? sg_spconv_gather_conv_f32(in, in_rows, p.nbr, p.rows, p.kvol, cin, cout, w, post_s,
+                                                    post_b, residual, act.scale, act.shift, act.out, p.order,
+                                                    p.tile_mask, p.nbr_tiles, out, ws, ws ? nb : 0, stream)
+                        : conv_gather_rows(in, in_rows, p.nbr, p.rows, p.kvol, cin, cout, w, post_s, post_b, residual,
+                                           act.scale, act.shift, act.out, p.order, p.tile_mask, p.nbr_tiles, out, ws,
+                                           ws ? nb : 0, stream, in_f32 ? 0 : 1, out_f32 ? 0 : 1, 1);
     ar.release(m);
     return rc;
   }
@@ -402,17 +440,18 @@ struct Exec {
   // identity branch when the channel count changes.  `xa` = relu(bn1(x)), made by whoever produced
   // x; `next` = the activation the consumer of this block's output wants (second output of conv2).
   int block(const sg_unet_block &b, const float *x, const float *xa, int rows, const Plan &subm,
-            const Plan &ident, const float *post_s, const float *post_b, const Act &next, float *out) {
+            const Plan &ident, const float *post_s, const float *post_b, const Act &next, float *out,
+            bool out_f32 = false) {
     const size_t m = ar.mark();
     const float *shortcut = x;
     if (b.w_i != nullptr) {
-      SG_ALLOC(sc, float, static_cast<size_t>(rows) * b.cout);
+      SG_ALLOC(sc, float, fsz(static_cast<size_t>(rows) * b.cout));
       SG_TRY(conv(x, rows, ident, b.cin, b.cout, b.w_i, nullptr, nullptr, nullptr, Act(), sc));
       shortcut = sc;
     }
-    SG_ALLOC(h, float, static_cast<size_t>(rows) * b.cout);
+    SG_ALLOC(h, float, fsz(static_cast<size_t>(rows) * b.cout));
     SG_TRY(conv(xa, rows, subm, b.cin, b.cout, b.w1, b.bn2_scale, b.bn2_shift, nullptr, Act(), h));
-    SG_TRY(conv(h, rows, subm, b.cout, b.cout, b.w2, post_s, post_b, shortcut, next, out));
+    SG_TRY(conv(h, rows, subm, b.cout, b.cout, b.w2, post_s, post_b, shortcut, next, out, false, out_f32));
     ar.release(m);
     return SG_OK;
   }
@@ -430,7 +469,7 @@ struct Exec {
     const LevelIdx &I = idx[l];
     const int rows = I.rows;
     const Plan &subm = I.subm, &ident = I.ident;
-    const size_t feat = static_cast<size_t>(rows ? rows : 1) * c;
+    const size_t feat = fsz(static_cast<size_t>(rows ? rows : 1) * c);      // floats of one [rows, c] buffer
     // optional input conv (outermost level only): SubMConv3d(in, planes) on the same rulebook
     if (pre_in != nullptr) {
       SG_ALLOC(x0, float, feat);
@@ -445,7 +484,7 @@ struct Exec {
             pre_in, rows, pre_cin, cpk, perm, xp);
         pre_in = xp;
       }
-      SG_TRY(conv(pre_in, rows, subm, cpk, c, d->input_w, nullptr, nullptr, nullptr, a0, x0));
+      SG_TRY(conv(pre_in, rows, subm, cpk, c, d->input_w, nullptr, nullptr, nullptr, a0, x0, true, false));
       x = x0;
       xa = x0a;
     } else if (xa == nullptr) {
@@ -472,7 +511,7 @@ struct Exec {
       }
       const bool fin = last && !deeper;
       SG_TRY(block(L.blocks[i], cur, cur_a, rows, subm, ident, fin ? post_s : nullptr,
-                   fin ? post_b : nullptr, next, dst));
+                   fin ? post_b : nullptr, next, dst, fin && l == 0));
       cur = dst;
       cur_a = next.out;
     }
@@ -483,7 +522,7 @@ struct Exec {
       // ---- (BN -> ReLU done by the last block) -> SparseConv3d(c, c2, k2 s2); its second output
       //      feeds the first BatchNorm of the inner level
       const sg_unet_level &L2 = d->levels[l + 1];
-      const size_t feat2 = static_cast<size_t>(rows2 ? rows2 : 1) * c2;
+      const size_t feat2 = fsz(static_cast<size_t>(rows2 ? rows2 : 1) * c2);
       SG_ALLOC(y, float, feat2);
       SG_ALLOC(ya, float, feat2);
       const Act ay{L2.blocks[0].bn1_scale, L2.blocks[0].bn1_shift, ya};
@@ -504,7 +543,12 @@ struct Exec {
         const size_t m = ar.mark();
         SG_ALLOC(upf, float, feat);
         SG_TRY(conv(z, rows2, up, c2, c, L.up_w, nullptr, nullptr, nullptr, Act(), upf));
-        if (rows && conv_chain_recording())
+        if (rows && r16)
+          concat2_bf16_kernel<<<grid_for(static_cast<int64_t>(rows) * (2 * c / 4), 256), 256, 0, as_stream(stream)>>>(
+              reinterpret_cast<const uint2 *>(cur), reinterpret_cast<const uint2 *>(upf), rows, c / 4, c / 4,
+              reinterpret_cast<const float4 *>(L.tail[0].bn1_scale), reinterpret_cast<const float4 *>(L.tail[0].bn1_shift),
+              reinterpret_cast<uint2 *>(cat), reinterpret_cast<uint2 *>(cata));
+        else if (rows && conv_chain_recording())
           SG_TRY(conv_chain_concat(cur, upf, rows, c, c, L.tail[0].bn1_scale, L.tail[0].bn1_shift, cat, cata));
         else if (rows)
           concat2_kernel<<<grid_for(static_cast<int64_t>(rows) * (2 * c / 4), 256), 256, 0, as_stream(stream)>>>(
@@ -528,7 +572,7 @@ struct Exec {
           next = Act{L.tail[i + 1].bn1_scale, L.tail[i + 1].bn1_shift, ta};
         }
         SG_TRY(block(L.tail[i], cur, cur_a, rows, subm, ident, last ? post_s : nullptr,
-                     last ? post_b : nullptr, next, dst));
+                     last ? post_b : nullptr, next, dst, last && l == 0));
         cur = dst;
         cur_a = next.out;
       }
@@ -590,7 +634,7 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   for (int l = 0; l < d->n_levels; ++l)
     SG_REQUIRE(d->levels[l].planes % 4 == 0 && d->levels[l].n_blocks >= 1,
                "sg_unet_forward: level %d: planes must be a multiple of 4", l);
-  SG_REQUIRE(d->arithmetic == 0 || d->arithmetic == 2, "sg_unet_forward: arithmetic must be 0 or 2");
+  SG_REQUIRE(d->arithmetic == 0 || d->arithmetic == 2 || d->arithmetic == 3, "sg_unet_forward: arithmetic must be 0, 2 or 3");
   if (num_rows == 0) return SG_OK;
   SG_TRY(conv_chain_check_abort("sg_unet_forward"));
   const int L = d->n_levels;
@@ -598,7 +642,11 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
     int keep;
     explicit ArithScope(int a) : keep(t_conv_arith) { if (a > 0) t_conv_arith = a; }
     ~ArithScope() { t_conv_arith = keep; }
-  } arith_scope(d->arithmetic);
+  } arith_scope(d->arithmetic == 3 ? 2 : d->arithmetic);
+  // bf16 rows between the layers (arithmetic 3) need an input conv (the API's fp32 features enter through it) and
+  // 32-channel items on every level; anything else runs as arithmetic 2 (bf16 operands, fp32 rows)
+  bool rows16 = d->arithmetic == 3 && d->input_w != nullptr;
+  for (int l = 0; l < d->n_levels; ++l) rows16 = rows16 && d->levels[l].planes % 32 == 0;
   // ---- internal row order (see morton_key_kernel): SG_UNET_MORTON=1 turns it on (A/B knob; off by
   //      default: measured neutral under the default tile plan and not enough to pay for the spatially
   //      local plans' extra items, profiles/r05_conv_locality.txt), SG_UNET_MORTON_MIN = smallest input
@@ -670,6 +718,7 @@ int sg_unet_forward(const sg_unet_desc *d, const float *feats, const int32_t *in
   }
   Exec ex(d, rest + used, rest_bytes - used, stream, li);
   ex.perm = pre ? perm : nullptr;
+  ex.r16 = rows16;
   int rc;
   {
     // a U-Net that is small from level 0 on (the tiny U-Net over the proposals' voxels): the whole forward

@@ -6,6 +6,7 @@ packed weights, eval-mode BatchNorm as scale/shift -- and runs it with one call 
 Used for inference only (no autograd through it); the module path launches the same kernels and
 remains the training path."""
 import ctypes as C
+import os
 import operator
 import threading
 
@@ -41,6 +42,11 @@ _VERSION = operator.attrgetter('_version')
 _DATA_PTR = torch.Tensor.data_ptr
 _desc_lock = threading.Lock()
 _ERR_WORKSPACE = -2     # SG_ERR_WORKSPACE (include/softgroup_hip.h)
+# bf16 rows between the layers under bf16 autocast (arithmetic 3).  Off by default: measured at the SAME speed as bf16
+# operands over fp32 rows (profiles/r06_rows16.txt: 64->64 x 77 k rows 35.3 against 34.8 us, backbone forward 1.22 against
+# 1.20 ms of conv time) at slightly lower accuracy (4.4e-3 against 3.2e-3 of the fp32 output) -- with one MFMA per product
+# the kernel waits neither for gather bytes nor for conversions.  Halves the activation memory of the forward.
+ROWS16 = os.environ.get('SG_UNET_ROWS16', '0') != '0'
 _arena = {}      # (device, stream) -> uint8 tensor, grow-only: concurrent scans on different
                  # streams never share an arena
 
@@ -244,8 +250,11 @@ class UNetExecutor:
             # convolutions take bf16 operands like the module path's gather_conv_bf16 does -- one
             # MFMA per product instead of the six of the fp32-accurate split; sums and stored
             # activations stay fp32.  (a per-call copy: the cached descriptor is shared by threads)
+            # Arithmetic 3 (SG_UNET_ROWS16=0: arithmetic 2): the activations BETWEEN the layers are bf16 rows as well
+            # -- what spconv keeps under the reference's autocast (tools/train.py:47) and what this package's module
+            # path does (gather_conv_bf16 stores bf16) -- half the gather bytes, no conversion in the matrix loop.
             d = _Desc.from_buffer_copy(d)
-            d.arithmetic = 2
+            d.arithmetic = 3 if ROWS16 else 2
         feats = x.features.contiguous()
         idx = x.indices.contiguous()
         M = feats.shape[0]

@@ -579,3 +579,37 @@ def test_in_launch_combine_equals_the_reduce_kernel(cin, cout, n, split):
             assert torch.equal(a_act, b_act)
         else:
             assert torch.isnan(b_act).all()              # no second output asked: left untouched
+
+
+@pytest.mark.parametrize('points', [30000, 150000])
+def test_executor_bf16_rows_under_autocast(points):
+    """sg_unet_desc.arithmetic = 3 (a frozen backbone under bf16 autocast, reference tools/train.py:47): bf16
+    operands AND bf16 activation rows between the layers -- 64-byte half-line gathers whose LDS-transposed chunks are
+    MFMA operands as they are, results rounded to nearest even when stored.  Against arithmetic 2 (bf16 operands,
+    fp32 rows) and against fp32: the extra rounding of ~80 stored activations stays at bf16 accuracy; input and
+    output of the U-Net stay fp32; deterministic."""
+    from softgroup_amd import synthetic, ops
+    from softgroup_amd.spconv import unet_exec
+    xyz, rgb, inst = synthetic.scene_s2(seed=6, n=points, room_scale=0.5 if points < 100000 else 1.0)
+    b = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    model = synthetic.build_model(seed=0)
+    with torch.no_grad():
+        vf = ops.voxelization(torch.cat((b['feats'], b['coords_float']), 1), b['p2v_map'])
+        x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], 1)
+        f32 = model._unet_features(x).clone()
+        keep = unet_exec.ROWS16
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                unet_exec.ROWS16 = False
+                a2 = model._unet_features(x).float().clone()
+                unet_exec.ROWS16 = True
+                a3 = model._unet_features(x).float().clone()
+                a3b = model._unet_features(x).float().clone()
+        finally:
+            unet_exec.ROWS16 = keep
+    assert torch.isfinite(a3).all() and torch.equal(a3, a3b)
+    rel = lambda u, v: float((u - v).norm() / v.norm())       # noqa: E731
+    e2, e3, e32 = rel(a2, f32), rel(a3, f32), rel(a3, a2)
+    print(f'{points} points: relative L2 to fp32: bf16 operands {e2:.3e}, + bf16 rows {e3:.3e}; between the two {e32:.3e}')
+    assert e2 <= 3e-2 and e3 <= 4e-2 and e3 <= 3 * e2 + 1e-3, (e2, e3)

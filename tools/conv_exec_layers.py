@@ -23,8 +23,10 @@ def main():
     b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     model = synthetic.build_model(seed=0)
     lib = L.lib()
-    with torch.no_grad():
-        vf = ops.voxelization(torch.cat((b['feats'], b['coords_float']), 1), b['p2v_map'])
+    import contextlib
+    ac = torch.autocast('cuda', dtype=torch.bfloat16) if os.environ.get('AUTOCAST') else contextlib.nullcontext()
+    with torch.no_grad(), ac:
+        vf = ops.voxelization(torch.cat((b['feats'], b['coords_float']), 1), b['p2v_map']).float()
         x = spconv.SparseConvTensor(vf, b['voxel_coords'].int(), b['spatial_shape'], 1)
         for _ in range(3):
             ref = model._unet_features(x)
