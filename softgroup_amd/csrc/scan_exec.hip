@@ -13,6 +13,7 @@
 // the calling thread's pinned words (no pageable copies, no interpreter lock held while waiting).
 // Every float operation of the glue is written as the separate IEEE operation torch performs
 // (file compiled with -ffp-contract=off): results are bit-identical to the module path.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -430,7 +431,22 @@ struct ScanArena {
   size_t at(const void *p) const { return static_cast<size_t>(static_cast<const char *>(p) - base); }
 };
 
+// SG_READBACK_KERNEL=1 (developer knob): the words reach the calling thread's pinned buffer through a one-wave
+// kernel that stores them there (the buffer is mapped into the device's address space) instead of a copy command
+__global__ void __launch_bounds__(64) read_back_kernel(const int32_t *__restrict__ dev, int words, int32_t *host) {
+  if (static_cast<int>(threadIdx.x) < words)
+    __hip_atomic_store(host + threadIdx.x, dev[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 static int read_back(int32_t *host, const int32_t *dev, int words, hipStream_t stream, const char *what) {
+  static const bool by_kernel = getenv("SG_READBACK_KERNEL") && atoi(getenv("SG_READBACK_KERNEL")) != 0;
+  if (by_kernel && words <= 64) {
+    read_back_kernel<<<1, 64, 0, stream>>>(dev, words, host);
+    if (hipStreamSynchronize(stream) != hipSuccess) {
+      set_error("%s: device -> host read-back failed", what);
+      return SG_ERR_LAUNCH;
+    }
+    return SG_OK;
+  }
   if (hipMemcpyAsync(host, dev, sizeof(int32_t) * words, hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess) {
     set_error("%s: device -> host read-back failed", what);
