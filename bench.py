@@ -929,14 +929,22 @@ def main():
         digest_on_worker = os.environ.get('SG_BENCH_DIGEST', 'main') == 'worker'
         if digest_on_worker and not os.environ.get('SG_BENCH_SKIP_DIGEST'):
             model.scan_result_hook = lambda res: res.__setitem__('result_digest', result_digest(res))
-        for r in [model(batches[i % n_scenes]) for i in range(max(args.warmup, 1))]:
-            r.resolve()
         # the interpreter's cyclic garbage collector pauses every thread of the process while it walks
         # the heap (scenes, modules, the oracle's tables: millions of objects by now): collect once and
-        # park what is alive, so that no full collection falls into the timed region
+        # park what is alive, so that no full collection falls into the timed region.  BEFORE the warm-up
+        # steps (SG_BENCH_GC_AFTER_WARMUP=1: after them, as until round 5): the collection takes a few hundred
+        # milliseconds of host time during which the GPU idles, and the timed region should follow the warm-up
+        # steps directly, as the contract describes it
         import gc
-        gc.collect()
-        gc.freeze()
+        gc_after = os.environ.get('SG_BENCH_GC_AFTER_WARMUP') == '1'
+        if not gc_after:
+            gc.collect()
+            gc.freeze()
+        for r in [model(batches[i % n_scenes]) for i in range(max(args.warmup, 1))]:
+            r.resolve()
+        if gc_after:
+            gc.collect()
+            gc.freeze()
         issued = iter(range(args.steps))
         checked = iter(range(args.steps))
 

@@ -57,6 +57,15 @@ int sg_device_info(char *name_host, int name_cap, int *num_cu_host, int *clock_k
  * before destroying it, on the stream's device.  No counterpart in the reference (spconv keeps its
  * workspaces in the torch allocator). */
 int sg_stream_release(sg_stream_t stream);
+/* A stream of the library's own (hipStreamCreateWithFlags, non-blocking) for a scan worker, and its end:
+ * sg_stream_destroy synchronises it, releases its state (sg_stream_release) and destroys it.  Unlike the streams
+ * a framework hands out from a fixed pool (torch.cuda.Stream() reuses 32 raw handles per device), such a handle
+ * is never shared with a later owner, so releasing its state cannot pull buffers from under somebody else's
+ * kernels.  The Python binding wraps it as torch.cuda.ExternalStream and, because PyTorch's caching allocator
+ * aborts when a stream it has seen disappears, PARKS a retired worker's stream (sg_stream_release only) for the
+ * next pool instead of destroying it; sg_stream_destroy is for hosts without such an allocator. */
+int sg_stream_create(sg_stream_t *stream_out);
+int sg_stream_destroy(sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelisation index build.  Replaces `voxelize_idx` (softgroup_api.cpp:12,

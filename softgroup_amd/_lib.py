@@ -20,6 +20,8 @@ SIGNATURES = {
     'sg_last_error': (C.c_char_p, []),
     'sg_device_info': (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
     'sg_stream_release': (_i, [_vp]),
+    'sg_stream_create': (_i, [_vp]),
+    'sg_stream_destroy': (_i, [_vp]),
     'sg_voxelize_idx_host': (_i, [_vp, _i, _i, _i, _vp, _pi32, _pi32]),
     'sg_voxelize_idx_fill_host': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'sg_voxelize_idx_workspace_bytes': (_sz, [_i]),

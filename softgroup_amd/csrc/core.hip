@@ -83,6 +83,33 @@ int sg_stream_release(sg_stream_t stream) {
   return SG_OK;
 }
 
+int sg_stream_create(sg_stream_t *stream_out) {
+  SG_REQUIRE(stream_out != nullptr, "sg_stream_create: null argument");
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    sg::set_error("sg_stream_create: hipStreamCreateWithFlags failed");
+    return SG_ERR_LAUNCH;
+  }
+  *stream_out = reinterpret_cast<sg_stream_t>(s);
+  return SG_OK;
+}
+
+int sg_stream_destroy(sg_stream_t stream) {
+  SG_REQUIRE(stream != nullptr, "sg_stream_destroy: the null stream is not the library's");
+  hipStream_t s = sg::as_stream(stream);
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    sg::set_error("sg_stream_destroy: synchronising the stream failed");
+    return SG_ERR_LAUNCH;
+  }
+  const int rc = sg_stream_release(stream);
+  if (rc != SG_OK) return rc;
+  if (hipStreamDestroy(s) != hipSuccess) {
+    sg::set_error("sg_stream_destroy: hipStreamDestroy failed");
+    return SG_ERR_LAUNCH;
+  }
+  return SG_OK;
+}
+
 size_t sg_scan_workspace_bytes(int n) { return sg::scan_workspace_bytes(n); }
 
 // start_len[i,0] = exclusive prefix of start_len[:,1]

@@ -44,6 +44,7 @@ class _Mlp2(ctypes.Structure):       # sg_mlp2 (include/softgroup_hip.h)
 _scan_local = threading.local()      # per worker thread: its HIP stream
 _EARLY_COPY = os.environ.get('SG_EARLY_COPY', '1') != '0'      # (developer A/B knob)
 _POOL_LOCK = threading.Lock()        # creation / retirement of a model's scan pool
+_PARKED_STREAMS = {}                 # device -> library-owned worker streams of retired pools, for the next pool
 
 
 def _retire_pool(pool, wait=True):
@@ -65,7 +66,14 @@ def _retire_pool(pool, wait=True):
             NS.release_stream(raw)
             SF.release_stream(raw)
             UE.release_stream(raw)
+            # the workers' streams are the library's own (sg_stream_create): no other Stream object holds this
+            # handle, so releasing its per-stream state cannot pull buffers from under anybody else's kernels
+            # (ADVICE r5).  The stream itself is PARKED for the next pool's workers, not destroyed: PyTorch's
+            # caching allocator keeps blocks and events tied to every stream it has seen and aborts the process
+            # when one of them is gone (measured: the next allocation after a hipStreamDestroy).
             L.check(L.lib().sg_stream_release(raw), 'sg_stream_release')
+            with _POOL_LOCK:
+                _PARKED_STREAMS.setdefault(dev, []).append(st)
     pool._sg_streams = []
 
 
@@ -234,8 +242,16 @@ class SoftGroup(nn.Module):
             with torch.cuda.device(dev):
                 st = getattr(local, 'stream', None)
                 if st is None:
-                    st = local.stream = torch.cuda.Stream()
-                    my_pool._sg_streams.append((dev, st))      # released when the pool is retired
+                    with _POOL_LOCK:
+                        parked = _PARKED_STREAMS.get(dev)
+                        st = parked.pop() if parked else None
+                    if st is None:
+                        from .. import _lib as L_
+                        raw = ctypes.c_void_p(0)
+                        L_.check(L_.lib().sg_stream_create(ctypes.byref(raw)), 'sg_stream_create')
+                        st = torch.cuda.ExternalStream(raw.value, device=dev)
+                    local.stream = st
+                    my_pool._sg_streams.append((dev, st))      # state released, stream parked when the pool is retired
                 with torch.cuda.stream(st), torch.no_grad():
                     st.wait_event(ready)
                     out = self.forward_test(**batch, _inline_results=True)

@@ -470,3 +470,43 @@ def test_bench_ddp_leg_runs_on_rccl():
     assert rec['backend'] == 'nccl' and rec['allreduce_bytes'] == 2919208
     assert rec['trainable_bytes'] == 2919208            # what DDP all-reduces: the heads, not the frozen backbone
     assert 0 < rec['allreduce_ms_min'] and 0 < rec['train_ms_per_step_min'] < 1000
+
+
+def test_bf16_autocast_full_model_follows_fp32_from_the_same_weights():
+    """The full-model lines of tools/train_step_bench.py up to round 5 (profiles/r05_train_step.txt: total loss 12.51
+    in fp32, 9.50 under bf16 autocast) were NOT a precision gap: the tool timed 13 optimisation steps in fp32 and then
+    13 MORE under autocast on the same model and optimiser and printed each block's last loss -- the bf16 figure is the
+    loss after 26 steps.  From the SAME weights (S3DIS model section, nothing frozen, one S2 scene, semantic head
+    re-drawn with std 20) the two precisions follow each other: every loss term of every one of 4 steps within 5 %."""
+    import copy
+    from softgroup_amd.model import SoftGroup
+    cfg = copy.deepcopy(synthetic.S3DIS_MODEL_CFG)
+    cfg['test_cfg']['x4_split'] = False
+    cfg['fixed_modules'] = []
+    xyz, rgb, inst = synthetic.scene_s2(seed=21, n=60000, room_scale=0.65)
+    batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
+    batch['semantic_labels'] = batch['semantic_labels'].clamp(max=12)
+    batch['instance_cls'] = batch['instance_cls'].clamp(max=12)
+    runs = {}
+    for name in ('fp32', 'bf16'):
+        torch.manual_seed(0)
+        model = SoftGroup(**cfg).cuda()
+        with torch.no_grad():
+            model.semantic_linear[-1].weight.normal_(0, 20.0)
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16) if name == 'bf16' else torch.autocast('cuda', enabled=False)
+        logs = []
+        for it in range(4):
+            torch.manual_seed(100 + it)
+            with ctx:
+                loss, log = model(batch, return_loss=True)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            logs.append(log)
+        runs[name] = logs
+    for it, (a, b) in enumerate(zip(runs['fp32'], runs['bf16'])):
+        print(f'step {it}: fp32', {k: round(v, 4) for k, v in a.items()}, '| bf16', {k: round(v, 4) for k, v in b.items()})
+        for k in ('semantic_loss', 'offset_loss', 'loss'):
+            assert abs(a[k] - b[k]) <= 0.05 * abs(a[k]) + 2e-2, (it, k, a[k], b[k])

@@ -20,18 +20,21 @@ def main():
         cfg['test_cfg']['x4_split'] = False
         if not frozen:
             cfg['fixed_modules'] = []
-        torch.manual_seed(0)
-        model = SoftGroup(**cfg).cuda()
-        with torch.no_grad():
-            model.semantic_linear[-1].weight.normal_(0, 20.0)
-        model.train()
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
         xyz, rgb, inst = synthetic.scene_s2(seed=21, n=n)
         batch = synthetic.make_batch(xyz, rgb, instance_labels=inst)
         batch['semantic_labels'] = batch['semantic_labels'].clamp(max=12)
         batch['instance_cls'] = batch['instance_cls'].clamp(max=12)
         for name, ctx in (('fp32', torch.autocast('cuda', enabled=False)),
                           ('bf16 autocast', torch.autocast('cuda', dtype=torch.bfloat16))):
+            # a fresh model and optimiser per precision: both lines start from the SAME weights and print the loss
+            # of the same step (until round 5 the bf16 block continued the fp32 block's training: its loss was the
+            # one after 26 steps, which read as a precision gap -- 12.5 vs 9.5 on the full model)
+            torch.manual_seed(0)
+            model = SoftGroup(**cfg).cuda()
+            with torch.no_grad():
+                model.semantic_linear[-1].weight.normal_(0, 20.0)
+            model.train()
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
             ts = []
             for it in range(13):
                 torch.cuda.synchronize()
