@@ -640,6 +640,25 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
         torch.cuda.synchronize()
         ms_h2d_prefetch = (time.perf_counter() - t0) / 10 * 1e3
         del rets
+        # ... and the headline's shape -- scans in flight on the worker streams -- fed from pinned HOST scenes by the
+        # loader thread instead of from HBM-resident batches: what a serving loop over a DataLoader sees
+        in_flight, _ = host_thread_plan(5, 1)
+        n_loaders = int(os.environ.get('SG_BENCH_LOADERS', '1'))
+        model.scan_contexts = in_flight
+        try:
+            for r in [model(b_) for b_ in prefetch_device([[sample]] * (2 * in_flight), depth=2, workers=n_loaders)]:
+                r.resolve()
+            torch.cuda.synchronize()
+            n_fed = 40
+            t0 = time.perf_counter()
+            rets = [model(b_) for b_ in prefetch_device([[sample]] * n_fed, depth=2, workers=n_loaders)]
+            for r in rets:
+                r.resolve()
+            torch.cuda.synchronize()
+            ms_fed = (time.perf_counter() - t0) / n_fed * 1e3
+            del rets
+        finally:
+            model.scan_contexts = 1
         # the host link of this box, for reading the figure: pinned -> device copy rate
         hbuf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
         dbuf = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
@@ -647,6 +666,8 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
         scan_bytes = sum(v.numel() * v.element_size() for v in sample if isinstance(v, torch.Tensor))
         legs['with_h2d'] = {'ms_per_step_with_h2d': round(ms_h2d, 3),
                             'ms_per_step_with_h2d_next_scan_prefetched': round(ms_h2d_prefetch, 3),
+                            'ms_per_scan_scans_in_flight_fed_from_pinned_host': round(ms_fed, 3),
+                            'scans_in_flight': in_flight, 'loader_threads': n_loaders,
                             'collate_ms': round(collate_ms, 3), 'collate_host_part_ms': round(collate_host_ms, 3),
                             'host_bytes_per_scan': int(scan_bytes),
                             'pinned_h2d_GBps_on_this_box': round((64 << 20) / link_ms / 1e6, 2),

@@ -713,6 +713,15 @@ int sg_scan_grouping_pp(const sg_grouping_pp_cfg *cfg, const float *scores, cons
                         void *arena, size_t arena_bytes, sg_grouping_result *result_host,
                         sg_stream_t stream);
 
+/* Host-side staging copies of the device-side collate (the reference's collate_fn, data/custom.py:196-256, does
+ * them with torch.cat on the CPU): dense / strided row copies, the float64 -> float32 cast of an item's labels and
+ * the batch-index column of the collated coordinates, as plain C so that a binding can run them without the
+ * interpreter lock (a loader thread preparing the next scan next to the threads that drive the scans in flight). */
+int sg_host_copy_2d(void *dst, int64_t dst_pitch_bytes, const void *src, int64_t src_pitch_bytes, int64_t rows,
+                    int64_t row_bytes);
+int sg_host_cast_f64_f32(float *dst, const double *src, int64_t n);
+int sg_host_fill_i64_strided(int64_t *dst, int64_t pitch_elems, int64_t rows, int64_t value);
+
 typedef struct sg_instances_cfg {
   int n_proposals, n_classes;   /* instance classes (without the background column) */
   int score_stride;             /* columns of cls_prob / iou_scores / mask_scores (n_classes + 1) */

@@ -20,6 +20,9 @@ SIGNATURES = {
     'sg_last_error': (C.c_char_p, []),
     'sg_device_info': (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
     'sg_stream_release': (_i, [_vp]),
+    'sg_host_copy_2d': (_i, [_vp, _i64, _vp, _i64, _i64, _i64]),
+    'sg_host_cast_f64_f32': (_i, [_vp, _vp, _i64]),
+    'sg_host_fill_i64_strided': (_i, [_vp, _i64, _i64, _i64]),
     'sg_stream_create': (_i, [_vp]),
     'sg_stream_destroy': (_i, [_vp]),
     'sg_voxelize_idx_host': (_i, [_vp, _i, _i, _i, _vp, _pi32, _pi32]),

@@ -292,3 +292,51 @@ int64_t sg_rle_format_bound(int64_t total_runs, int digits) {
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------
+// Staging copies of the device-side collate (softgroup_amd/data: the reference's collate_fn,
+// data/custom.py:196-256, concatenates its items with torch.cat on the CPU): plain C loops that a ctypes
+// binding runs WITHOUT the interpreter lock, so that a loader thread filling the next scan's pinned
+// staging buffers does not stall the threads that drive the scans in flight.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+// rows x row_bytes from src (pitch src_pitch) to dst (pitch dst_pitch); one memcpy when both are dense
+int sg_host_copy_2d(void *dst, int64_t dst_pitch, const void *src, int64_t src_pitch, int64_t rows, int64_t row_bytes) {
+  if (rows <= 0 || row_bytes <= 0) return SG_OK;
+  if (dst == nullptr || src == nullptr || dst_pitch < row_bytes || src_pitch < row_bytes) {
+    sg::set_error("sg_host_copy_2d: bad arguments");
+    return SG_ERR_ARG;
+  }
+  if (dst_pitch == row_bytes && src_pitch == row_bytes) {
+    memcpy(dst, src, static_cast<size_t>(rows) * row_bytes);
+    return SG_OK;
+  }
+  char *d = static_cast<char *>(dst);
+  const char *s = static_cast<const char *>(src);
+  for (int64_t r = 0; r < rows; ++r) memcpy(d + r * dst_pitch, s + r * src_pitch, static_cast<size_t>(row_bytes));
+  return SG_OK;
+}
+
+// dst[i] = (float)src[i] (float64 labels of an item into a float32 batch tensor)
+int sg_host_cast_f64_f32(float *dst, const double *src, int64_t n) {
+  if (n > 0 && (dst == nullptr || src == nullptr)) {
+    sg::set_error("sg_host_cast_f64_f32: null pointer");
+    return SG_ERR_ARG;
+  }
+  for (int64_t i = 0; i < n; ++i) dst[i] = static_cast<float>(src[i]);
+  return SG_OK;
+}
+
+// the batch-index column of the collated coordinates: dst[r * pitch_elems] = value for r < rows
+int sg_host_fill_i64_strided(int64_t *dst, int64_t pitch_elems, int64_t rows, int64_t value) {
+  if (rows > 0 && (dst == nullptr || pitch_elems < 1)) {
+    sg::set_error("sg_host_fill_i64_strided: bad arguments");
+    return SG_ERR_ARG;
+  }
+  for (int64_t r = 0; r < rows; ++r) dst[r * pitch_elems] = value;
+  return SG_OK;
+}
+
+}  // extern "C"

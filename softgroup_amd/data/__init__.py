@@ -17,10 +17,12 @@ Every tensor of the result is already resident: ``forward_test``'s ``cuda_cast``
 """
 import math
 import threading
+import time
 
 import numpy as np
 import torch
 
+from .. import _lib as L
 from .. import ops
 
 _STAGING_POOL, _STAGING_POOL_LOCK = [], threading.Lock()    # staging sets of finished prefetch_device loaders
@@ -45,10 +47,21 @@ def _to_device(key, parts, dtype, device):
     slot, host = _pinned(key, shape, dtype)
     # plain single-threaded numpy copies: a torch CPU op would wake the whole intra-op thread pool
     # (one thread per core) for a few MB and leave it spinning next to the launch thread
+    # the copies run in C without the interpreter lock where they are a plain move or the float64 -> float32 cast
+    # (libsoftgroup_hip.so: sg_host_copy_2d / sg_host_cast_f64_f32); anything else through numpy
+    lib = L.lib()
     dst, row = host.numpy(), 0
+    row_bytes = host[0:1].numel() * host.element_size() if shape[0] else 0
     for p in parts:
-        dst[row:row + p.shape[0]] = p.numpy()          # casts when the dtypes differ
-        row += p.shape[0]
+        n = p.shape[0]
+        if n and p.dtype == dtype and p.is_contiguous():
+            L.check(lib.sg_host_copy_2d(host.data_ptr() + row * row_bytes, row_bytes, p.data_ptr(), row_bytes, n, row_bytes),
+                    'sg_host_copy_2d')
+        elif n and p.dtype == torch.float64 and dtype == torch.float32 and p.is_contiguous():
+            L.check(lib.sg_host_cast_f64_f32(host.data_ptr() + row * row_bytes, p.data_ptr(), p.numel()), 'sg_host_cast_f64_f32')
+        elif n:
+            dst[row:row + n] = p.numpy()          # casts when the dtypes differ
+        row += n
     dev = torch.empty(shape, dtype=dtype, device=device)
     dev.copy_(host, non_blocking=True)
     if slot[1] is None:
@@ -238,11 +251,17 @@ def collate_device(batch, min_spatial=128, device='cuda'):
     # coords [N, 1+3] with the batch index in column 0, assembled directly in the staging buffer
     n_total = sum(c.shape[0] for c in coords)
     slot, host = _pinned('coords', (n_total, 4), torch.int64)
+    lib = L.lib()
     dst, row = host.numpy(), 0
     for b, c in enumerate(coords):
-        dst[row:row + c.shape[0], 0] = b
-        dst[row:row + c.shape[0], 1:] = c.numpy()
-        row += c.shape[0]
+        n = c.shape[0]
+        if n and c.dtype == torch.int64 and c.is_contiguous() and c.shape[1] == 3:      # (no interpreter lock held)
+            L.check(lib.sg_host_fill_i64_strided(host.data_ptr() + row * 32, 4, n, b), 'sg_host_fill_i64_strided')
+            L.check(lib.sg_host_copy_2d(host.data_ptr() + row * 32 + 8, 32, c.data_ptr(), 24, n, 24), 'sg_host_copy_2d')
+        elif n:
+            dst[row:row + n, 0] = b
+            dst[row:row + n, 1:] = c.numpy()
+        row += n
     d_coords = torch.empty((n_total, 4), dtype=torch.int64, device=dev)
     d_coords.copy_(host, non_blocking=True)
     if slot[1] is None:
@@ -267,34 +286,57 @@ def collate_device(batch, min_spatial=128, device='cuda'):
     return out
 
 
-def prefetch_device(batches, collate=None, depth=1, device='cuda'):
-    """Generator over device-resident batch dicts with the NEXT batch's collate -- the copies into pinned
-    staging, the asynchronous H2D transfers and the device voxel index -- running on a loader thread and its
-    own stream while the consumer works on the current one: what the reference gets from DataLoader workers
+def prefetch_device(batches, collate=None, depth=1, device='cuda', workers=1):
+    """Generator over device-resident batch dicts with the NEXT batches' collate -- the copies into pinned
+    staging, the asynchronous H2D transfers and the device voxel index -- running on loader threads with
+    their own streams while the consumer works on the current one: what the reference gets from DataLoader workers
     (data/__init__.py:28-47 building data/custom.py:196-256's ``collate_fn`` ahead of the test loop,
     tools/test.py:145).  ``batches`` yields lists of dataset items; ``collate`` defaults to collate_device.
-    The consumer's current stream is made to wait for the loader stream's work (an event per batch); tensors
-    are registered with the consumer's stream so the caching allocator does not hand them out early."""
+    ``workers`` loader threads take the batches round-robin (batch i on thread i % workers, each up to ``depth``
+    batches ahead) and the generator yields them IN ORDER: with scans in flight on a busy GPU one collate takes
+    longer than on an idle one (its voxel-index kernels and their read-back queue behind the scans' kernels), two
+    loaders hide that.  The consumer's current stream is made to wait for the loader stream's work (an event per
+    batch); tensors are registered with the consumer's stream so the caching allocator does not hand them out early."""
     import queue
     collate = collate or collate_device
     dev = torch.device(device)
-    q = queue.Queue(maxsize=max(1, int(depth)))
+    workers = max(1, int(workers))
     stop = threading.Event()
-    # the loader thread's pinned staging buffers outlive it (page-locking 11 MB costs tens of ms: a new set per
+    src_lock = threading.Lock()
+    src = iter(batches)
+    state = {'next': 0}
+    qs = [queue.Queue(maxsize=max(1, int(depth))) for _ in range(workers)]
+    # the loader threads' pinned staging buffers outlive them (page-locking 11 MB costs tens of ms: a new set per
     # generator made the first measurement of this path 32 ms per scan): taken from / returned to a module pool
+    stagings = []
     with _STAGING_POOL_LOCK:
-        staging = _STAGING_POOL.pop() if _STAGING_POOL else {}
+        for _ in range(workers):
+            stagings.append(_STAGING_POOL.pop() if _STAGING_POOL else {})
 
-    def loader():
-        _local.staging = staging
+    def loader(w):
+        _local.staging = stagings[w]
+        q = qs[w]
         try:
             with torch.cuda.device(dev):
                 side = torch.cuda.Stream()
                 with torch.cuda.stream(side), torch.no_grad():
-                    for items in batches:
-                        if stop.is_set():
+                    while not stop.is_set():
+                        # batch i belongs to thread i % workers: take from the source in order, under the lock
+                        with src_lock:
+                            if state['next'] % workers != w:
+                                mine = None
+                            else:
+                                try:
+                                    mine = next(src)
+                                except StopIteration:
+                                    mine = StopIteration
+                                state['next'] += 1
+                        if mine is None:
+                            time.sleep(0.0002)
+                            continue
+                        if mine is StopIteration:
                             break
-                        out = collate(items, device=device)
+                        out = collate(mine, device=device)
                         ev = torch.cuda.Event()
                         ev.record(side)
                         q.put((out, ev))
@@ -302,11 +344,13 @@ def prefetch_device(batches, collate=None, depth=1, device='cuda'):
         except BaseException as e:      # noqa: BLE001 -- handed to the consumer
             q.put(e)
 
-    t = threading.Thread(target=loader, name='sg-prefetch', daemon=True)
-    t.start()
+    threads = [threading.Thread(target=loader, args=(w, ), name=f'sg-prefetch-{w}', daemon=True) for w in range(workers)]
+    for t in threads:
+        t.start()
     try:
+        k = 0
         while True:
-            got = q.get()
+            got = qs[k % workers].get()
             if got is None:
                 return
             if isinstance(got, BaseException):
@@ -318,15 +362,20 @@ def prefetch_device(batches, collate=None, depth=1, device='cuda'):
                 if isinstance(v, torch.Tensor) and v.is_cuda:
                     v.record_stream(cur)
             yield out
+            k += 1
     finally:
         stop.set()
-        while t.is_alive():
-            try:
-                q.get_nowait()
-            except queue.Empty:
+        for t in threads:
+            while t.is_alive():
+                for q in qs:
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass
                 t.join(0.01)
-        for slot in staging.values():      # (copies out of the buffers have finished before they are reused)
-            if slot[1] is not None:
-                slot[1].synchronize()
+        for staging in stagings:      # (copies out of the buffers have finished before they are reused)
+            for slot in staging.values():
+                if slot[1] is not None:
+                    slot[1].synchronize()
         with _STAGING_POOL_LOCK:
-            _STAGING_POOL.append(staging)
+            _STAGING_POOL.extend(stagings)

@@ -112,7 +112,8 @@ def test_collate_x4_device_equals_the_reference_s3dis_test_collate():
         assert np.array_equal(got, ref), k
 
 
-def test_prefetch_device_hands_over_the_same_batches_and_results():
+@pytest.mark.parametrize('workers', [1, 2])
+def test_prefetch_device_hands_over_the_same_batches_and_results(workers):
     """data.prefetch_device: the next scan's collate on a loader thread / stream (the reference's DataLoader
     workers ahead of tools/test.py:145) -- every batch equal to collate_device's key by key, the scans' results
     equal to the ones computed from batches collated in line, an exception of the loader reaches the consumer"""
@@ -127,7 +128,7 @@ def test_prefetch_device_hands_over_the_same_batches_and_results():
         want = [collate_device([it]) for it in items]
         ref = [dict(model(b)) for b in want]
         got = []
-        for k, b in enumerate(prefetch_device([[it] for it in items])):
+        for k, b in enumerate(prefetch_device([[it] for it in items], workers=workers, depth=2)):
             for key, v in want[k].items():
                 if isinstance(v, torch.Tensor):
                     assert torch.equal(b[key], v), key
@@ -148,5 +149,5 @@ def test_prefetch_device_hands_over_the_same_batches_and_results():
         raise RuntimeError('loader failed')
 
     with pytest.raises(RuntimeError, match='loader failed'):
-        for _ in prefetch_device(broken()):
+        for _ in prefetch_device(broken(), workers=workers):
             pass
