@@ -460,7 +460,6 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
   res->semantic_prob = ar.at(prob);
   res->pt_offsets = ar.at(off);
   res->semantic_preds = ar.at(preds);
-  const size_t scratch0 = ar.off;
 
   // ---- 1. voxel feature pooling, backbone, point-wise heads, softmax
   static const int token_env = getenv("SG_SCAN_TOKEN") ? atoi(getenv("SG_SCAN_TOKEN")) : 0;
