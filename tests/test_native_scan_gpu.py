@@ -315,3 +315,54 @@ def test_softgroup_pp_grouping_in_c_equals_the_per_class_loop(points, scale):
         assert a['label_id'] == c['label_id'] and a['pred_mask'] == c['pred_mask']
         assert abs(float(a['conf']) - float(c['conf'])) <= 1e-6
     np.testing.assert_array_equal(out_c['semantic_preds'], out_py['semantic_preds'])
+
+
+@pytest.mark.parametrize('with_pyramid,with_octree,batch_size,lvl2', [(True, False, 1, False), (False, True, 1, False),
+                                                                       (True, True, 2, False), (True, False, 2, True)])
+def test_softgroup_pp_grouping_variants(with_pyramid, with_octree, batch_size, lvl2):
+    """the branches of sg_scan_grouping_pp the STPLS3D configuration does not take: pyramid levels with the hashed-grid
+    ball query, octree query without the pyramid, two scenes in a batch (the octree query ignores the batch index like
+    the reference's, functions.py:14-44), a class above 100 000 points (level 2) -- against the per-class operator loop
+    on synthetic scores, proposals and proposal voxels bit-identical"""
+    import copy
+    from softgroup_amd.model import native_scan as NS
+    rng = np.random.default_rng(7 + batch_size)
+    n_per = 130000 if lvl2 else 40000
+    parts, bidx = [], []
+    for b in range(batch_size):
+        xyz, _, _ = synthetic.scene_s2(seed=31 + b, n=n_per)
+        parts.append((xyz * np.float32(30)).astype(np.float32))
+        bidx.append(np.full(n_per, b, np.int32))
+    coords = torch.from_numpy(np.concatenate(parts)).cuda()
+    batch_idxs = torch.from_numpy(np.concatenate(bidx)).cuda()
+    N = coords.shape[0]
+    cfg = copy.deepcopy(synthetic.STPLS3D_PP_MODEL_CFG)
+    cfg['grouping_cfg'].update(with_pyramid=with_pyramid, with_octree=with_octree)
+    model = synthetic.build_model(cfg, seed=0)
+    n_cls = cfg['semantic_classes']
+    # scores: a few big classes (one takes level 2 when lvl2), the rest small or empty
+    logits = torch.full((N, n_cls), -8.0)
+    cls_of = torch.from_numpy(rng.choice([1, 2, 4, 7, 9], size=N, p=[0.86 if lvl2 else 0.5, 0.05 if lvl2 else 0.2, 0.04 if lvl2 else 0.15, 0.04 if lvl2 else 0.1, 0.01 if lvl2 else 0.05]))
+    logits[torch.arange(N), cls_of] = 4.0
+    logits += torch.from_numpy(rng.normal(0, 0.5, (N, n_cls)).astype(np.float32))
+    logits = logits.cuda()
+    offs = torch.from_numpy(rng.normal(0, 0.05, (N, 3)).astype(np.float32)).cuda()
+    feats = torch.from_numpy(rng.normal(0, 1, (N, 16)).astype(np.float32)).cuda()
+    g, v = model.grouping_cfg, model.instance_voxel_cfg
+    with torch.no_grad():
+        pidx, poff = model.forward_grouping(logits, offs, batch_idxs, coords, g, batch_size=batch_size)
+        assert poff.numel() - 1 >= 5
+        _, seg_thr, _, cls32 = model._grouping_constants(logits.device)
+        scores = logits.float().softmax(-1)
+        base = NS.GroupingCfg(n_points=N, n_sem_classes=n_cls, n_seg=cls32.numel(), seg_class=cls32.data_ptr(),
+                              seg_thr=seg_thr.data_ptr(), score_thr=g['score_thr'], min_npoint=model.test_cfg['min_npoint'],
+                              radius=g['radius'], batch_size=batch_size, voxel_scale=v['scale'],
+                              voxel_shape=v['spatial_shape'], feat_channels=16)
+        pp = NS.GroupingPPCfg(base=base, with_pyramid=int(with_pyramid), with_octree=int(with_octree), lvl_fusion=0,
+                              radius=float(g['radius']), base_size=float(g['pyramid_base_size']))
+        r = NS.grouping(pp, scores, offs, coords, batch_idxs, feats)
+        assert torch.equal(r['proposals_offset'], poff) and torch.equal(r['proposals_idx'], pidx)
+        inst_t, inst_map = model.clusters_voxelization(pidx, poff, feats, coords, **v)
+        assert torch.equal(r['voxel_coords'], inst_t.indices) and torch.equal(r['voxel_feats'], inst_t.features)
+    if lvl2:
+        assert int((cls_of == 1).sum()) > 100000      # the big class really took level 2
