@@ -67,6 +67,12 @@ inline int thin_levels_on() {
   const char *e = getenv("SG_BFS_THIN");
   return e ? atoi(e) : 0;
 }
+// SG_BFS_BIG_LOCAL=0 (developer knob, read per call): without the LOCAL form of the giant clusters' replay
+// (bfs_emit_big_local_kernel), which runs in front of bfs_emit_big_kernel by default
+inline bool big_local_on() {
+  const char *e = getenv("SG_BFS_BIG_LOCAL");
+  return !(e && atoi(e) == 0);
+}
 inline size_t big_stage_entries(int n) {
   return n > kBigClusterMin && big_fast_on() ? static_cast<size_t>(n) + static_cast<size_t>(kBigFastWgs) * kBigSlice : 0;
 }
@@ -915,7 +921,8 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
     const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
     const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
     int32_t *owner_g, int32_t *wcnt, int32_t *stage0, int32_t *stage1, u64 *srec0, u64 *srec1, int priv_base,
-    int32_t *cluster_idxs, int32_t *sync, bool flag_barrier, bool trace_on) {
+    int32_t *cluster_idxs, int32_t *sync, bool flag_barrier, bool trace_on, const int32_t *gate) {
+  if (gate != nullptr && *gate == 0) return;      // (the LOCAL form completed: nothing to redo)
   __shared__ int lds_scan[kEmitWaves];
   __shared__ int lds_flag, lds_off;
   __shared__ int node_off[kEmitThreads];
@@ -1327,6 +1334,453 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_kernel(
   }
 }
 
+// ---------------------------------------------------------------- D''. giant clusters, LOCAL form (round 6)
+// bfs_emit_big_kernel pays ~9.5 us per level: five dependent trips through the fabric -- wait for the G records,
+// fetch the staged records of a re-partitioned range, claim sweep, claim rendezvous, emit sweep + drain
+// (profiles/r06_bfs_big_phases.txt), ~2 us each.  The first two exist only because the frontier is re-partitioned
+// evenly EVERY level.  Here a workgroup keeps ITS OWN children: the frontier of level L+1 that workgroup w holds is
+// the winners of its level-L nodes in (node, position) order, i.e. a CONTIGUOUS piece of the queue order, and the
+// pieces follow each other in workgroup order (induction over the levels: children of an earlier piece come before
+// children of a later one).  So the claim key of an edge is (w, local node index, position) -- no global ranks, no
+// waiting for anybody's record, no remote fetch: a level is claim sweep | ONE grid rendezvous | emit sweep.
+//   * claims of level L go to owner[L & 1][t] (two arrays): a workgroup already claiming for level L+1 cannot disturb
+//     a slower one that still decides its level-L winners; a winner is marked visited (-1) in both.
+//   * filter: a bit per point in LDS for the targets this workgroup ever sent a claim to (visited one level later,
+//     whoever won): edges to them -- most edges of a dense cluster -- never leave the CU again.
+//   * balance: every `every`-th level (and the first `warm`) is a RE-PARTITION level, done like the old kernel's
+//     levels (records of all workgroups, even ranges over the global order, keys by global rank).  Measured on the
+//     kitti cluster, 16 workgroups: every = 2 / 4 / 8 / 16 -> 2.61 / 2.56 / 2.80 / 3.36 ms (the rendezvous waits
+//     1.97 / 2.45 / 3.12 / 4.61 us for the slowest workgroup); default 4.
+//   * the queue: a workgroup's winners of a level go to a region of ONE pool (atomicAdd on its head; the answer is
+//     first needed behind the next level's claim sweep); (offset, length) of every (level, workgroup) lands in a
+//     table, and when the cluster is complete every workgroup copies ITS regions to their places in the output, all
+//     entries at once (positions = prefix over the table in (level, workgroup) order).
+//   * termination: frontier totals per level in a 4-slot ring of counters, read behind the rendezvous.
+//   * limits: <= kLF frontier nodes per workgroup and level (kLE of its edges are cached between the sweeps, the
+//     rest worked out twice), <= tab_levels levels; beyond them (or a wait that times out) `fail` is set, everybody
+//     leaves, and bfs_emit_big_kernel replays the giant clusters (gated on that word).
+// Measured (profiles/r06_bfs_local.txt): the kitti scene's cluster (299 levels) 2.97 -> 2.55 ms, the stpls3d one
+// (423 levels) 3.07 -> 2.67 ms; per level 8.0 / 5.9 us = re-partition 0.8 / 0.7 (averaged over all levels), edge
+// bases + claim sweep 2.0 / 1.3, drain of the claims 0.7 / 0.5, rendezvous 2.4 / 2.0, emit sweep 1.4 / 0.9, totals +
+// publication 0.6 / 0.6.  What is left is the rendezvous (arrival skew between the workgroups, not the counter).
+constexpr int kLF = 2048;
+constexpr int kLE = 8192;
+constexpr int kVisWords = 16384;     // the workgroup's visited filter: one bit per point, up to 524 288 points
+constexpr int kLevSeg = 2048;        // levels whose output positions one pass of the final copy holds in LDS
+constexpr int kLocalLdsInts = 5 * kLF + 8 + kLE + kLE / 2;
+constexpr int kSweepU = 4;           // edges per thread whose loads are in flight together in the two sweeps
+
+__global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_local_kernel(
+    const int32_t *__restrict__ idx, const int4 *__restrict__ node_rec, const int2 *__restrict__ erec,
+    const int32_t *__restrict__ seeds, const int32_t *__restrict__ cluster_offsets, int n_cluster,
+    int32_t *owner0, int32_t *owner1, int32_t *pool_ids, unsigned long long *pool_rec, unsigned long long *tab,
+    int tab_levels, int32_t *cluster_idxs, int32_t *sync, int n, int every, int warm, bool trace_on) {
+  typedef unsigned long long u64;
+  __shared__ int lds_scan[kEmitWaves];
+  __shared__ int lds_flag;
+  __shared__ int pre[kBigWgsMax + 1], offs[kBigWgsMax];
+  __shared__ int lds_raw[kLocalLdsInts];
+  int (*f_st)[kLF] = reinterpret_cast<int (*)[kLF]>(lds_raw);                                            // [2][kLF]
+  unsigned short (*f_ln)[kLF] = reinterpret_cast<unsigned short (*)[kLF]>(lds_raw + 2 * kLF);            // [2][kLF]
+  int *f_eb = lds_raw + 3 * kLF;                  // [kLF + 1]
+  int *w_t = f_eb + kLF + 8;                      // [kLF] ids of the winners of the last emit (until they are in the pool)
+  int *c_t = w_t + kLF;                           // [kLE]
+  unsigned short *c_j = reinterpret_cast<unsigned short *>(c_t + kLE);                                    // [kLE]
+  // nodes this workgroup KNOWS to be visited (every target it ever sent a claim to is visited one level later):
+  // edges to them -- most edges of a dense cluster -- are dropped in the claim sweep without touching memory
+  __shared__ unsigned vis[kVisWords];
+  const bool use_vis = n <= kVisWords * 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int G = gridDim.x, b = blockIdx.x;
+  int32_t *bar = sync, *fail = sync + 1, *pool_head = sync + 2, *tot = sync + 4;
+  int epoch = 0;
+  unsigned tagc = 0;          // tag of the current level's table row, unique over the launch, never 0
+  // developer phase trace (SG_BFS_STATS; workgroup 0, thread 0; 100 MHz ticks): [0] re-partition (wait, ranks, records)
+  // [1] edge bases + claim sweep  [2] pool write + rendezvous  [3] emit sweep  [4] totals, pool region, publication
+  // [5] levels  [6] re-partition levels  [7] pool write + drain of the claims (then [2] is the rendezvous alone)
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  const bool tracing = trace_on && blockIdx.x == 0 && threadIdx.x == 0;
+  auto stamp = [&](int i) {
+    if (tracing) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      ph[i] += now - t_prev;
+      t_prev = now;
+    }
+  };
+  auto entry = [&](int L, int w) { return tab + (static_cast<size_t>(L) * G + w) * 2; };
+  auto publish = [&](int L, unsigned tag, int off, int len) {      // (thread 0, stores drained by the caller)
+    __hip_atomic_store(entry(L, b), (static_cast<u64>(tag) << 32) | static_cast<unsigned>(off), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(entry(L, b) + 1, (static_cast<u64>(tag) << 32) | static_cast<unsigned>(len), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto give_up = [&](int why) {                   // (why: 2 levels, 3 frontier at a re-partition, 5 winners of a level)
+    if (threadIdx.x == 0) __hip_atomic_store(fail, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int c = 0; c < n_cluster; ++c) {
+    const int off_c = cluster_offsets[c];
+    const int size = cluster_offsets[c + 1] - off_c;
+    if (size <= kBigMin) continue;                               // uniform over the grid
+    const int seed = seeds[c];
+    int32_t *Q = cluster_idxs + 2LL * off_c;
+    const unsigned tag0 = tagc;                                   // level L of this cluster has tag tag0 + L + 1
+    if (use_vis)
+      for (int i = threadIdx.x; i < kVisWords; i += kEmitThreads) vis[i] = 0u;
+    __syncthreads();
+    // ---- level 0: the seed -- first entry of the queue, row 0 of the level table (workgroup 0's piece)
+    // (measured and dropped: replaying the first, thin levels -- <= 4096 edges -- by workgroup 0 alone, claims in an
+    //  LDS hash table, visited bits in LDS, no rendezvous: 6.8-7.1 us per level, no faster than a level of all
+    //  workgroups, and only 12 / 58 of the 299 / 423 levels of the two benchmark clusters are that thin)
+    constexpr int T0 = 1;
+    if (threadIdx.x == 0) {
+      if (b == 0) {
+        const int4 r = node_rec[seed];
+        __hip_atomic_store(&pool_rec[0], pack_rec(r.z, r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SG_ST(&owner0[seed], -1);
+        SG_ST(&owner1[seed], -1);
+        Q[0] = c;
+        Q[1] = seed;
+        SG_ST(pool_head, 1);
+        SG_ST(&tot[0], 0);
+        SG_ST(&tot[1], 0);
+        SG_ST(&tot[2], 0);
+        SG_ST(&tot[3], 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish(0, tag0 + 1, 0, b == 0 ? 1 : 0);
+    }
+    int cur = 0, nf = 0, L = 0;
+    bool pending = false;          // my current frontier's ids / records are not in the pool yet
+    int pend_off = 0;              // (thread 0: the pool region of the pending piece, once the atomic has answered)
+    bool dead = false;
+    while (true) {
+      if (L >= tab_levels) { give_up(2); dead = true; break; }
+      const unsigned tag = tag0 + static_cast<unsigned>(L) + 1u;
+      const bool reb = L < warm || (L % every) == 0;
+      const bool next_reb = (L + 1) < warm || ((L + 1) % every) == 0;
+      int keybase;
+      if (tracing) t_prev = __builtin_amdgcn_s_memrealtime();
+      if (reb) {
+        // ---- re-partition: wait for the G entries of row L, ranks, my even range, its records from the pool
+        if (wave == 0) {
+          int ok = 1;
+          for (int w0 = 0; w0 < G; w0 += 64) {
+            const int w = w0 + lane;
+            u64 a = 0, l = 0;
+            unsigned spins = 0;
+            while (true) {
+              bool ready = true;
+              if (w < G) {
+                a = __hip_atomic_load(entry(L, w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l = __hip_atomic_load(entry(L, w) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = (a >> 32) == tag && (l >> 32) == tag;
+              }
+              if (__all(ready)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if ((++spins & 1023u) == 0u &&
+                  (spins > (1u << 24) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+              }
+            }
+            if (w < G) {
+              offs[w] = static_cast<int>(a & 0xffffffffu);
+              pre[w + 1] = static_cast<int>(l & 0xffffffffu);
+            }
+            if (!ok) break;
+          }
+          if (lane == 0) lds_flag = ok;
+        }
+        __syncthreads();
+        if (!lds_flag) return;
+        if (threadIdx.x == 0) {
+          pre[0] = 0;
+          for (int w = 0; w < G; ++w) pre[w + 1] += pre[w];
+        }
+        __syncthreads();
+        const int Ltot = pre[G];
+        if (Ltot == 0) break;                                      // cluster complete (uniform)
+        const int lo = static_cast<int>(static_cast<long long>(Ltot) * b / G);
+        const int hi = static_cast<int>(static_cast<long long>(Ltot) * (b + 1) / G);
+        nf = hi - lo;
+        if (nf > kLF) { give_up(3); dead = true; break; }
+        for (int i = threadIdx.x; i < nf; i += kEmitThreads) {
+          const int q = lo + i;
+          int w0 = 0, w1 = G;                                      // last w with pre[w] <= q
+          while (w1 - w0 > 1) {
+            const int mid = (w0 + w1) >> 1;
+            if (pre[mid] <= q) w0 = mid; else w1 = mid;
+          }
+          const u64 r = __hip_atomic_load(&pool_rec[offs[w0] + (q - pre[w0])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f_st[cur][i] = static_cast<int>(r & 0xffffffffu);
+          f_ln[cur][i] = static_cast<unsigned short>(r >> 32);
+        }
+        keybase = lo;
+        __syncthreads();
+      } else {
+        keybase = b << 13;          // (kLF <= 8192 nodes per workgroup: disjoint key ranges, in workgroup order)
+      }
+      stamp(0);
+      // ---- edge bases of my frontier
+      int E = 0;
+      {
+        int carry = 0;
+        for (int i0 = 0; i0 < nf; i0 += kEmitThreads) {
+          const int i = i0 + threadIdx.x;
+          const int ln = i < nf ? f_ln[cur][i] : 0;
+          int t;
+          const int ex = wg_excl_scan(ln, lds_scan, &t);
+          if (i < nf) f_eb[i] = carry + ex;
+          carry += t;
+        }
+        if (threadIdx.x == 0) f_eb[nf] = carry;
+        __syncthreads();
+        E = carry;
+      }
+      // (edges beyond the kLE the level cache holds are worked out again in the emit sweep)
+      int32_t *own = (L & 1) ? owner1 : owner0;
+      auto edge_node = [&](int e) {                                // last j with f_eb[j] <= e (lists may be empty)
+        int j0 = 0, j1 = nf;
+        while (j1 - j0 > 1) {
+          const int mid = (j0 + j1) >> 1;
+          if (f_eb[mid] <= e) j0 = mid; else j1 = mid;
+        }
+        return j0;
+      };
+      // ---- claim sweep (kSweepU edges per thread in flight: their loads go out together, one wait)
+      {
+        const bool direct = E <= kBigDirectDegree * nf;
+        // (measured and dropped: the kSweepU searches stepping together branch-free, one body per number of chunks --
+        //  claim sweep 2.3 against 2.0 us on the kitti cluster, 1.7 against 1.3 on the stpls3d one: the fixed trip
+        //  count and the selects cost more than the overlap of the LDS reads gives)
+        for (int e0 = threadIdx.x; e0 < E; e0 += kSweepU * kEmitThreads) {
+          int jn[kSweepU], key[kSweepU], ex[kSweepU], tg[kSweepU], ow[kSweepU];
+#pragma unroll
+          for (int u = 0; u < kSweepU; ++u) {
+            const int e = e0 + u * kEmitThreads;
+            jn[u] = 0; key[u] = 0; ex[u] = 0xffff; tg[u] = 0;
+            if (e < E) {
+              jn[u] = edge_node(e);
+              const int p = e - f_eb[jn[u]], g = f_st[cur][jn[u]] + p;
+              key[u] = ((keybase + jn[u]) << 10) | p;
+              ex[u] = erec[g].x;
+              tg[u] = idx[g];
+            }
+          }
+          bool mine_[kSweepU];
+#pragma unroll
+          for (int u = 0; u < kSweepU; ++u) {
+            mine_[u] = (ex[u] & 0xffff) != 0xffff;                 // else: target in another cluster (or no edge)
+            if (use_vis && mine_[u]) mine_[u] = ((vis[tg[u] >> 5] >> (tg[u] & 31)) & 1u) == 0u;
+          }
+          if (!direct && !use_vis) {
+#pragma unroll
+            for (int u = 0; u < kSweepU; ++u) ow[u] = mine_[u] ? SG_LD(&own[tg[u]]) : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < kSweepU; ++u) {
+            const int e = e0 + u * kEmitThreads;
+            const bool mine = mine_[u];
+            if (mine && (direct || use_vis || ow[u] > key[u])) atomicMin(&own[tg[u]], key[u]);
+            if (e < E && e < kLE) {
+              c_t[e] = mine ? tg[u] : -1;
+              c_j[e] = static_cast<unsigned short>(jn[u]);
+            }
+          }
+        }
+      }
+      stamp(1);
+      // ---- my current frontier (= the winners of my last emit) into the pool, if that was put off
+      if (pending) {
+        if (threadIdx.x == 0) lds_scan[0] = pend_off;             // (thread 0 holds the atomic's answer)
+        __syncthreads();
+        const int reg = lds_scan[0];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf; i += kEmitThreads) {
+          SG_ST(&pool_ids[reg + i], w_t[i]);
+          __hip_atomic_store(&pool_rec[reg + i], pack_rec(f_st[cur][i], f_ln[cur][i]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (b == 0 && threadIdx.x == 0) SG_ST(&tot[(L + 2) & 3], 0);      // (idle since level L - 2)
+      if (trace_on) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);
+      }
+      if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+      if (pending) {
+        if (threadIdx.x == 0) publish(L, tag, pend_off, nf);        // (its stores were drained by the rendezvous)
+        pending = false;
+      }
+      if (!reb) {
+        // frontier total of this level (added by everybody before the rendezvous): empty = cluster complete
+        if (threadIdx.x == 0) lds_scan[0] = SG_LD(&tot[L & 3]);
+        __syncthreads();
+        const int Ltot = lds_scan[0];
+        __syncthreads();
+        if (Ltot == 0) break;
+      }
+      stamp(2);
+      // ---- emit sweep: winners in edge order = (node, position) order -> my next frontier
+      int cnt = 0;
+      {
+        const int nxt = cur ^ 1;
+        bool over = false;
+        for (int e0 = 0; e0 < E; e0 += kSweepU * kEmitThreads) {
+          int t[kSweepU], key[kSweepU], ow[kSweepU];
+          int2 er[kSweepU];
+#pragma unroll
+          for (int u = 0; u < kSweepU; ++u) {
+            const int e = e0 + u * kEmitThreads + threadIdx.x;
+            t[u] = -1; key[u] = 0; ow[u] = -1; er[u] = make_int2(0, 0);
+            if (e < E) {
+              int jn;
+              if (e < kLE) {
+                t[u] = c_t[e];
+                jn = c_j[e];
+              } else {
+                jn = edge_node(e);
+              }
+              const int p = e - f_eb[jn], g = f_st[cur][jn] + p;
+              key[u] = ((keybase + jn) << 10) | p;
+              if (e >= kLE) {
+                er[u] = erec[g];
+                t[u] = (er[u].x & 0xffff) != 0xffff ? idx[g] : -1;
+              } else if (t[u] >= 0) {
+                er[u] = erec[g];
+              }
+              if (t[u] >= 0) {
+                ow[u] = SG_LD(&own[t[u]]);
+                if (use_vis) atomicOr(&vis[t[u] >> 5], 1u << (t[u] & 31));      // visited by the end of this level
+              }
+            }
+          }
+          // (ranks: one workgroup scan per chunk of 512 edges; a ballot table with one rendezvous for the
+          //  kSweepU chunks measured the same on fat levels and slower on thin ones)
+#pragma unroll
+          for (int u = 0; u < kSweepU; ++u) {
+            if (e0 + u * kEmitThreads >= E) break;                  // (uniform)
+            const bool win = t[u] >= 0 && ow[u] == key[u];
+            int tt;
+            const int ex = wg_excl_scan(win ? 1 : 0, lds_scan, &tt);
+            if (win) {
+              const int o = cnt + ex;
+              if (o < kLF) {
+                f_st[nxt][o] = er[u].y;
+                f_ln[nxt][o] = static_cast<unsigned short>(static_cast<unsigned>(er[u].x) >> 16);
+                w_t[o] = t[u];
+              }
+              SG_ST(&owner0[t[u]], -1);
+              SG_ST(&owner1[t[u]], -1);
+            }
+            cnt += tt;
+            over = over || cnt > kLF;
+          }
+        }
+        if (over) { give_up(5); dead = true; break; }
+      }
+      stamp(3);
+      // ---- totals and my pool region (the region's offset is first needed behind the next claim sweep, or now
+      //      if the next level re-partitions)
+      if (threadIdx.x == 0) {
+        if (cnt > 0) atomicAdd(&tot[(L + 1) & 3], cnt);
+        pend_off = cnt > 0 ? __hip_atomic_fetch_add(pool_head, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      }
+      cur ^= 1;
+      nf = cnt;
+      ++L;
+      pending = true;
+      if (next_reb) {
+        if (threadIdx.x == 0) lds_scan[0] = pend_off;
+        __syncthreads();
+        const int reg = lds_scan[0];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf; i += kEmitThreads) {
+          SG_ST(&pool_ids[reg + i], w_t[i]);
+          __hip_atomic_store(&pool_rec[reg + i], pack_rec(f_st[cur][i], f_ln[cur][i]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) publish(L, tag + 1u, reg, nf);
+        pending = false;
+      }
+      stamp(4);
+      ph[5] += 1;
+      ph[6] += reb ? 1 : 0;
+    }
+    if (dead) {                      // a limit was hit: everybody learns it at the next wait; leave now
+      return;
+    }
+    // ---- the cluster is complete: L levels (0 .. L-1) have entries.  (An entry put off at the last level was
+    //      published behind its rendezvous; `pending` pieces of an EMPTY frontier need nothing.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+    {
+      int *lv_dst = c_t;                               // [kLevSeg] output position of my piece of the level
+      int *lv_off = c_t + kLevSeg;                     // [kLevSeg] its pool region
+      int *lv_cum = reinterpret_cast<int *>(f_st);     // [kLevSeg + 1] my pieces' cumulative lengths (2 * kLF ints)
+      static_assert(2 * kLevSeg <= kLE && kLevSeg + 1 <= 2 * kLF, "the final copy's tables live in the level caches");
+      int base = T0;                                   // output entries before the segment (row 0 is in the queue already)
+      for (int l0 = 1; l0 < L; l0 += kLevSeg) {
+        const int nl = min(kLevSeg, L - l0);
+        // per level: row total, my prefix inside the row, my (offset, length)
+        int seg_carry = 0, cum_carry = 0;
+        for (int i0 = 0; i0 < nl; i0 += kEmitThreads) {
+          const int i = i0 + threadIdx.x;
+          int rowtot = 0, mypre = 0, myoff = 0, mylen = 0;
+          if (i < nl) {
+            for (int w = 0; w < G; ++w) {
+              const int len = static_cast<int>(__hip_atomic_load(entry(l0 + i, w) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffu);
+              if (w < b) mypre += len;
+              if (w == b) mylen = len;
+              rowtot += len;
+            }
+            myoff = static_cast<int>(__hip_atomic_load(entry(l0 + i, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffu);
+          }
+          int t1, t2;
+          const int ex1 = wg_excl_scan(rowtot, lds_scan, &t1);
+          const int ex2 = wg_excl_scan(mylen, lds_scan, &t2);
+          if (i < nl) {
+            lv_dst[i] = base + seg_carry + ex1 + mypre;
+            lv_off[i] = myoff;
+            lv_cum[i] = cum_carry + ex2;
+          }
+          seg_carry += t1;
+          cum_carry += t2;
+        }
+        if (threadIdx.x == 0) lv_cum[nl] = cum_carry;
+        __syncthreads();
+        // flat copy of my pieces: entry k of my concatenated pieces -> its level by binary search
+        for (int k = threadIdx.x; k < cum_carry; k += kEmitThreads) {
+          int j0 = 0, j1 = nl;                                     // last j with lv_cum[j] <= k
+          while (j1 - j0 > 1) {
+            const int mid = (j0 + j1) >> 1;
+            if (lv_cum[mid] <= k) j0 = mid; else j1 = mid;
+          }
+          const int r = k - lv_cum[j0];
+          const int id = SG_LD(&pool_ids[lv_off[j0] + r]);
+          Q[2LL * (lv_dst[j0] + r)] = c;
+          Q[2LL * (lv_dst[j0] + r) + 1] = id;
+        }
+        base += seg_carry;
+        __syncthreads();
+      }
+    }
+    tagc = tag0 + static_cast<unsigned>(L) + 2u;
+    if (b == 0 && threadIdx.x == 0) {                 // (developer counters, SG_BFS_STATS)
+      sync[8] += L;
+      sync[9] += 1;
+      if (tracing)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long *>(sync + 16)[i] = ph[i];
+    }
+    // the next cluster re-uses pool, table rows and counters: everybody is past its reads before anybody re-writes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!big_barrier(bar, epoch, fail, &lds_flag)) return;
+  }
+}
+
 // ---- the giant clusters' replay runs NEXT TO the per-cluster kernel, on a side stream of the caller's
 //      stream (the two touch disjoint clusters): one side stream and two events per (device, caller stream)
 struct BfsSide {
@@ -1532,17 +1986,41 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
     if (static_cast<size_t>(n) >= static_cast<size_t>(kBigSyncWords)) {
       hipMemsetAsync(sync, 0, kBigSyncWords * 4, stream);
       if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))      // test hook: pretend the barrier gave up
-        if (atoi(e)) hipMemsetAsync(sync + 1, 1, 1, stream);
+        if (atoi(e) & 1) hipMemsetAsync(sync + 1, 1, 1, stream);      // (bit 1: the LOCAL form's word, below)
       // frontier staging pools (one per level parity, at most a cluster's points each): the union-find
       // arrays of the labelling, idle by now
+      // LOCAL form first (SG_BFS_BIG_LOCAL, read per call): its own sync words behind the old kernel's; if it gives
+      // up (a level beyond its LDS limits, a wait that timed out) its fail word gates the old kernel in
+      const int32_t *gate = nullptr;
+      if (big_local_on() && big_fast_on() && w.big_stage[0] != nullptr &&
+          static_cast<size_t>(n) >= static_cast<size_t>(kBigSyncWords) + 96) {
+        const int lw_env = getenv("SG_BFS_BIG_LOCAL_WGS") ? atoi(getenv("SG_BFS_BIG_LOCAL_WGS")) : 16;   // developer knobs, read per call
+        const int lw = lw_env < 8 ? 8 : lw_env > kBigWgsMax ? kBigWgsMax : lw_env;
+        // a level re-partitions the frontier evenly when level % every == 0 (and during the first `warm` levels)
+        const int every_env = getenv("SG_BFS_BIG_LOCAL_EVERY") ? atoi(getenv("SG_BFS_BIG_LOCAL_EVERY")) : 4;
+        const int warm_env = getenv("SG_BFS_BIG_LOCAL_WARM") ? atoi(getenv("SG_BFS_BIG_LOCAL_WARM")) : 8;
+        const int every = every_env < 1 ? 1 : every_env, warm = warm_env < 1 ? 1 : warm_env;
+        int32_t *sync3 = sync + kBigSyncWords;
+        const size_t rows = big_stage_entries(n) / (2 * static_cast<size_t>(lw));
+        hipMemsetAsync(sync3, 0, 96 * 4, stream);
+        hipMemsetAsync(w.big_rec[1], 0, rows * 2 * lw * 8, stream);         // no stale tags in the level table
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.parent), 0x7fffffff, n, stream);    // second claim array
+        if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))
+          if (atoi(e) & 2) hipMemsetAsync(sync3 + 1, 1, 1, stream);      // test hook: the LOCAL form gave up
+        bfs_emit_big_local_kernel<<<lw, kEmitThreads, 0, stream>>>(
+            bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.parent, w.big_stage[0],
+            w.big_rec[0], w.big_rec[1], static_cast<int>(rows) - 1, cluster_idxs, sync3, n, every, warm, want_stats);
+        gate = sync3 + 1;
+        bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin, gate, w.owner);
+      }
       if (big_fast_on() && big_wgs <= kBigFastWgs && w.big_stage[0] != nullptr)
         bfs_emit_big_kernel<true><<<big_wgs, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.big_stage[0],
-            w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync, flags_on, want_stats);
+            w.big_stage[1], w.big_rec[0], w.big_rec[1], n, cluster_idxs, sync, flags_on, want_stats, gate);
       else
         bfs_emit_big_kernel<false><<<big_wgs, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.wcnt, w.parent, w.lab,
-            nullptr, nullptr, 0, cluster_idxs, sync, false, false);
+            nullptr, nullptr, 0, cluster_idxs, sync, false, false, gate);
       // sync[1] != 0: the replay gave up somewhere (see big_barrier) -- redo the giant clusters on
       // the per-cluster kernel (same output, slower); both launches are no-ops otherwise
       bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin,
@@ -1558,6 +2036,18 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
       set_error("sg_bfs_cluster_emit: joining the side stream failed");
       return SG_ERR_LAUNCH;
     }
+  }
+  if (want_stats && has_big && big_local_on()) {
+    hipStreamSynchronize(stream);
+    int32_t h[32];
+    hipMemcpy(h, w.asym_nodes + kBigSyncWords, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long lp[8];
+    hipMemcpy(lp, w.asym_nodes + kBigSyncWords + 16, sizeof(lp), hipMemcpyDeviceToHost);
+    const double lv = lp[5] ? static_cast<double>(lp[5]) : 1.0;
+    fprintf(stderr, "bfs giant clusters, local form: %s (%d); %d clusters, %d levels (%llu re-partition levels); us per level: "
+            "re-partition %.2f, edge bases+claim sweep %.2f, pool+drain %.2f, rendezvous %.2f, emit sweep %.2f, totals+publication %.2f\n",
+            h[1] ? "gave up" : "completed", h[1], h[9], h[8], lp[6], lp[0] / lv / 100.0, lp[1] / lv / 100.0, lp[7] / lv / 100.0,
+            lp[2] / lv / 100.0, lp[3] / lv / 100.0, lp[4] / lv / 100.0);
   }
   if (want_stats && has_big) {
     unsigned long long ph[6];

@@ -262,13 +262,27 @@ def test_bfs_cluster_bigger_than_the_lds_claim_array():
     finally:
         del os.environ['SG_BFS_FORCE_FALLBACK']
     assert np.array_equal(co2.cpu().numpy(), rco) and np.array_equal(ci2.cpu().numpy(), rci)
+    # the default replay is the LOCAL form (a workgroup keeps its own children, one rendezvous per level) in
+    # front of the round-5 form in front of the per-cluster kernel: without the LOCAL form, with the LOCAL
+    # form's fail word set up front (bit 1: the round-5 form redoes the clusters), and with both set
+    for local, fallback in (('0', None), ('1', '2'), ('1', '3')):
+        os.environ['SG_BFS_BIG_LOCAL'] = local
+        if fallback:
+            os.environ['SG_BFS_FORCE_FALLBACK'] = fallback
+        try:
+            ci3, co3 = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
+        finally:
+            del os.environ['SG_BFS_BIG_LOCAL']
+            os.environ.pop('SG_BFS_FORCE_FALLBACK', None)
+        assert np.array_equal(co3.cpu().numpy(), rco), (local, fallback)
+        assert np.array_equal(ci3.cpu().numpy(), rci), (local, fallback)
 
 
 def test_bfs_cluster_giant_with_fat_levels_both_replay_forms():
     """one 40 000-point slab whose BFS levels have 10^5..10^6 edges (a workgroup's share exceeds the
     cached level: the multi-workgroup replay takes its chunked path, frontier regions come out of the
     shared pool) and the thin sheet above (always the cached level, private slices): membership and BFS
-    order exact, in the default form of the replay and in the round-4 form (SG_BFS_BIG_FAST=0)."""
+    order exact, in the default form of the replay (LOCAL), the round-5 form and the round-4 form."""
     import os
     rng = np.random.default_rng(29)
     slab = rng.random((40000, 3)) * np.array([1.0, 1.0, 0.02])
@@ -283,12 +297,17 @@ def test_bfs_cluster_giant_with_fat_levels_both_replay_forms():
     mean = torch.tensor([-1.0])
     rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 50.0, 0)
     assert sorted(np.diff(rco).tolist()) == [22500, 40000]
-    for form in ('1', '0'):
-        os.environ['SG_BFS_BIG_FAST'] = form
+    for form in ({}, {'SG_BFS_BIG_LOCAL': '0'}, {'SG_BFS_BIG_FAST': '0'}, {'SG_BFS_BIG_LOCAL_WGS': '8'},
+                 {'SG_BFS_BIG_LOCAL_WGS': '64', 'SG_BFS_BIG_LOCAL_EVERY': '16'}):
+        # default: the LOCAL form (the slab's fat levels work out the edges beyond its level cache twice; where
+        # a workgroup's share of a frontier exceeds what it holds it gives up and the round-5 form redoes both
+        # clusters -- 8 workgroups); without it; the round-4 form; few / many workgroups, rare re-partitions
+        os.environ.update(form)
         try:
             ci, co = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
         finally:
-            del os.environ['SG_BFS_BIG_FAST']
+            for k in form:
+                del os.environ[k]
         assert np.array_equal(co.cpu().numpy(), rco), form
         assert np.array_equal(ci.cpu().numpy(), rci), form
 
