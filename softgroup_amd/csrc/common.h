@@ -165,6 +165,17 @@ int conv_gather_rows(const void *in, int num_in_rows, const int32_t *nbr, int M_
                      const float *act_scale, const float *act_shift, void *out_act, const int32_t *order,
                      const uint32_t *tile_mask, const int32_t *nbr_tiles, void *out, void *ws, size_t ws_bytes,
                      sg_stream_t stream, int in16, int out16, int res16);
+// sg_spconv_wgrad writing the parameter's layout [Cout][K][Cin] when out_oki (spconv_train.hip; the training tape)
+int spconv_wgrad_layout(const void *in, int in_bf16, const void *g_out, int g_bf16, const int32_t *nbr_t, int M_out,
+                        int K, int Cin, int Cout, float *dw, int out_oki, void *ws, size_t ws_bytes,
+                        sg_stream_t stream);
+// one launch for many sg_spconv_pack_weight calls (spconv_conv.hip; the training tape packs a step's weights twice)
+struct PackJob {
+  const float *w;
+  float *out;
+  int cout, kvol, cin, mode;
+};
+int spconv_pack_weights(const PackJob *jobs, int n, sg_stream_t stream);
 // octree ball query whose count pass parks short lists for the fill pass (octree.hip; sg_scan_grouping_pp)
 size_t octree_stash_bytes(int n);
 int octree_ballquery_count_stash(const float *points, const float *boxes, const int32_t *pt_inds,

@@ -1326,6 +1326,75 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float *__restric
   }
 }
 
+// many pack_weight calls in one launch (the training tape: every conv weight of the step, once for the forward
+// layout and once for the input gradients' -- 171 launches of ~5 us each before): the jobs travel as kernel arguments
+constexpr int kPackBatch = 64;
+struct PackBatchArgs {
+  const float *w[kPackBatch];
+  float *out[kPackBatch];
+  int cout[kPackBatch], K[kPackBatch], cin[kPackBatch], mode[kPackBatch];
+  int block0[kPackBatch + 1];      // first workgroup of every job
+  int n;
+};
+static_assert(sizeof(PackBatchArgs) <= 4096, "the batch travels as kernel arguments");
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackBatchArgs a) {
+  int j0 = 0, j1 = a.n;                                   // last job with block0 <= blockIdx.x
+  while (j1 - j0 > 1) {
+    const int mid = (j0 + j1) >> 1;
+    if (a.block0[mid] <= static_cast<int>(blockIdx.x)) j0 = mid; else j1 = mid;
+  }
+  const float *__restrict__ w = a.w[j0];
+  float *__restrict__ out = a.out[j0];
+  const int cout = a.cout[j0], K = a.K[j0], cin = a.cin[j0], src_kio = a.mode[j0];
+  const int c8 = (cin + 7) / 8;
+  const int64_t total = static_cast<int64_t>(K) * c8 * cout * 8;
+  const int64_t stride = static_cast<int64_t>(a.block0[j0 + 1] - a.block0[j0]) * 256;
+  for (int64_t t = (blockIdx.x - a.block0[j0]) * 256LL + threadIdx.x; t < total; t += stride) {
+    const int j = static_cast<int>(t & 7);
+    int64_t r = t >> 3;
+    const int co = static_cast<int>(r % cout);
+    r /= cout;
+    const int blk = static_cast<int>(r % c8), k = static_cast<int>(r / c8);
+    const int ci = blk * 8 + j;
+    float v = 0.f;
+    if (ci < cin) {
+      if (src_kio == 0) v = w[(static_cast<int64_t>(co) * K + k) * cin + ci];
+      else if (src_kio == 1) v = w[(static_cast<int64_t>(k) * cin + ci) * cout + co];
+      else v = w[(static_cast<int64_t>(ci) * K + (src_kio == 3 ? K - 1 - k : k)) * cout + co];
+    }
+    out[t] = v;
+    uint16_t *planes = reinterpret_cast<uint16_t *>(out + total);
+    const uint16_t h = bf16_rne(v);
+    const float rest = v - bf16_f32(h);
+    const uint16_t m = bf16_rne(rest);
+    const uint16_t l = bf16_rne(rest - bf16_f32(m));
+    planes[t] = h;
+    planes[total + t] = m;
+    planes[2 * total + t] = l;
+  }
+}
+
+int spconv_pack_weights(const PackJob *jobs, int n, sg_stream_t stream) {
+  for (int at = 0; at < n; at += kPackBatch) {
+    PackBatchArgs a;
+    a.n = n - at < kPackBatch ? n - at : kPackBatch;
+    a.block0[0] = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const PackJob &j = jobs[at + i];
+      if (j.cout <= 0 || j.kvol <= 0 || j.cin <= 0 || j.mode < 0 || j.mode > 3 || j.w == nullptr || j.out == nullptr) {
+        set_error("spconv_pack_weights: bad job %d", at + i);
+        return SG_ERR_ARG;
+      }
+      a.w[i] = j.w; a.out[i] = j.out; a.cout[i] = j.cout; a.K[i] = j.kvol; a.cin[i] = j.cin; a.mode[i] = j.mode;
+      const int64_t total = static_cast<int64_t>(j.kvol) * ((j.cin + 7) / 8) * j.cout * 8;
+      const int64_t blocks = (total + 255) / 256;
+      a.block0[i + 1] = a.block0[i] + static_cast<int>(blocks < 256 ? blocks : 256);
+    }
+    pack_weights_kernel<<<a.block0[a.n], 256, 0, as_stream(stream)>>>(a);
+  }
+  return check_launch("spconv_pack_weights");
+}
+
 template <int NBW>
 static void launch_tile(const ConvArgs &a, int grid, size_t lds, bool vec, hipStream_t stream) {
   if (vec)

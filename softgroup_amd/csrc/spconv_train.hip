@@ -303,6 +303,10 @@ struct RowVec<uint16_t, 2> {
 //      each wave owns whole supertiles (round-robin over the 4 waves x gridDim.z workgroups); with 1
 //      or 2 the compacted rows are split over 4 or 2 waves whose accumulators meet in LDS in a
 //      fixed order ((w0 + w1) + (w2 + w3)).
+#ifndef SG_WGRAD_DEPTH
+#define SG_WGRAD_DEPTH 2
+#endif
+constexpr int kWgDepth = SG_WGRAD_DEPTH;      // trips of 8 rows whose loads are in flight per wave
 template <typename TA, typename TG, int VI, int VO>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ in, const TG *__restrict__ g_out,
                                                         const int32_t *__restrict__ nbr_t, int M_out, int K,
@@ -395,21 +399,25 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
             acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][c], b[u][d], acc[c][d], 0, 0, 0);
     };
     {
-      float a0[4][VI], b0[4][VO], a1[4][VI], b1[4][VO];
+      // kWgDepth trips in the ring, the loads of kWgDepth - 1 of them in flight while one multiplies.  Depth 2
+      // (one trip ahead) is the default: depth 4 measured no faster on the single layers (66 / 125 / 165 us
+      // against 67 / 120 / 163 on levels 0-2, tools/train_conv_bench.py) and 53 against 49 us per call in the
+      // training step -- the kernel waits for the gathered rows' bytes (two 256-B rows per pair for 8 KFLOP),
+      // not for their latency
+      float a[kWgDepth][4][VI], b[kWgDepth][4][VO];
       int t = begin;
-      if (t < end) ld(t, a0, b0);
+#pragma unroll
+      for (int i = 0; i + 1 < kWgDepth; ++i) ld(t + 8 * i, a[i], b[i]);      // past the end: no access, zeros
       while (t < end) {
-        ld(t + 8, a1, b1);               // past the end: no access, zeros
-        __builtin_amdgcn_sched_barrier(0);
-        mm(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        t += 8;
-        if (t >= end) break;
-        ld(t + 8, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        t += 8;
+#pragma unroll
+        for (int i = 0; i < kWgDepth; ++i) {
+          ld(t + 8 * (kWgDepth - 1), a[(i + kWgDepth - 1) % kWgDepth], b[(i + kWgDepth - 1) % kWgDepth]);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(a[i], b[i]);
+          __builtin_amdgcn_sched_barrier(0);
+          t += 8;
+          if (t >= end) break;
+        }
       }
     }
     if (RS > 1) {            // uniform per workgroup: every wave runs exactly one supertile
@@ -463,8 +471,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
 
 // dw[o] = sum over chunks, in a fixed order: thread (o, q) adds the chunks c = q mod 4 in ascending
 // order (4 loads in flight), the four partial sums meet in LDS as (s0 + s1) + (s2 + s3)
+// (oki_cin > 0: dw is the PARAMETER's layout [Cout][K][Cin] instead of [K][Cin][Cout] -- the training tape's
+//  extra transposing launch per layer, 86 per step, folded in)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, int chunks,
-                                                          long long n, float *__restrict__ dw) {
+                                                          long long n, float *__restrict__ dw, int oki_k,
+                                                          int oki_cin, int oki_cout) {
   __shared__ float sh[4][64];
   const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const long long o = blockIdx.x * 64LL + l;
@@ -483,7 +494,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
   }
   sh[q][l] = a;
   __syncthreads();
-  if (q == 0 && o < n) dw[o] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+  if (q == 0 && o < n) {
+    long long at = o;
+    if (oki_cin > 0) {
+      const int co = static_cast<int>(o % oki_cout);
+      const long long r = o / oki_cout;
+      const int ci = static_cast<int>(r % oki_cin), k = static_cast<int>(r / oki_cin);
+      at = (static_cast<long long>(co) * oki_k + k) * oki_cin + ci;
+    }
+    dw[at] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+  }
 }
 
 // gather table [M][K] -> [K][M]: the weight gradient walks one offset's column at a time, and a
@@ -637,6 +657,17 @@ size_t sg_spconv_wgrad_workspace_bytes(int M_out, int K, int Cin, int Cout) {
 int sg_spconv_wgrad(const void *in, int in_bf16, const void *g_out, int g_bf16, const int32_t *nbr_t,
                     int M_out, int K, int Cin, int Cout, float *dw_kio, void *ws, size_t ws_bytes,
                     sg_stream_t stream_) {
+  return sg::spconv_wgrad_layout(in, in_bf16, g_out, g_bf16, nbr_t, M_out, K, Cin, Cout, dw_kio, 0, ws, ws_bytes,
+                                 stream_);
+}
+
+}  // extern "C"
+
+namespace sg {
+// out_oki != 0: the gradient lands in the parameter's layout [Cout][K][Cin]
+int spconv_wgrad_layout(const void *in, int in_bf16, const void *g_out, int g_bf16, const int32_t *nbr_t, int M_out,
+                        int K, int Cin, int Cout, float *dw_kio, int out_oki, void *ws, size_t ws_bytes,
+                        sg_stream_t stream_) {
   SG_REQUIRE(M_out >= 0 && K >= 1 && K <= kTMaxK && Cin >= 1 && Cout >= 1 && dw_kio,
              "sg_spconv_wgrad: bad arguments");
   hipStream_t stream = as_stream(stream_);
@@ -653,8 +684,8 @@ int sg_spconv_wgrad(const void *in, int in_bf16, const void *g_out, int g_bf16, 
   else if (in_bf16) launch_wgrad<uint16_t, float>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
   else if (g_bf16) launch_wgrad<float, uint16_t>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
   else launch_wgrad<float, float>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
-  wgrad_reduce_kernel<<<static_cast<int>((n + 63) / 64), 256, 0, stream>>>(partial, w.chunks, n, dw_kio);
+  wgrad_reduce_kernel<<<static_cast<int>((n + 63) / 64), 256, 0, stream>>>(partial, w.chunks, n, dw_kio, K,
+                                                                           out_oki ? Cin : 0, Cout);
   return check_launch("sg_spconv_wgrad");
 }
-
-}  // extern "C"
+}  // namespace sg

@@ -20,7 +20,10 @@
 //     nothing uses floating-point atomics: the step is bit-reproducible.
 // Arena need is computed exactly by a dry run of forward + backward once the level row counts are
 // known (the only host synchronisation of the step, inside the shared index build).
+#include <iterator>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -31,7 +34,9 @@ namespace sg {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-constexpr int kStatBlocksMax = 128;
+constexpr int kStatBlocksMax = 512;
+constexpr int kStatGroup = 16;          // workgroups whose partials one workgroup adds in the first stage
+constexpr int kStatCounters = 1 + kStatBlocksMax / kStatGroup;      // counters of one column_sums call
 
 __device__ __forceinline__ void st_agent(double *p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -41,10 +46,13 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 }
 
 // Column sums of two per-element quantities over [rows, c] (c % 4 == 0): thread (lane, g) walks rows
-// lane, lane + lanes, ... of its workgroup's row range for the channel group g (4 channels), fp64
-// accumulators; lanes meet in LDS in lane order; workgroup partials go to `partial`
-// [gridDim.x][c][2] with agent-scope stores; the last workgroup to arrive (counter) adds them in
-// workgroup order and calls `fin(channel, sum0, sum1)`.
+// lane, lane + lanes, ... of its workgroup's row range for the channel group g (4 channels), FOUR rows in
+// flight (their loads are independent; one row at a time the walk was a chain of memory round trips: 25-27 us
+// per call whatever the size, 4.2 ms of the 19 ms of a training step -- profiles/r06_train_profile.txt), fp64
+// accumulators; lanes meet in LDS in lane order; workgroup partials go to `partial` [gridDim.x][c][2] with
+// agent-scope stores; they meet in two stages (below): the last workgroup of every group of kStatGroup adds its
+// group's partials, the last group to finish adds the group sums and calls `fin(channel, sum0, sum1)`.  Every
+// order is fixed: the sums are bit-reproducible.
 template <typename Elem, typename Fin>
 __device__ __forceinline__ void column_sums(int64_t rows, int c, double *partial, unsigned *counter, Elem elem,
                                             Fin fin) {
@@ -59,8 +67,21 @@ __device__ __forceinline__ void column_sums(int64_t rows, int c, double *partial
     const int g = g0 + (c4 >= 256 ? tid : tid % c4);
     const int lane = c4 >= 256 ? 0 : tid / c4;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (lane < lanes && g < c4)
-      for (int64_t r = r0 + lane; r < r1; r += lanes) {
+    if (lane < lanes && g < c4) {
+      int64_t r = r0 + lane;
+      for (; r + 3 * lanes < r1; r += 4 * lanes) {
+        double a[4][4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) elem(r + u * lanes, g, a[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s[j] += a[u][j];
+            s[4 + j] += b[u][j];
+          }
+      }
+      for (; r < r1; r += lanes) {
         double a[4], b[4];
         elem(r, g, a, b);
 #pragma unroll
@@ -69,6 +90,7 @@ __device__ __forceinline__ void column_sums(int64_t rows, int c, double *partial
           s[4 + j] += b[j];
         }
       }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = s[j];
     __syncthreads();
@@ -86,20 +108,80 @@ __device__ __forceinline__ void column_sums(int64_t rows, int c, double *partial
     }
     __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's partial stores are out before the arrival below
+  __syncthreads();
+  // ---- two-stage meeting: the last workgroup of every group of kStatGroup adds its group's partials, the
+  //      last group to finish adds the group sums (one stage over ~500 partials was a 7-round chain of loads)
+  const int nb = static_cast<int>(gridDim.x);
+  const int ngroups = (nb + kStatGroup - 1) / kStatGroup;
+  const int grp = blockIdx.x / kStatGroup;
+  const int gfirst = grp * kStatGroup, gcount = min(kStatGroup, nb - gfirst);
+  double *gpartial = partial + static_cast<int64_t>(nb) * c * 2;      // [ngroups][c][2]
+  const int cc = c < 256 ? c : 256;             // channels per pass
+  const int nq = 256 / cc;                      // threads per channel
+  // rows [first, first + count) of src[.][c][2] summed per channel: thread (channel, q) the rows q, q + nq, ...
+  // in ascending order, eight loads in flight; the nq sums meet in LDS in q order
+  auto sum_rows = [&](const double *src, int first, int count, auto &&sink) {
+    for (int ch0 = 0; ch0 < c; ch0 += cc) {
+      const int ch = ch0 + tid % cc, q = tid / cc;
+      double s0 = 0, s1 = 0;
+      if (q < nq && ch < c) {
+        int i = q;
+        for (; i + 7 * nq < count; i += 8 * nq) {
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v0[u] = ld_agent(&src[(static_cast<int64_t>(first + i + u * nq) * c + ch) * 2 + 0]);
+            v1[u] = ld_agent(&src[(static_cast<int64_t>(first + i + u * nq) * c + ch) * 2 + 1]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s0 += v0[u];
+            s1 += v1[u];
+          }
+        }
+        for (; i < count; i += nq) {
+          s0 += ld_agent(&src[(static_cast<int64_t>(first + i) * c + ch) * 2 + 0]);
+          s1 += ld_agent(&src[(static_cast<int64_t>(first + i) * c + ch) * 2 + 1]);
+        }
+      }
+      sh[tid * 2] = s0;
+      sh[tid * 2 + 1] = s1;
+      __syncthreads();
+      if (q == 0 && ch < c) {
+        double t0 = 0, t1 = 0;
+        for (int k = 0; k < nq; ++k) {
+          t0 += sh[(k * cc + tid) * 2];
+          t1 += sh[(k * cc + tid) * 2 + 1];
+        }
+        sink(ch, t0, t1);
+      }
+      __syncthreads();
+    }
+  };
   if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = prev == gridDim.x - 1;
+    const unsigned prev = __hip_atomic_fetch_add(counter + 1 + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == static_cast<unsigned>(gcount - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  for (int ch = tid; ch < c; ch += 256) {
-    double s0 = 0, s1 = 0;
-    for (unsigned b = 0; b < gridDim.x; ++b) {
-      s0 += ld_agent(&partial[(static_cast<int64_t>(b) * c + ch) * 2 + 0]);
-      s1 += ld_agent(&partial[(static_cast<int64_t>(b) * c + ch) * 2 + 1]);
-    }
-    fin(ch, s0, s1);
+  if (ngroups == 1) {
+    sum_rows(partial, 0, nb, fin);
+    return;
   }
+  sum_rows(partial, gfirst, gcount, [&](int ch, double t0, double t1) {
+    st_agent(&gpartial[(static_cast<int64_t>(grp) * c + ch) * 2 + 0], t0);
+    st_agent(&gpartial[(static_cast<int64_t>(grp) * c + ch) * 2 + 1], t1);
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == static_cast<unsigned>(ngroups - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  sum_rows(gpartial, 0, ngroups, fin);
 }
 
 // BatchNorm1d, train() mode: batch mean / biased variance per channel; running statistics updated
@@ -234,18 +316,6 @@ __global__ void __launch_bounds__(256) add2_kernel(const float4 *__restrict__ a,
     out[t] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
   }
 }
-// weight gradient [K][Cin][Cout] (sg_spconv_wgrad) -> the parameter's layout [Cout][K][Cin]
-__global__ void __launch_bounds__(256) kio_to_oki_kernel(const float *__restrict__ kio, int K, int cin, int cout,
-                                                        float *__restrict__ oki) {
-  const int64_t total = static_cast<int64_t>(K) * cin * cout;
-  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += gridDim.x * 256LL) {
-    const int ci = static_cast<int>(t % cin);
-    const int64_t r = t / cin;
-    const int k = static_cast<int>(r % K), co = static_cast<int>(r / K);
-    oki[t] = kio[(static_cast<int64_t>(k) * cin + ci) * cout + co];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // tape
 // ---------------------------------------------------------------------------------------------
@@ -279,7 +349,7 @@ struct Tape {
   int counters_used = 0;
   int root = -1, result = -1;
 };
-constexpr int kCounters = 4096;
+constexpr int kCounters = 16384;
 
 struct TrainExec {
   Tape &tp;
@@ -326,9 +396,10 @@ struct TrainExec {
     *id = new_tensor(p, rows, c);
     return SG_OK;
   }
-  unsigned *next_counter() {
-    unsigned *c = tp.counters + (tp.counters_used % kCounters);
-    ++tp.counters_used;
+  unsigned *next_counter() {      // (kStatCounters words: the top counter and one per group of workgroups)
+    if (tp.counters_used + kStatCounters > kCounters) tp.counters_used = 0;
+    unsigned *c = tp.counters + tp.counters_used;
+    tp.counters_used += kStatCounters;
     return c;
   }
   static int stat_blocks(int64_t rows, int c) {
@@ -339,10 +410,68 @@ struct TrainExec {
     return static_cast<int>(b > kStatBlocksMax ? kStatBlocksMax : b);
   }
 
-  // ---- raw conv launch (forward convs and input gradients): packs `w` with `pack_mode` first
+  // ---- every conv weight of a pass packed by ONE launch per 64 (spconv_pack_weights): the forward walks the
+  //      descriptor, the backward the tape; conv_launch finds the packed copy by (weights, mode)
+  std::map<std::pair<const float *, int>, float *> packed;
+  std::vector<PackJob> jobs;
+  int pack_job(const float *w, int cout, int kvol, int cin, int mode) {
+    if (w == nullptr || packed.count({w, mode})) return SG_OK;
+    SG_TALLOC(wp, float, sg_spconv_packed_weight_elems(kvol, cin, cout));
+    packed[{w, mode}] = wp;
+    jobs.push_back(PackJob{w, wp, cout, kvol, cin, mode});
+    return SG_OK;
+  }
+  int pack_flush() {
+    int rc = SG_OK;
+    if (!dry && !jobs.empty()) rc = spconv_pack_weights(jobs.data(), static_cast<int>(jobs.size()), stream);
+    jobs.clear();
+    return rc;
+  }
+  int prepack_block(const sg_unet_train_block &b, int l) {
+    SG_TRY(pack_job(b.c1.w, b.cout, plan(l, PK_SUBM).kvol, b.cin, 0));
+    if (b.ci.w != nullptr) SG_TRY(pack_job(b.ci.w, b.cout, plan(l, PK_IDENT).kvol, b.cin, 0));
+    SG_TRY(pack_job(b.c2.w, b.cout, plan(l, PK_SUBM).kvol, b.cout, 0));
+    return SG_OK;
+  }
+  int prepack_forward(const sg_unet_train_desc *d) {
+    const int c0 = d->levels[0].planes;
+    if (d->input.w != nullptr) SG_TRY(pack_job(d->input.w, c0, plan(0, PK_SUBM).kvol, d->input_cin, 0));
+    for (int l = 0; l < d->n_levels; ++l) {
+      const sg_unet_train_level &L = d->levels[l];
+      for (int i = 0; i < L.n_blocks; ++i) SG_TRY(prepack_block(L.blocks[i], l));
+      if (l + 1 < d->n_levels) {
+        const int c = L.planes, c2 = d->levels[l + 1].planes;
+        SG_TRY(pack_job(L.down.w, c2, plan(l, PK_DOWN).kvol, c, 0));
+        SG_TRY(pack_job(L.up.w, c, plan(l, PK_UP).kvol, c2, 0));
+        for (int i = 0; i < L.n_blocks; ++i) SG_TRY(prepack_block(L.tail[i], l));
+      }
+    }
+    return pack_flush();
+  }
+  int prepack_backward() {
+    for (const Op &op : tp.ops) {
+      if (op.kind != Op::CONV || !tp.t[op.in].needs_grad) continue;
+      // (the transposed conv: this conv's Cout = the layer's Cin -- conv_launch's arguments in backward_op)
+      SG_TRY(pack_job(op.cv.w, op.cin, plan_t(op.level, op.plan_kind).kvol, op.cout, op.plan_kind == PK_SUBM ? 3 : 2));
+    }
+    return pack_flush();
+  }
+
+  // ---- raw conv launch (forward convs and input gradients): packs `w` with `pack_mode` first (unless prepacked)
   int conv_launch(const float *in, int in_rows, const Plan &p, int cin, int cout, const float *w_raw, int pack_mode,
                   const float *residual, float *out) {
-    SG_TALLOC(wp, float, sg_spconv_packed_weight_elems(p.kvol, cin, cout));
+    float *wp = nullptr;
+    const auto hit = packed.find({w_raw, pack_mode});
+    const bool prepacked = hit != packed.end();
+    if (prepacked) {
+      wp = hit->second;
+    } else {
+      wp = take<float>(sg_spconv_packed_weight_elems(p.kvol, cin, cout));
+      if (wp == nullptr) {
+        set_error("%s: arena too small (%zu bytes)", who, ar.cap);
+        return SG_ERR_WORKSPACE;
+      }
+    }
     const size_t m = ar.mark();
     const size_t nb = sg_spconv_conv_workspace_bytes(p.rows, cout);
     void *ws = nullptr;
@@ -355,7 +484,7 @@ struct TrainExec {
     }
     int rc = SG_OK;
     if (!dry && p.rows > 0) {
-      rc = sg_spconv_pack_weight(w_raw, cout, p.kvol, cin, pack_mode, wp, stream);
+      if (!prepacked) rc = sg_spconv_pack_weight(w_raw, cout, p.kvol, cin, pack_mode, wp, stream);
       if (rc == SG_OK)
         rc = sg_spconv_gather_conv_f32(in, in_rows, p.nbr, p.rows, p.kvol, cin, cout, wp, nullptr, nullptr, residual,
                                        nullptr, nullptr, nullptr, p.order, p.tile_mask, p.nbr_tiles, out, ws,
@@ -378,7 +507,7 @@ struct TrainExec {
     else SG_TRY(alloc_tensor(X.rows, X.c, &y));
     op.out = y;
     const int nb = stat_blocks(X.rows, X.c);
-    SG_TALLOC(partial, double, static_cast<size_t>(nb) * X.c * 2);
+    SG_TALLOC(partial, double, static_cast<size_t>(nb + (nb + kStatGroup - 1) / kStatGroup) * X.c * 2);
     if (!dry && X.rows > 0) {
       bn_stats_kernel<<<nb, 256, 0, hs()>>>(X.p, X.rows, X.c, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                             bn.momentum, bn.eps, partial, next_counter(), op.mean, op.invstd, scale,
@@ -458,6 +587,8 @@ struct TrainExec {
     const int c0 = d->levels[0].planes;
     int x = new_tensor(const_cast<float *>(feats), num_rows, d->input.w != nullptr ? d->input_cin : c0);
     tp.root = x;
+    packed.clear();
+    SG_TRY(prepack_forward(d));
     if (d->input.w != nullptr) SG_TRY(conv(x, 0, PK_SUBM, d->input, d->input_cin, c0, -1, &x));
     int y;
     SG_TRY(level(d, 0, x, &y));
@@ -501,7 +632,7 @@ struct TrainExec {
       if (!X.needs_grad && !want_params) return SG_OK;
       SG_TALLOC(coef, float, 3 * static_cast<size_t>(X.c));
       const int nb = stat_blocks(X.rows, X.c);
-      SG_TALLOC(partial, double, static_cast<size_t>(nb) * X.c * 2);
+      SG_TALLOC(partial, double, static_cast<size_t>(nb + (nb + kStatGroup - 1) / kStatGroup) * X.c * 2);
       if (!dry && X.rows > 0)
         bn_bwd_sums_kernel<<<nb, 256, 0, hs()>>>(O.g, O.p, X.p, X.rows, X.c, op.mean, op.invstd, op.bn.weight, partial,
                                                  next_counter(), op.bn.g_weight, op.bn.g_bias, coef);
@@ -534,15 +665,16 @@ struct TrainExec {
     const Plan &p = plan(op.level, op.plan_kind);
     if (op.cv.g_w != nullptr) {
       const size_t n = static_cast<size_t>(p.kvol) * op.cin * op.cout;
-      SG_TALLOC(dw, float, n);
       const size_t m = ar.mark();
       const size_t nb = sg_spconv_wgrad_workspace_bytes(p.rows, p.kvol, op.cin, op.cout);
       SG_TALLOC(ws, char, nb);
       if (!dry) {
-        SG_TRY(sg_spconv_wgrad(X.p, 0, O.g, 0, tp.nbr_t[op.level][op.plan_kind], p.rows, p.kvol, op.cin, op.cout, dw,
-                               ws, nb, stream));
-        kio_to_oki_kernel<<<grid_for(static_cast<int64_t>(n), 256), 256, 0, hs()>>>(dw, p.kvol, op.cin, op.cout,
-                                                                                    op.cv.g_w);
+        if (p.rows > 0) {      // (the reduction writes the parameter's layout [Cout][K][Cin])
+          SG_TRY(spconv_wgrad_layout(X.p, 0, O.g, 0, tp.nbr_t[op.level][op.plan_kind], p.rows, p.kvol, op.cin, op.cout,
+                                     op.cv.g_w, 1, ws, nb, stream));
+        } else if (hipMemsetAsync(op.cv.g_w, 0, n * 4, hs()) != hipSuccess) {
+          return check_launch(who);
+        }
       }
       ar.release(m);
     }
@@ -561,6 +693,8 @@ struct TrainExec {
     // (dry run: any non-null address, so that aliasing and chaining are counted as they will happen)
     if (dry && g_out == nullptr) g_out = reinterpret_cast<const float *>(tp.arena);
     tp.t[tp.result].g = const_cast<float *>(g_out);
+    for (auto it = packed.begin(); it != packed.end();) it = it->first.second >= 2 ? packed.erase(it) : std::next(it);
+    SG_TRY(prepack_backward());
     for (size_t i = tp.ops.size(); i-- > 0;) SG_TRY(backward_op(tp.ops[i]));
     if (g_feats != nullptr && !dry) {
       const Tensor &R = tp.t[tp.root];

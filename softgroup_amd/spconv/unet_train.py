@@ -290,4 +290,7 @@ class _UNetTrainFn(torch.autograd.Function):
                                         L.stream())
         tape.done()
         L.check(rc, 'sg_unet_train_backward')
-        return (g_feats, None, None, None) + tuple(ctx.grads)
+        # hand the slices over without keeping a reference: AccumulateGrad then takes each as the parameter's
+        # .grad as it is; with the node still holding them it cloned every one (246 copies per step)
+        grads, ctx.grads = ctx.grads, None
+        return (g_feats, None, None, None) + tuple(grads)
