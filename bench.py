@@ -943,6 +943,14 @@ def main():
         for _ in range(2):
             for r in [model(batches[i % n_scenes]) for i in range(contexts)]:
                 r.resolve()
+        # ... and the pinned staging blocks of the results (12 MB each, torch's caching host allocator hands them
+        # out): as many as can be alive at once in the region -- the scans in flight plus finished results the
+        # consumer has not released yet -- exist before it.  A page-locking allocation inside the region stalls the
+        # streams for milliseconds, and a 20-step region saw 2-3 of them (profiles/r06_driver_shape.txt)
+        held = [model(batches[i % n_scenes]) for i in range(2 * contexts + 4)]
+        for r in held:
+            r.resolve()
+        del held, r
         # the digest of every result is computed and compared by the consumer inside the timed region
         # (SG_BENCH_DIGEST=worker: the digest computed by the scan worker through model.scan_result_hook instead
         # of by the consumer -- measured within the run-to-run noise of the consumer-side check at 20 steps and

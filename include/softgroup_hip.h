@@ -66,6 +66,10 @@ int sg_stream_release(sg_stream_t stream);
  * next pool instead of destroying it; sg_stream_destroy is for hosts without such an allocator. */
 int sg_stream_create(sg_stream_t *stream_out);
 int sg_stream_destroy(sg_stream_t stream);
+/* The same with a dispatch priority: level > 0 the device's highest, 0 its default, < 0 its lowest
+ * (hipStreamCreateWithPriority over hipDeviceGetStreamPriorityRange).  For scan workers whose scans should not
+ * all advance in lockstep: the scan on the high-priority stream finishes at its stand-alone latency. */
+int sg_stream_create_priority(sg_stream_t *stream_out, int level);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelisation index build.  Replaces `voxelize_idx` (softgroup_api.cpp:12,

@@ -24,6 +24,7 @@ SIGNATURES = {
     'sg_host_cast_f64_f32': (_i, [_vp, _vp, _i64]),
     'sg_host_fill_i64_strided': (_i, [_vp, _i64, _i64, _i64]),
     'sg_stream_create': (_i, [_vp]),
+    'sg_stream_create_priority': (_i, [_vp, _i]),
     'sg_stream_destroy': (_i, [_vp]),
     'sg_voxelize_idx_host': (_i, [_vp, _i, _i, _i, _vp, _pi32, _pi32]),
     'sg_voxelize_idx_fill_host': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

@@ -94,6 +94,23 @@ int sg_stream_create(sg_stream_t *stream_out) {
   return SG_OK;
 }
 
+int sg_stream_create_priority(sg_stream_t *stream_out, int level) {
+  SG_REQUIRE(stream_out != nullptr, "sg_stream_create_priority: null argument");
+  int least = 0, greatest = 0;      // (numerically: greatest priority = the smaller number)
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+    sg::set_error("sg_stream_create_priority: hipDeviceGetStreamPriorityRange failed");
+    return SG_ERR_LAUNCH;
+  }
+  const int prio = level > 0 ? greatest : level < 0 ? least : (least + greatest) / 2;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) {
+    sg::set_error("sg_stream_create_priority: hipStreamCreateWithPriority failed");
+    return SG_ERR_LAUNCH;
+  }
+  *stream_out = reinterpret_cast<sg_stream_t>(s);
+  return SG_OK;
+}
+
 int sg_stream_destroy(sg_stream_t stream) {
   SG_REQUIRE(stream != nullptr, "sg_stream_destroy: the null stream is not the library's");
   hipStream_t s = sg::as_stream(stream);

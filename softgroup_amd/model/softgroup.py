@@ -45,6 +45,10 @@ _scan_local = threading.local()      # per worker thread: its HIP stream
 _EARLY_COPY = os.environ.get('SG_EARLY_COPY', '1') != '0'      # (developer A/B knob)
 _POOL_LOCK = threading.Lock()        # creation / retirement of a model's scan pool
 _PARKED_STREAMS = {}                 # device -> library-owned worker streams of retired pools, for the next pool
+# SG_SCAN_PRIO (developer knob): dispatch priority of the scan workers' streams in creation order, one letter
+# each -- h(igh) / n(ormal) / l(ow), e.g. "hnnll"; unset: all default
+_SCAN_PRIO = [{'h': 1, 'n': 0, 'l': -1}[c] for c in os.environ.get('SG_SCAN_PRIO', '') if c in 'hnl']
+
 
 
 def _retire_pool(pool, wait=True):
@@ -248,7 +252,12 @@ class SoftGroup(nn.Module):
                     if st is None:
                         from .. import _lib as L_
                         raw = ctypes.c_void_p(0)
-                        L_.check(L_.lib().sg_stream_create(ctypes.byref(raw)), 'sg_stream_create')
+                        prio = _SCAN_PRIO[min(len(my_pool._sg_streams), len(_SCAN_PRIO) - 1)] if _SCAN_PRIO else None
+                        if prio is None:
+                            L_.check(L_.lib().sg_stream_create(ctypes.byref(raw)), 'sg_stream_create')
+                        else:
+                            L_.check(L_.lib().sg_stream_create_priority(ctypes.byref(raw), prio),
+                                     'sg_stream_create_priority')
                         st = torch.cuda.ExternalStream(raw.value, device=dev)
                     local.stream = st
                     my_pool._sg_streams.append((dev, st))      # state released, stream parked when the pool is retired
