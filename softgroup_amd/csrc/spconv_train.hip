@@ -310,15 +310,39 @@ constexpr int kWgDepth = SG_WGRAD_DEPTH;      // trips of 8 rows whose loads are
 template <typename TA, typename TG, int VI, int VO>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ in, const TG *__restrict__ g_out,
                                                         const int32_t *__restrict__ nbr_t, int M_out, int K,
-                                                        int Cin, int Cout, int chunk_rows,
+                                                        int Cin, int Cout, int chunk_rows, int csplit,
                                                         float *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) int32_t wg_lds[];
   int32_t *row_c = wg_lds, *src_c = wg_lds + chunk_rows;
   float *red = reinterpret_cast<float *>(wg_lds + 2 * chunk_rows);    // [2][VI*VO*16][64]
   __shared__ int wcount[4];
-  const int k = blockIdx.y;
-  const int r0 = blockIdx.x * chunk_rows;
-  const int nrows = min(chunk_rows, M_out - r0);
+#ifdef SG_WGRAD_OFFSET_MAJOR      // (A/B build, measured no faster: 72 / 135 / 166 us against 66 / 125 / 165 on levels 0-2 --
+  const int k = blockIdx.x, vchunk = blockIdx.y;      //  the offsets of one row chunk as consecutive workgroups)
+#else
+  // the centre offset first: every row has that neighbour (itself), the other 26 offsets ~1 in 7 at 2 cm voxels, so
+  // its workgroups carry 3-7 times the pairs of the others and should not be the last to start
+  const int k = (static_cast<int>(blockIdx.y) + (K >> 1)) % K, vchunk = blockIdx.x;
+#endif
+  // ... and its chunks are cut into `csplit` pieces, one workgroup each (the other offsets: one workgroup per
+  // chunk, the pieces' other workgroups leave at once): a centre workgroup with all of a chunk's rows was the
+  // longest chain of the launch
+  // (the other offsets' workgroups are the FIRST gridDim / csplit of their row of the grid: consecutive workgroups go
+  //  round the XCDs, every csplit-th one would have put all of them on 8 / csplit of the 8)
+  const bool centre = csplit > 1 && k == (K >> 1);
+#ifdef SG_WGRAD_OFFSET_MAJOR
+  const int n_chunks = gridDim.y / csplit;
+#else
+  const int n_chunks = gridDim.x / csplit;
+#endif
+  if (!centre && vchunk >= n_chunks) return;
+  const int chunk = centre ? vchunk / csplit : vchunk, sub = centre ? vchunk % csplit : 0;
+  int r0 = chunk * chunk_rows;
+  int nrows = min(chunk_rows, M_out - r0);
+  if (centre) {
+    const int piece = (chunk_rows + csplit - 1) / csplit;
+    nrows = max(0, min(piece, nrows - sub * piece));
+    r0 += sub * piece;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // every thread's (<= 8) gather-table words are requested before the first one is used
   constexpr int kMaxPer = 8;           // chunk_rows <= 2048
@@ -351,7 +375,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
     total += all;
     __syncthreads();
   }
-  float *dst = partial + (static_cast<long long>(blockIdx.x) * K + k) * Cin * Cout;
+  float *dst = partial + (static_cast<long long>(vchunk) * K + k) * Cin * Cout;
   if (total == 0) {
     for (int t = threadIdx.x; t < Cin * Cout; t += 256) dst[t] = 0.f;
     return;
@@ -475,22 +499,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
 //  extra transposing launch per layer, 86 per step, folded in)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ partial, int chunks,
                                                           long long n, float *__restrict__ dw, int oki_k,
-                                                          int oki_cin, int oki_cout) {
+                                                          int oki_cin, int oki_cout, int csplit, int cico) {
   __shared__ float sh[4][64];
   const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const long long o = blockIdx.x * 64LL + l;
   float a = 0.f;
   if (o < n) {
+    // (partial holds chunks * csplit slots per offset: the centre offset fills all of them, the others the first `chunks`)
+    const bool centre = csplit > 1 && static_cast<int>(o / cico) == (oki_k >> 1);
+    const int cnt = centre ? chunks * csplit : chunks;
+    const long long step = n;
     int c = q;
-    for (; c + 12 < chunks; c += 16) {
-      const float v0 = partial[c * n + o], v1 = partial[(c + 4) * n + o];
-      const float v2 = partial[(c + 8) * n + o], v3 = partial[(c + 12) * n + o];
+    for (; c + 12 < cnt; c += 16) {
+      const float v0 = partial[c * step + o], v1 = partial[(c + 4) * step + o];
+      const float v2 = partial[(c + 8) * step + o], v3 = partial[(c + 12) * step + o];
       a += v0;
       a += v1;
       a += v2;
       a += v3;
     }
-    for (; c < chunks; c += 4) a += partial[c * n + o];
+    for (; c < cnt; c += 4) a += partial[c * step + o];
   }
   sh[q][l] = a;
   __syncthreads();
@@ -521,8 +549,11 @@ __global__ void __launch_bounds__(256) transpose_table_kernel(const int32_t *__r
 }
 
 struct WgradShape {
-  int vi, vo, nst, zs, rows, chunks;
+  int vi, vo, nst, zs, rows, chunks, csplit;
 };
+#ifndef SG_WGRAD_CSPLIT
+#define SG_WGRAD_CSPLIT 4
+#endif
 // one decomposition for the workspace query and the launch: ~1024 workgroups
 static WgradShape wgrad_shape(int M_out, int K, int Cin, int Cout) {
   WgradShape w;
@@ -540,21 +571,26 @@ static WgradShape wgrad_shape(int M_out, int K, int Cin, int Cout) {
   if (r > 2048) r = 2048;
   w.rows = r;
   w.chunks = (M_out + r - 1) / r;
+  w.csplit = (K == 27 && r >= 64 * SG_WGRAD_CSPLIT) ? SG_WGRAD_CSPLIT : 1;      // (SubM: the centre offset is every row)
   return w;
 }
 
 template <typename TA, typename TG>
 static void launch_wgrad(const void *in, const void *g, const int32_t *nbr, int M_out, int K, int Cin,
                          int Cout, const WgradShape &w, float *partial, hipStream_t stream) {
-  const dim3 grid(w.chunks, K, w.zs);
+#ifdef SG_WGRAD_OFFSET_MAJOR
+  const dim3 grid(K, w.chunks * w.csplit, w.zs);
+#else
+  const dim3 grid(w.chunks * w.csplit, K, w.zs);
+#endif
   const size_t lds = static_cast<size_t>(w.rows) * 8 + (w.nst < 3 ? 2u * w.vi * w.vo * 16 * 64 * 4 : 0u);
   const TA *a = static_cast<const TA *>(in);
   const TG *b = static_cast<const TG *>(g);
   const int rows = w.rows;
-  if (w.vi == 2 && w.vo == 2) conv_wgrad_kernel<TA, TG, 2, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
-  else if (w.vi == 2) conv_wgrad_kernel<TA, TG, 2, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
-  else if (w.vo == 2) conv_wgrad_kernel<TA, TG, 1, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
-  else conv_wgrad_kernel<TA, TG, 1, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, partial);
+  if (w.vi == 2 && w.vo == 2) conv_wgrad_kernel<TA, TG, 2, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, w.csplit, partial);
+  else if (w.vi == 2) conv_wgrad_kernel<TA, TG, 2, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, w.csplit, partial);
+  else if (w.vo == 2) conv_wgrad_kernel<TA, TG, 1, 2><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, w.csplit, partial);
+  else conv_wgrad_kernel<TA, TG, 1, 1><<<grid, 256, lds, stream>>>(a, b, nbr, M_out, K, Cin, Cout, rows, w.csplit, partial);
 }
 
 }  // namespace sg
@@ -649,7 +685,7 @@ int sg_spconv_transpose_table(const int32_t *nbr, int M, int K, int32_t *nbr_t, 
 size_t sg_spconv_wgrad_workspace_bytes(int M_out, int K, int Cin, int Cout) {
   if (M_out <= 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 256;
   const WgradShape w = wgrad_shape(M_out, K, Cin, Cout);
-  return static_cast<size_t>(w.chunks) * K * Cin * Cout * sizeof(float) + 256;
+  return static_cast<size_t>(w.chunks) * w.csplit * K * Cin * Cout * sizeof(float) + 256;
 }
 
 // dw_kio [K][Cin][Cout] fp32 is overwritten.  `in` is the input the forward conv gathered from
@@ -685,7 +721,7 @@ int spconv_wgrad_layout(const void *in, int in_bf16, const void *g_out, int g_bf
   else if (g_bf16) launch_wgrad<float, uint16_t>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
   else launch_wgrad<float, float>(in, g_out, nbr_t, M_out, K, Cin, Cout, w, partial, stream);
   wgrad_reduce_kernel<<<static_cast<int>((n + 63) / 64), 256, 0, stream>>>(partial, w.chunks, n, dw_kio, K,
-                                                                           out_oki ? Cin : 0, Cout);
+                                                                           out_oki ? Cin : 0, Cout, w.csplit, Cin * Cout);
   return check_launch("sg_spconv_wgrad");
 }
 }  // namespace sg
