@@ -2000,6 +2000,8 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
         const int every_env = getenv("SG_BFS_BIG_LOCAL_EVERY") ? atoi(getenv("SG_BFS_BIG_LOCAL_EVERY")) : 4;
         const int warm_env = getenv("SG_BFS_BIG_LOCAL_WARM") ? atoi(getenv("SG_BFS_BIG_LOCAL_WARM")) : 8;
         const int every = every_env < 1 ? 1 : every_env, warm = warm_env < 1 ? 1 : warm_env;
+        // (test hook: the path of scenes above 524 288 points, whose visited filter does not fit the LDS)
+        const bool novis = getenv("SG_BFS_BIG_LOCAL_NOVIS") && atoi(getenv("SG_BFS_BIG_LOCAL_NOVIS")) != 0;
         int32_t *sync3 = sync + kBigSyncWords;
         const size_t rows = big_stage_entries(n) / (2 * static_cast<size_t>(lw));
         hipMemsetAsync(sync3, 0, 96 * 4, stream);
@@ -2009,7 +2011,8 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
           if (atoi(e) & 2) hipMemsetAsync(sync3 + 1, 1, 1, stream);      // test hook: the LOCAL form gave up
         bfs_emit_big_local_kernel<<<lw, kEmitThreads, 0, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.parent, w.big_stage[0],
-            w.big_rec[0], w.big_rec[1], static_cast<int>(rows) - 1, cluster_idxs, sync3, n, every, warm, want_stats);
+            w.big_rec[0], w.big_rec[1], static_cast<int>(rows) - 1, cluster_idxs, sync3, novis ? 0x7fffffff : n, every, warm,
+            want_stats);
         gate = sync3 + 1;
         bfs_owner_reset_kernel<<<grid_for(n, 256, 1024), 256, 0, stream>>>(n, w.label, w.size, kBigMin, gate, w.owner);
       }

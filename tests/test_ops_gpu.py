@@ -298,10 +298,12 @@ def test_bfs_cluster_giant_with_fat_levels_both_replay_forms():
     rci, rco = oracle.bfs_cluster(mean.numpy(), idx.cpu().numpy(), sl.cpu().numpy(), 50.0, 0)
     assert sorted(np.diff(rco).tolist()) == [22500, 40000]
     for form in ({}, {'SG_BFS_BIG_LOCAL': '0'}, {'SG_BFS_BIG_FAST': '0'}, {'SG_BFS_BIG_LOCAL_WGS': '8'},
-                 {'SG_BFS_BIG_LOCAL_WGS': '64', 'SG_BFS_BIG_LOCAL_EVERY': '16'}):
+                 {'SG_BFS_BIG_LOCAL_WGS': '64', 'SG_BFS_BIG_LOCAL_EVERY': '16'}, {'SG_BFS_BIG_LOCAL_NOVIS': '1'},
+                 {'SG_BFS_BIG_LOCAL_EVERY': '1', 'SG_BFS_BIG_LOCAL_WGS': '24'}):
         # default: the LOCAL form (the slab's fat levels work out the edges beyond its level cache twice; where
         # a workgroup's share of a frontier exceeds what it holds it gives up and the round-5 form redoes both
-        # clusters -- 8 workgroups); without it; the round-4 form; few / many workgroups, rare re-partitions
+        # clusters -- 8 workgroups); without it; the round-4 form; few / many workgroups, rare re-partitions;
+        # without the LDS visited filter (the path of scenes above 524 288 points); re-partition at every level
         os.environ.update(form)
         try:
             ci, co = ops.bfs_cluster(mean, idx, sl, 50.0, 0)
