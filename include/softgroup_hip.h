@@ -689,6 +689,8 @@ typedef struct sg_grouping_result {   /* host */
   size_t voxel_feats;        /* float [n_voxels, C] */
   size_t point_to_voxel;     /* int32 [sum_npoint] */
   size_t arena_used, arena_needed;
+  int deferred_classes;      /* sg_scan_grouping_pp: classes whose tail ran behind their giant clusters' replay (0 | 1) */
+  int reserved_;
 } sg_grouping_result;
 /* scores f32 [N, n_sem_classes] = softmax of the semantic logits; pt_offsets, coords_float f32 [N,3];
  * batch_idxs int32 [N]; point_feats f32 [N, C] = backbone features per point. */
@@ -705,7 +707,10 @@ int sg_scan_grouping(const sg_grouping_cfg *cfg, const float *scores, const floa
  * proposal voxelisation as sg_scan_grouping.  base.radius is ignored: `radius` and `base_size` are the
  * configuration's Python floats (the level's radius and voxel size are their double products rounded once,
  * as the reference's Python computes them).  Same results as the per-class loop over the operator surface,
- * bit for bit.  2 + 4 host read-backs per grouped class (voxel count, neighbour total, cluster count, rows). */
+ * bit for bit.  2 + 4 host read-backs per grouped class (voxel count, neighbour total, cluster count, rows).
+ * A class with a cluster above 16 384 points (its ordered emission is a multi-workgroup replay of milliseconds
+ * on a side stream) does not hold up the classes behind it: the rest of that class is queued behind the replay,
+ * the next classes run next to it, one join before the proposals are voxelised (result->deferred_classes). */
 typedef struct sg_grouping_pp_cfg {
   sg_grouping_cfg base;
   int with_pyramid, with_octree, lvl_fusion;

@@ -827,7 +827,7 @@ constexpr int kBigMin = kOwnCap;        // clusters above this size take this pa
 constexpr int kBigNodes = 1024;         // frontier nodes / edges of a workgroup's range that the cached level holds
 constexpr int kBigEdges = 8192;
 constexpr int kBigDirectDegree = 32;    // FAST: mean list length of a level up to which claims are not filtered
-static_assert(kBigSlice == kBigEdges && kBigClusterMin == kBigMin, "staging sizes follow the kernel's constants");
+static_assert(kBigSlice == kBigEdges && kBigClusterMin == kBigMin && kBfsGiantMin == kBigMin, "staging sizes follow the kernel's constants");
 static_assert(kBigNodes <= 65535, "c_j holds node indices of a range as 16-bit");
 
 // Everything the workgroups exchange (frontier regions, claims, records) is written with
@@ -1785,8 +1785,13 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_local_kernel(
 //      stream (the two touch disjoint clusters): one side stream and two events per (device, caller stream)
 struct BfsSide {
   hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, back = nullptr;
 };
+// sg_scan_grouping_pp's request (bfs_emit_defer, thread-local, consumed by the next sg_bfs_cluster_emit call of
+// the thread): when the call replays giant clusters on the side stream, do NOT join -- the side stream waits for
+// the caller's stream instead (so it sees the small clusters too) and is handed to the caller, who queues the rest
+// of this class behind the replay and goes on with the next class on its own stream (bfs_emit_join at the end)
+static thread_local BfsDefer *t_bfs_defer = nullptr;
 static std::mutex g_bfs_mu;
 static std::map<std::pair<int, hipStream_t>, BfsSide> g_bfs_side;
 static BfsSide *bfs_side(hipStream_t stream) {
@@ -1797,7 +1802,8 @@ static BfsSide *bfs_side(hipStream_t stream) {
   if (b.side == nullptr) {
     if (hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b.join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&b.join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b.back, hipEventDisableTiming) != hipSuccess) {
       b = BfsSide();
       return nullptr;
     }
@@ -1813,6 +1819,7 @@ void bfs_release_stream(int dev, hipStream_t stream) {      // sg_stream_release
     hipStreamDestroy(it->second.side);
     hipEventDestroy(it->second.fork);
     hipEventDestroy(it->second.join);
+    hipEventDestroy(it->second.back);
   }
   g_bfs_side.erase(it);
 }
@@ -1823,6 +1830,48 @@ struct BfsLabelNote {
   int max_kept = -1;
 };
 static thread_local BfsLabelNote t_bfs_note;
+
+void bfs_emit_defer(BfsDefer *d) { t_bfs_defer = d; }
+int bfs_emit_join(const BfsDefer &d, hipStream_t stream) {
+  if (!d.deferred) return SG_OK;
+  BfsSide *side = bfs_side(stream);
+  if (side == nullptr || side->side != d.side || hipEventRecord(side->join, side->side) != hipSuccess ||
+      hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
+    set_error("bfs_emit_join: joining the side stream failed");
+    return SG_ERR_LAUNCH;
+  }
+  return SG_OK;
+}
+int bfs_label_max_kept(const void *ws) { return t_bfs_note.ws == ws ? t_bfs_note.max_kept : -1; }
+
+// points of a class whose level voxel l2p[p] lies in a KEPT cluster of the labelling that just ran on `ws`
+// (= the rows pyramid_inverse_map will produce for it): known before the clusters are emitted
+__global__ void __launch_bounds__(256) bfs_kept_members_kernel(const int32_t *__restrict__ l2p, int n_pts,
+                                                              const int4 *__restrict__ label,
+                                                              const int32_t *__restrict__ size,
+                                                              const float *__restrict__ thr_dev,
+                                                              int32_t *__restrict__ out) {
+  __shared__ int wsum[4];
+  const float thr = thr_dev[0];
+  int mine = 0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < n_pts; p += gridDim.x * 256)
+    mine += static_cast<float>(size[label[l2p[p]].x]) >= thr ? 1 : 0;      // (the labelling's own `keep` test)
+  const int w = wave_sum(mine);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+int bfs_count_kept_members(const void *ws, size_t ws_bytes, int n, int64_t n_edges, const int32_t *l2p, int n_pts,
+                           const float *thr_dev, int32_t *out, hipStream_t stream) {
+  BfsWs w;
+  if (!bfs_carve(const_cast<void *>(ws), ws_bytes, n, n_edges, &w)) {
+    set_error("bfs_count_kept_members: workspace too small");
+    return SG_ERR_WORKSPACE;
+  }
+  hipMemsetAsync(out, 0, 4, stream);
+  bfs_kept_members_kernel<<<grid_for(n_pts, 256, 1024), 256, 0, stream>>>(l2p, n_pts, w.label, w.size, thr_dev, out);
+  return check_launch("bfs_count_kept_members");
+}
 
 }  // namespace sg
 
@@ -1966,6 +2015,9 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   static const bool side_env = !(getenv("SG_BFS_BIG_SIDE") && atoi(getenv("SG_BFS_BIG_SIDE")) == 0);
   BfsSide *side = has_big && side_env && !want_stats ? bfs_side(stream) : nullptr;
   hipStream_t main_stream = stream;
+  BfsDefer *defer = t_bfs_defer;      // (one call's worth)
+  t_bfs_defer = nullptr;
+  if (defer != nullptr) defer->deferred = false;
   if (side != nullptr) {
     if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->side, side->fork, 0) != hipSuccess) {
       set_error("sg_bfs_cluster_emit: forking the side stream failed");
@@ -2033,7 +2085,16 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
           cluster_idxs, nullptr, 0x7fffffff, kBigMin, sync + 1, thin_levels_on());
     }
   }
-  if (side != nullptr) {
+  if (side != nullptr && defer != nullptr) {
+    // deferred join: the side stream sees the per-cluster kernel's clusters and belongs to the caller from here
+    stream = main_stream;
+    if (hipEventRecord(side->back, stream) != hipSuccess || hipStreamWaitEvent(side->side, side->back, 0) != hipSuccess) {
+      set_error("sg_bfs_cluster_emit: handing the side stream over failed");
+      return SG_ERR_LAUNCH;
+    }
+    defer->deferred = true;
+    defer->side = side->side;
+  } else if (side != nullptr) {
     stream = main_stream;
     if (hipEventRecord(side->join, side->side) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
       set_error("sg_bfs_cluster_emit: joining the side stream failed");

@@ -189,5 +189,16 @@ void conv_release_stream(int dev, hipStream_t stream);
 void unet_release_stream(int dev, hipStream_t stream);
 void scan_release_stream(int dev, hipStream_t stream);
 void bfs_release_stream(int dev, hipStream_t stream);
+// deferred join of the giant clusters' replay (bfs.hip; sg_scan_grouping_pp overlaps it with the next classes)
+constexpr int kBfsGiantMin = 16384;      // clusters above this many points are "giant" (bfs.hip: kBigMin)
+struct BfsDefer {
+  bool deferred = false;
+  hipStream_t side = nullptr;
+};
+void bfs_emit_defer(BfsDefer *d);                        // request for the thread's next sg_bfs_cluster_emit
+int bfs_emit_join(const BfsDefer &d, hipStream_t stream);   // `stream` waits for everything queued on d.side
+int bfs_label_max_kept(const void *ws);                  // largest kept cluster of the thread's last labelling on ws (-1: unknown)
+int bfs_count_kept_members(const void *ws, size_t ws_bytes, int n, int64_t n_edges, const int32_t *l2p, int n_pts,
+                           const float *thr_dev, int32_t *out, hipStream_t stream);
 
 }  // namespace sg

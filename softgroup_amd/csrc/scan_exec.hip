@@ -654,8 +654,25 @@ int sg_scan_grouping_pp(const sg_grouping_pp_cfg *pcfg, const float *scores, con
   SG_TAKE(poff, int32_t, static_cast<size_t>(n_sel) + 2);
   int n_prop = 0, S = 0;
   int64_t n_nbr = 0;
-  const size_t loop_mark = ar.off;       // per-class temporaries: the same region for every class (stream order)
+  const size_t loop_mark0 = ar.off;      // per-class temporaries: the same region for every class (stream order)
+  size_t loop_mark = loop_mark0;
   bool hook_pending = t_scan_emit_hook != nullptr;
+  // A class with a giant cluster (> 16 384 points: milliseconds of multi-workgroup replay on the emission's side
+  // stream) does not hold up the classes behind it: its emission hands the side stream over instead of joining
+  // (bfs_emit_defer), the rest of the class -- inverse map, append at its known place -- is queued there, its
+  // temporaries stay where they are, and the caller's stream goes on with the next class; one join before the
+  // proposals are used.  The rows the inverse map will yield (the append offset of the classes behind) are
+  // counted from the labelling before the emission.  One class per call (there is one side stream).
+  const bool defer_on = !(getenv("SG_PP_DEFER") && atoi(getenv("SG_PP_DEFER")) == 0);      // developer A/B knob, read per call
+  BfsDefer def;
+  int def_rows = -1;
+  bool def_mapped = false;
+  struct DeferGuard {      // (an early return must not leave the side stream working on a released arena)
+    BfsDefer &d;
+    ~DeferGuard() {
+      if (d.deferred && d.side != nullptr) hipStreamSynchronize(d.side);
+    }
+  } defer_guard{def};
   int s0 = 0;
   for (int s = 0; s < n_seg; s0 += count[s], ++s) {
     const int nc_pts = count[s];
@@ -743,6 +760,15 @@ int sg_scan_grouping_pp(const sg_grouping_pp_cfg *pcfg, const float *scores, con
     SG_TRY(sg_bfs_cluster_label(bq_idx, start_len, n_q, n_active, flags, nullptr, cfg->seg_thr + s, 1, &nc, &sp, bfs_ws,
                                 bfs_bytes, stream_));
     if (sp == 0) continue;
+    bool later = false;
+    for (int t = s + 1; t < n_seg; ++t) later = later || count[t] > 0;
+    const bool want_defer = defer_on && def_rows < 0 && later && bfs_label_max_kept(bfs_ws) > kBfsGiantMin;
+    int rows = sp;
+    if (want_defer && mapped) {
+      SG_TRY(bfs_count_kept_members(bfs_ws, bfs_bytes, n_q, n_active, l2p, nc_pts, cfg->seg_thr + s, meta + 72, stream));
+      SG_TRY(read_back(host, meta + 72, 1, stream, kWhat));
+      rows = host[0];
+    }
     SG_TAKE(cidx, int32_t, 2 * static_cast<size_t>(sp));
     SG_TAKE(coff, int32_t, static_cast<size_t>(nc) + 1);
     hipMemsetAsync(coff, 0, sizeof(int32_t) * (nc + 1), stream);
@@ -750,29 +776,49 @@ int sg_scan_grouping_pp(const sg_grouping_pp_cfg *pcfg, const float *scores, con
       t_scan_emit_hook(t_scan_emit_ctx);
       hook_pending = false;
     }
+    if (want_defer) bfs_emit_defer(&def);
     SG_TRY(sg_bfs_cluster_emit(bq_idx, start_len, n_q, n_active, nullptr, cfg->seg_thr + s, nc, sp, cidx, coff, bfs_ws,
                                bfs_bytes, stream_));
+    const bool deferred = want_defer && def.deferred;      // (no side stream: the call joined as usual)
+    hipStream_t tail = deferred ? def.side : stream;
     const int32_t *src_idx = cidx, *src_off = coff;
-    int rows = sp;
     if (mapped) {      // pyramid_inverse_map (:500-507): proposals over level voxels -> over the class's points
       SG_TAKE(oidx, int32_t, 2 * static_cast<size_t>(nc_pts));
       SG_TAKE(ooff, int32_t, static_cast<size_t>(nc) + 1);
       const size_t ib = sg_pyramid_inverse_map_workspace_bytes(nc_pts, n_lvl, nc);
       SG_TAKE(i_ws, char, ib);
-      SG_TRY(sg_pyramid_inverse_map(cidx, sp, nc, l2p, nc_pts, n_lvl, oidx, ooff, meta + 48, i_ws, ib, stream_));
-      SG_TRY(read_back(host, meta + 48, 1, stream, kWhat));
-      rows = host[0];
+      SG_TRY(sg_pyramid_inverse_map(cidx, sp, nc, l2p, nc_pts, n_lvl, oidx, ooff, deferred ? meta + 80 : meta + 48, i_ws,
+                                    ib, reinterpret_cast<sg_stream_t>(tail)));
+      if (!deferred) {
+        SG_TRY(read_back(host, meta + 48, 1, stream, kWhat));
+        rows = host[0];
+      }
       src_idx = oidx;
       src_off = ooff;
     }
+    if (deferred) {
+      def_rows = rows;
+      def_mapped = mapped;
+      loop_mark = ar.off;      // the class's buffers stay until the join
+    }
     if (rows == 0) continue;
     SG_REQUIRE(S + rows <= n_sel, "sg_scan_grouping_pp: more proposal rows than selected points");
-    pp_append_kernel<<<grid_for(rows > nc ? rows : nc, 256, 1 << 22), 256, 0, stream>>>(src_idx, rows, src_off, nc, obj + s0,
-                                                                                    n_prop, S, pairs, poff);
+    pp_append_kernel<<<grid_for(rows > nc ? rows : nc, 256, 1 << 22), 256, 0, tail>>>(src_idx, rows, src_off, nc, obj + s0,
+                                                                                  n_prop, S, pairs, poff);
     n_prop += nc;
     S += rows;
   }
-  ar.off = loop_mark;
+  res->deferred_classes = def_rows >= 0 ? 1 : 0;
+  if (def.deferred) {
+    SG_TRY(bfs_emit_join(def, stream));
+    def.deferred = false;
+    if (def_mapped) {      // the count taken from the labelling against the inverse map's own
+      SG_TRY(read_back(host, meta + 80, 1, stream, kWhat));
+      SG_REQUIRE(host[0] == def_rows, "sg_scan_grouping_pp: the deferred class's rows were predicted as %d, the inverse map made %d",
+                 def_rows, host[0]);
+    }
+  }
+  ar.off = loop_mark0;
   res->n_neighbours = static_cast<int>(n_nbr < 0x7fffffff ? n_nbr : 0x7fffffff);
   res->n_proposals = n_prop;
   res->sum_npoint = S;

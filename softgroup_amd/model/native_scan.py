@@ -33,7 +33,8 @@ class GroupingResult(C.Structure):
                 ('proposals_idx', C.c_size_t), ('proposals_offset', C.c_size_t),
                 ('voxel_coords', C.c_size_t), ('voxel_offsets', C.c_size_t),
                 ('voxel_feats', C.c_size_t), ('point_to_voxel', C.c_size_t),
-                ('arena_used', C.c_size_t), ('arena_needed', C.c_size_t)]
+                ('arena_used', C.c_size_t), ('arena_needed', C.c_size_t),
+                ('deferred_classes', C.c_int), ('reserved_', C.c_int)]
 
 
 class InstancesCfg(C.Structure):
@@ -103,6 +104,7 @@ def grouping(cfg, scores, pt_offsets, coords_float, batch_idxs, point_feats):
                     proposals_offset=_view(arena, res.proposals_offset, torch.int32, nP + 1).clone(),
                     n_proposals=nP)
     return dict(
+        deferred_classes=int(res.deferred_classes),
         proposals_idx=_view(arena, res.proposals_idx, torch.int32, S, 2).clone(),
         proposals_offset=_view(arena, res.proposals_offset, torch.int32, nP + 1).clone(),
         voxel_coords=_view(arena, res.voxel_coords, torch.int32, M, 4),

@@ -299,12 +299,21 @@ def test_softgroup_pp_grouping_in_c_equals_the_per_class_loop(points, scale):
                               voxel_scale=v['scale'], voxel_shape=v['spatial_shape'], feat_channels=feats.size(1))
         pp = NS.GroupingPPCfg(base=base, with_pyramid=1, with_octree=1, lvl_fusion=0, radius=float(g['radius']),
                               base_size=float(g['pyramid_base_size']))
-        r = NS.grouping(pp, scores, off.float().contiguous(), b['coords_float'].contiguous(), bidx.contiguous(),
-                        feats.contiguous())
-        assert torch.equal(r['proposals_idx'], pidx) and torch.equal(r['proposals_offset'], poff)
         inst_t, inst_map = model.clusters_voxelization(pidx, poff, feats, b['coords_float'], **v)
-        assert torch.equal(r['voxel_coords'], inst_t.indices) and torch.equal(r['voxel_feats'], inst_t.features)
-        assert torch.equal(r['point_to_voxel'].long(), inst_map.long())
+        # with and without the deferred join (a class with a giant cluster lets the classes behind it run next
+        # to its replay; at 150 k points the first grouped class holds one)
+        import os
+        for defer in ('1', '0'):
+            os.environ['SG_PP_DEFER'] = defer
+            try:
+                r = NS.grouping(pp, scores, off.float().contiguous(), b['coords_float'].contiguous(),
+                                bidx.contiguous(), feats.contiguous())
+            finally:
+                del os.environ['SG_PP_DEFER']
+            assert r['deferred_classes'] == (1 if defer == '1' and points >= 150000 else 0), (defer, r['deferred_classes'])
+            assert torch.equal(r['proposals_idx'], pidx) and torch.equal(r['proposals_offset'], poff), defer
+            assert torch.equal(r['voxel_coords'], inst_t.indices) and torch.equal(r['voxel_feats'], inst_t.features)
+            assert torch.equal(r['point_to_voxel'].long(), inst_map.long())
         # (b) the whole scan, C driver against the per-class loop
         assert model.use_native_grouping_pp
         out_c = dict(model(b))
