@@ -1387,9 +1387,11 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_local_kernel(
   int *c_t = w_t + kLF;                           // [kLE]
   unsigned short *c_j = reinterpret_cast<unsigned short *>(c_t + kLE);                                    // [kLE]
   // nodes this workgroup KNOWS to be visited (every target it ever sent a claim to is visited one level later):
-  // edges to them -- most edges of a dense cluster -- are dropped in the claim sweep without touching memory
-  __shared__ unsigned vis[kVisWords];
+  // edges to them -- most edges of a dense cluster -- are dropped in the claim sweep without touching memory.
+  // Dynamic LDS, one bit per point of THIS call (19 KB at 150 k points: the workgroup fits next to others on a busy CU)
+  extern __shared__ unsigned vis[];
   const bool use_vis = n <= kVisWords * 32;
+  const int vis_words = use_vis ? (n + 31) >> 5 : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int G = gridDim.x, b = blockIdx.x;
   int32_t *bar = sync, *fail = sync + 1, *pool_head = sync + 2, *tot = sync + 4;
@@ -1424,8 +1426,7 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_local_kernel(
     const int seed = seeds[c];
     int32_t *Q = cluster_idxs + 2LL * off_c;
     const unsigned tag0 = tagc;                                   // level L of this cluster has tag tag0 + L + 1
-    if (use_vis)
-      for (int i = threadIdx.x; i < kVisWords; i += kEmitThreads) vis[i] = 0u;
+    for (int i = threadIdx.x; i < vis_words; i += kEmitThreads) vis[i] = 0u;
     __syncthreads();
     // ---- level 0: the seed -- first entry of the queue, row 0 of the level table (workgroup 0's piece)
     // (measured and dropped: replaying the first, thin levels -- <= 4096 edges -- by workgroup 0 alone, claims in an
@@ -2061,7 +2062,25 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
         hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.parent), 0x7fffffff, n, stream);    // second claim array
         if (const char *e = getenv("SG_BFS_FORCE_FALLBACK"))
           if (atoi(e) & 2) hipMemsetAsync(sync3 + 1, 1, 1, stream);      // test hook: the LOCAL form gave up
-        bfs_emit_big_local_kernel<<<lw, kEmitThreads, 0, stream>>>(
+        // the visited filter: one bit per point in dynamic LDS (on top of ~92 KB static)
+        const size_t vis_bytes = (!novis && n <= kVisWords * 32) ? static_cast<size_t>((n + 31) >> 5) * 4 : 0;
+        {
+          static std::mutex mu;
+          static uint64_t done_mask = 0;      // bit d: device d configured (the attribute is per device)
+          int dev = 0;
+          hipGetDevice(&dev);
+          std::lock_guard<std::mutex> g(mu);
+          if (dev < 0 || dev >= 64 || !((done_mask >> dev) & 1)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(bfs_emit_big_local_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kVisWords * 4) != hipSuccess) {
+              (void)hipGetLastError();
+              set_error("sg_bfs_cluster_emit: %d bytes of dynamic LDS are not available on this device", kVisWords * 4);
+              return SG_ERR_LAUNCH;
+            }
+            if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+          }
+        }
+        bfs_emit_big_local_kernel<<<lw, kEmitThreads, vis_bytes, stream>>>(
             bq_idxs, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, w.parent, w.big_stage[0],
             w.big_rec[0], w.big_rec[1], static_cast<int>(rows) - 1, cluster_idxs, sync3, novis ? 0x7fffffff : n, every, warm,
             want_stats);
