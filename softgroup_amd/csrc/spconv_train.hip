@@ -260,37 +260,49 @@ static void launch_bf16(const Bf16Args &a, int grid, size_t lds, bool vec, hipSt
 // ---------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------
+// Operand loads of the weight gradient's matrix loop, in two halves: `fetch` issues the load of an address that
+// is always readable (the caller clamps it) and returns the RAW words; `value` -- called one trip later, right
+// before the MFMAs -- converts and masks.  Until round 6 a load sat under its validity branch and was converted
+// where it was issued: the compiler then waits for ALL outstanding loads at the top of every trip, so no trip's
+// loads ever overlapped its predecessor's MFMAs, whatever the depth of the ring.
 template <typename T, int V>
 struct RowVec;
 template <>
 struct RowVec<float, 1> {
-  static __device__ __forceinline__ void load(const float *p, bool ok, float (&v)[1]) { v[0] = ok ? *p : 0.f; }
+  typedef float Raw;
+  static __device__ __forceinline__ Raw fetch(const float *p) { return *p; }
+  static __device__ __forceinline__ void value(Raw r, bool ok, float (&v)[1]) { v[0] = ok ? r : 0.f; }
 };
 template <>
 struct RowVec<float, 2> {
-  static __device__ __forceinline__ void load(const float *p, bool ok, float (&v)[2]) {
-    const float2 t = ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
-    v[0] = t.x;
-    v[1] = t.y;
+  typedef float2 Raw;
+  static __device__ __forceinline__ Raw fetch(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+  static __device__ __forceinline__ void value(Raw r, bool ok, float (&v)[2]) {
+    v[0] = ok ? r.x : 0.f;
+    v[1] = ok ? r.y : 0.f;
   }
 };
 template <>
 struct RowVec<uint16_t, 1> {
-  // the aligned 32-bit word that holds the element (a 16-bit load merges into its destination
-  // register and serialises behind it); the neighbour half is inside the same row or, for the very
-  // last element of an odd-sized tensor, inside the allocation's alignment padding
-  static __device__ __forceinline__ void load(const uint16_t *p, bool ok, float (&v)[1]) {
+  // the aligned 32-bit word that holds the element (a 16-bit load merges into its destination register and
+  // serialises behind it) with the element moved to the high half; the neighbour half is inside the same row or,
+  // for the very last element of an odd-sized tensor, inside the allocation's alignment padding
+  typedef uint2 Raw;      // (word, shift)
+  static __device__ __forceinline__ Raw fetch(const uint16_t *p) {
     const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
-    const uint32_t t = ok ? *reinterpret_cast<const uint32_t *>(addr & ~static_cast<uintptr_t>(3)) : 0u;
-    v[0] = __builtin_bit_cast(float, (addr & 2) ? (t & 0xffff0000u) : (t << 16));
+    return make_uint2(*reinterpret_cast<const uint32_t *>(addr & ~static_cast<uintptr_t>(3)), (addr & 2) ? 0u : 16u);
+  }
+  static __device__ __forceinline__ void value(Raw r, bool ok, float (&v)[1]) {
+    v[0] = ok ? __builtin_bit_cast(float, (r.x << r.y) & 0xffff0000u) : 0.f;
   }
 };
 template <>
 struct RowVec<uint16_t, 2> {
-  static __device__ __forceinline__ void load(const uint16_t *p, bool ok, float (&v)[2]) {
-    const uint32_t t = ok ? *reinterpret_cast<const uint32_t *>(p) : 0u;
-    v[0] = __builtin_bit_cast(float, t << 16);
-    v[1] = __builtin_bit_cast(float, t & 0xffff0000u);
+  typedef uint32_t Raw;
+  static __device__ __forceinline__ Raw fetch(const uint16_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
+  static __device__ __forceinline__ void value(Raw r, bool ok, float (&v)[2]) {
+    v[0] = ok ? __builtin_bit_cast(float, r << 16) : 0.f;
+    v[1] = ok ? __builtin_bit_cast(float, r & 0xffff0000u) : 0.f;
   }
 };
 
@@ -394,6 +406,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
     const int sib = st / nso, sob = st % nso;
     const int ci0 = sib * 32 * VI + VI * col, co0 = sob * 32 * VO + VO * col;
     const bool ci_ok = ci0 + VI <= Cin, co_ok = co0 + VO <= Cout;
+    const int ci_ld = ci_ok ? ci0 : 0, co_ld = co_ok ? co0 : 0;      // (lanes beyond the channels read channel 0)
+    const int last = total - 1;
     f32x16 acc[VI][VO];
 #pragma unroll
     for (int c = 0; c < VI; ++c)
@@ -403,41 +417,54 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const TA *__restrict__ 
         for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
     // 4 pairs of existing rows per trip (8 vector loads, 4 VI VO MFMAs); the loads of trip t+1 are
     // in flight while trip t multiplies
-    auto ld = [&](int t, float (&a)[4][VI], float (&b)[4][VO]) {
+    typedef typename RowVec<TA, VI>::Raw RawA;
+    typedef typename RowVec<TG, VO>::Raw RawB;
+    auto ld = [&](int t, RawA (&a)[4], RawB (&b)[4], int &okm) {
+      okm = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int it = t + 2 * u + half;
         const bool ok = it < end;
-        const int s = ok ? src_c[it] : 0, r = ok ? row_c[it] : 0;
-        RowVec<TA, VI>::load(in + static_cast<long long>(s) * Cin + ci0, ok && ci_ok, a[u]);
-        RowVec<TG, VO>::load(g_out + static_cast<long long>(r0 + r) * Cout + co0, ok && co_ok, b[u]);
+        const int itc = ok ? it : last;                  // (past the end: the chunk's last pair again, value dropped)
+        const int s = src_c[itc], r = row_c[itc];
+        a[u] = RowVec<TA, VI>::fetch(in + static_cast<long long>(s) * Cin + ci_ld);
+        b[u] = RowVec<TG, VO>::fetch(g_out + static_cast<long long>(r0 + r) * Cout + co_ld);
+        okm |= (ok ? 1 : 0) << u;
       }
     };
-    auto mm = [&](float (&a)[4][VI], float (&b)[4][VO]) {
+    // (a pair past the end, or a lane beyond the input channels, multiplies ZERO by a real gradient row; output
+    //  channels beyond Cout are computed and not stored)
+    auto mm = [&](const RawA (&ra)[4], const RawB (&rb)[4], int okm) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 4; ++u) {
+        float a[VI], b[VO];
+        RowVec<TA, VI>::value(ra[u], ((okm >> u) & 1) != 0 && ci_ok, a);
+        RowVec<TG, VO>::value(rb[u], true, b);
 #pragma unroll
         for (int c = 0; c < VI; ++c)
 #pragma unroll
           for (int d = 0; d < VO; ++d)
-            acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][c], b[u][d], acc[c][d], 0, 0, 0);
+            acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[d], acc[c][d], 0, 0, 0);
+      }
     };
     {
-      // kWgDepth trips in the ring, the loads of kWgDepth - 1 of them in flight while one multiplies.  Depth 2
-      // (one trip ahead) is the default: depth 4 measured no faster on the single layers (66 / 125 / 165 us
-      // against 67 / 120 / 163 on levels 0-2, tools/train_conv_bench.py) and 53 against 49 us per call in the
-      // training step -- the kernel waits for the gathered rows' bytes (two 256-B rows per pair for 8 KFLOP),
-      // not for their latency
-      float a[kWgDepth][4][VI], b[kWgDepth][4][VO];
+      // kWgDepth trips in the ring: the loads of kWgDepth - 1 of them are in flight while one multiplies.  With the
+      // loads out of their branches (RowVec above): sum over the 7 levels 0.517 -> 0.465 ms fp32 rows, 0.559 -> 0.467
+      // bf16 rows at depth 2; depth 3 the same (0.468 / 0.481), depth 4 slower (0.522: registers) -- what is left is
+      // not the latency of the gathered rows
+      RawA a[kWgDepth][4];
+      RawB b[kWgDepth][4];
+      int okm[kWgDepth];
       int t = begin;
 #pragma unroll
-      for (int i = 0; i + 1 < kWgDepth; ++i) ld(t + 8 * i, a[i], b[i]);      // past the end: no access, zeros
+      for (int i = 0; i + 1 < kWgDepth; ++i) ld(t + 8 * i, a[i], b[i], okm[i]);
       while (t < end) {
 #pragma unroll
         for (int i = 0; i < kWgDepth; ++i) {
-          ld(t + 8 * (kWgDepth - 1), a[(i + kWgDepth - 1) % kWgDepth], b[(i + kWgDepth - 1) % kWgDepth]);
+          constexpr int kNext = kWgDepth - 1;
+          ld(t + 8 * kNext, a[(i + kNext) % kWgDepth], b[(i + kNext) % kWgDepth], okm[(i + kNext) % kWgDepth]);
           __builtin_amdgcn_sched_barrier(0);
-          mm(a[i], b[i]);
+          mm(a[i], b[i], okm[i]);
           __builtin_amdgcn_sched_barrier(0);
           t += 8;
           if (t >= end) break;
