@@ -1657,6 +1657,11 @@ __global__ void __launch_bounds__(kEmitThreads) bfs_emit_big_local_kernel(
               }
             }
           }
+          // (measured and dropped, after reading the ISA: the compiler drains everything outstanding at the end of each
+          //  chunk's data-dependent branch, so the four chunks' loads do not overlap.  Every load unconditional from
+          //  clamped indices: emit sweep 1.72 against 1.43 us (kitti), 1.29 against 0.86 (stpls3d) -- most lanes have no
+          //  edge or a filtered one, and skipping their loads is worth more than overlapping the others'.  All
+          //  load-dependent decisions before the first atomic / store of a trip: no gain either.)
           // (ranks: one workgroup scan per chunk of 512 edges; a ballot table with one rendezvous for the
           //  kSweepU chunks measured the same on fat levels and slower on thin ones)
 #pragma unroll

@@ -1,11 +1,13 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
+cd $R
 F=$OUT/r06y_bfs_local.txt
 : > $F
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "bfs" 2>&1 | tail -2 >> $F
+cd /tmp && export TMPDIR=/tmp
 for cfg in kitti stpls3d_pp; do
-for v in "8 4" "12 4" "16 4" "12 3" "16 3" "20 4"; do
+for v in "16 4"; do
 set -- $v
 export SG_BFS_BIG_LOCAL_WGS=$1 SG_BFS_BIG_LOCAL_EVERY=$2
 rm -rf /tmp/prof_y
@@ -16,6 +18,9 @@ f=glob.glob('/tmp/prof_y/**/*kernel_stats.csv',recursive=True)
 for r in csv.DictReader(open(f[0])):
     if 'bfs_emit_big_local' in r['Name']: print('$cfg wgs=$1 every=$2', r['Calls'], r['AverageNs'])
 PY
+SG_BFS_STATS=1 timeout 300 python $R/tools/scan_only.py 2 150000 $cfg 2>&1 | grep -E "local form" | tail -1 >> $F
 done
+unset SG_BFS_BIG_LOCAL_WGS SG_BFS_BIG_LOCAL_EVERY
+for i in 1 2; do timeout 300 python $R/tools/scan_only.py 30 150000 $cfg 2>&1 | tail -1 >> $F; done
 done
 echo done >> $F
