@@ -2,25 +2,20 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd $R
-F=$OUT/r06y_bfs_local.txt
+F=$OUT/r06y_bfs_fast.txt
 : > $F
 timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "bfs" 2>&1 | tail -2 >> $F
 cd /tmp && export TMPDIR=/tmp
-for cfg in kitti stpls3d_pp; do
-for v in "16 4"; do
-set -- $v
-export SG_BFS_BIG_LOCAL_WGS=$1 SG_BFS_BIG_LOCAL_EVERY=$2
+for cfg in scannet kitti stpls3d_pp; do
 rm -rf /tmp/prof_y
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_y -o y -- python $R/tools/scan_only.py 12 150000 $cfg > /dev/null 2>&1
 python - <<PY >> $F
 import csv,glob
 f=glob.glob('/tmp/prof_y/**/*kernel_stats.csv',recursive=True)
 for r in csv.DictReader(open(f[0])):
-    if 'bfs_emit_big_local' in r['Name']: print('$cfg wgs=$1 every=$2', r['Calls'], r['AverageNs'])
+    if 'bfs_emit' in r['Name']: print('$cfg', r['Name'][:40], r['Calls'], r['AverageNs'])
 PY
-SG_BFS_STATS=1 timeout 300 python $R/tools/scan_only.py 2 150000 $cfg 2>&1 | grep -E "local form" | tail -1 >> $F
-done
-unset SG_BFS_BIG_LOCAL_WGS SG_BFS_BIG_LOCAL_EVERY
 for i in 1 2; do timeout 300 python $R/tools/scan_only.py 30 150000 $cfg 2>&1 | tail -1 >> $F; done
 done
+SG_BFS_STATS=1 timeout 300 python $R/tools/scan_only.py 1 150000 scannet 2>&1 | grep "bfs cluster" | sort -t' ' -k5 -n -r | head -8 >> $F
 echo done >> $F
