@@ -23,6 +23,7 @@ SIGNATURES = {
     'sg_host_copy_2d': (_i, [_vp, _i64, _vp, _i64, _i64, _i64]),
     'sg_host_cast_f64_f32': (_i, [_vp, _vp, _i64]),
     'sg_host_fill_i64_strided': (_i, [_vp, _i64, _i64, _i64]),
+    'sg_host_colmax_i64': (_i, [_vp, _i64, _i64, _vp]),
     'sg_stream_create': (_i, [_vp]),
     'sg_stream_create_priority': (_i, [_vp, _i]),
     'sg_stream_destroy': (_i, [_vp]),

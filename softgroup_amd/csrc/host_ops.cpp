@@ -339,4 +339,33 @@ int sg_host_fill_i64_strided(int64_t *dst, int64_t pitch_elems, int64_t rows, in
   return SG_OK;
 }
 
+// column-wise maximum of a row-major int64 matrix (the collate's spatial_shape = max voxel coordinate + 1,
+// data/custom.py:246: numpy's axis-0 reduction of a [150 000, 3] array takes 1.3 ms under the interpreter lock)
+int sg_host_colmax_i64(const int64_t *src, int64_t rows, int64_t cols, int64_t *out_max) {
+  if (cols < 1 || cols > 8 || out_max == nullptr || (rows > 0 && src == nullptr)) {
+    sg::set_error("sg_host_colmax_i64: bad arguments (1..8 columns)");
+    return SG_ERR_ARG;
+  }
+  int64_t m[8];
+  for (int64_t c = 0; c < cols; ++c) m[c] = INT64_MIN;
+  if (cols == 3) {      // (the usual case; fixed trip counts let the compiler keep the three maxima in registers)
+    int64_t a = INT64_MIN, b = INT64_MIN, c3 = INT64_MIN;
+    for (int64_t r = 0; r < rows; ++r) {
+      const int64_t x = src[3 * r], y = src[3 * r + 1], z = src[3 * r + 2];
+      a = x > a ? x : a;
+      b = y > b ? y : b;
+      c3 = z > c3 ? z : c3;
+    }
+    m[0] = a; m[1] = b; m[2] = c3;
+  } else {
+    for (int64_t r = 0; r < rows; ++r)
+      for (int64_t c = 0; c < cols; ++c) {
+        const int64_t v = src[r * cols + c];
+        m[c] = v > m[c] ? v : m[c];
+      }
+  }
+  for (int64_t c = 0; c < cols; ++c) out_max[c] = m[c];
+  return SG_OK;
+}
+
 }  // extern "C"

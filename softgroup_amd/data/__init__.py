@@ -16,6 +16,7 @@ dict (keys, dtypes, values), but
 Every tensor of the result is already resident: ``forward_test``'s ``cuda_cast`` is a no-op.
 """
 import math
+import os
 import threading
 import time
 
@@ -237,7 +238,14 @@ def collate_device(batch, min_spatial=128, device='cuda'):
         total_inst += inst_num
         scan_ids.append(scan_id)
         coords.append(coord)
-        cmax = np.maximum(cmax, coord.numpy().max(0)) if coord.numel() else cmax
+        if coord.numel():
+            if coord.dtype == torch.int64 and coord.is_contiguous() and coord.dim() == 2 and coord.shape[1] <= 8:
+                one = np.empty(coord.shape[1], np.int64)      # (C loop, no interpreter lock: numpy's axis-0 max of a
+                L.check(L.lib().sg_host_colmax_i64(coord.data_ptr(), coord.shape[0], coord.shape[1],      # [150 000, 3]
+                                                   one.ctypes.data), 'sg_host_colmax_i64')          # array is 1.3 ms)
+                cmax = np.maximum(cmax, one)
+            else:
+                cmax = np.maximum(cmax, coord.numpy().max(0))
         coords_float.append(coord_float)
         feats.append(feat)
         sem.append(semantic_label)
@@ -318,7 +326,11 @@ def prefetch_device(batches, collate=None, depth=1, device='cuda', workers=1):
         q = qs[w]
         try:
             with torch.cuda.device(dev):
-                side = torch.cuda.Stream()
+                # (SG_LOADER_PRIORITY=1, developer knob: a high-priority stream for the collate's dozen small kernels,
+                #  which queue behind the scans' persistent conv kernels on a busy GPU.  Measured worse: scans in
+                #  flight fed from the host 4.6 against 3.85 ms/scan, one scan with the next prefetched 5.95 against 5.25)
+                prio = -1 if os.environ.get('SG_LOADER_PRIORITY', '0') == '1' else 0
+                side = torch.cuda.Stream(priority=prio)
                 with torch.cuda.stream(side), torch.no_grad():
                     while not stop.is_set():
                         # batch i belongs to thread i % workers: take from the source in order, under the lock

@@ -47,3 +47,29 @@ def test_octree_build_host_matches_reference(golden):
         assert np.array_equal(boxes.numpy(), g[p + 'boxes'])
         assert np.array_equal(pt_inds.numpy(), g[p + 'pt_inds'])
         assert np.array_equal(psl.numpy(), g[p + 'pt_start_len'])
+
+
+def test_collate_staging_helpers_match_numpy():
+    """the plain-C staging copies of the device-side collate (sg_host_copy_2d, sg_host_cast_f64_f32,
+    sg_host_fill_i64_strided, sg_host_colmax_i64: what data/custom.py:196-256 does with torch.cat / max on the
+    CPU) against numpy, including empty inputs and the generic column count."""
+    lib = L.lib()
+    rng = np.random.default_rng(3)
+    src = rng.integers(-50, 700, (1001, 3)).astype(np.int64)
+    dst = np.zeros((1001, 4), np.int64)
+    L.check(lib.sg_host_fill_i64_strided(dst.ctypes.data, 4, 1001, 7), 'fill')
+    L.check(lib.sg_host_copy_2d(dst.ctypes.data + 8, 32, src.ctypes.data, 24, 1001, 24), 'copy')
+    assert (dst[:, 0] == 7).all() and np.array_equal(dst[:, 1:], src)
+    d = rng.normal(0, 1e3, 777)
+    f = np.empty(777, np.float32)
+    L.check(lib.sg_host_cast_f64_f32(f.ctypes.data, d.ctypes.data, 777), 'cast')
+    assert np.array_equal(f, d.astype(np.float32))
+    for cols in (1, 3, 4, 8):
+        m = rng.integers(-1000, 1000, (513, cols)).astype(np.int64)
+        out = np.empty(cols, np.int64)
+        L.check(lib.sg_host_colmax_i64(m.ctypes.data, 513, cols, out.ctypes.data), 'colmax')
+        assert np.array_equal(out, m.max(0)), cols
+    out = np.empty(3, np.int64)
+    L.check(lib.sg_host_colmax_i64(None, 0, 3, out.ctypes.data), 'colmax empty')
+    assert (out == np.iinfo(np.int64).min).all()
+    assert lib.sg_host_colmax_i64(src.ctypes.data, 10, 9, out.ctypes.data) != 0      # more than 8 columns: refused
