@@ -649,14 +649,21 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
             for r in [model(b_) for b_ in prefetch_device([[sample]] * (2 * in_flight), depth=2, workers=n_loaders)]:
                 r.resolve()
             torch.cuda.synchronize()
-            n_fed = 40
+            n_fed = 160      # (the headline region's length: a 40-scan region carried ~0.4 ms/scan of pipeline fill)
             t0 = time.perf_counter()
-            rets = [model(b_) for b_ in prefetch_device([[sample]] * n_fed, depth=2, workers=n_loaders)]
-            for r in rets:
-                r.resolve()
+            # results are taken and released as a serving loop would, at most 2 x in_flight scans behind the
+            # submission (keeping all 160 alive put ~140 of them into pageable copies beyond SG_PINNED_RESULTS_MB
+            # and made every scan of the region pay a 12 MB allocation + copy: 3.6-4.1 ms/scan until round 6)
+            import collections
+            pending = collections.deque()
+            for b_ in prefetch_device([[sample]] * n_fed, depth=2, workers=n_loaders):
+                pending.append(model(b_))
+                if len(pending) > 2 * in_flight:
+                    pending.popleft().resolve()
+            while pending:
+                pending.popleft().resolve()
             torch.cuda.synchronize()
             ms_fed = (time.perf_counter() - t0) / n_fed * 1e3
-            del rets
         finally:
             model.scan_contexts = 1
         # the host link of this box, for reading the figure: pinned -> device copy rate
