@@ -2017,7 +2017,9 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   static const bool big_on = !(getenv("SG_BFS_BIG") && atoi(getenv("SG_BFS_BIG")) == 0);
   // is there a giant cluster?  Known from the labelling call when it was this thread's last one on this workspace
   const bool noted = t_bfs_note.ws == ws && t_bfs_note.max_kept >= 0;
-  const bool has_big = big_on && sum_npoint > kBigMin && (!noted || t_bfs_note.max_kept > kBigMin);
+  // (claim keys of the multi-workgroup replay are frontier rank * 1024 + list position in 31 bits: up to 2^21 points;
+  //  beyond that the giant clusters stay on the per-cluster kernel, whose claims are edge indices)
+  const bool has_big = big_on && n < (1 << 21) && sum_npoint > kBigMin && (!noted || t_bfs_note.max_kept > kBigMin);
   t_bfs_note.ws = nullptr;
   // the giant clusters' replay (16 workgroups, milliseconds) next to the per-cluster kernel (one workgroup per
   // cluster, the rest of the chip): fork a side stream here, join behind both (SG_BFS_BIG_SIDE=0: one after the other)
@@ -2035,7 +2037,7 @@ int sg_bfs_cluster_emit(const int32_t *bq_idxs, const int32_t *start_len, int n,
   }
   bfs_emit_kernel<<<min(n_cluster, 4096), kEmitThreads, 0, stream>>>(
       bq_idxs, start_len, w.label, w.erec, w.seeds, cluster_offsets, n_cluster, w.owner, cluster_idxs,
-      stats, big_on ? kBigMin : 0x7fffffff, -1, nullptr, thin_levels_on());
+      stats, big_on && n < (1 << 21) ? kBigMin : 0x7fffffff, -1, nullptr, thin_levels_on());
   if (side != nullptr) stream = side->side;      // everything of the giant clusters goes to the side stream
   if (has_big) {
     static const int big_wgs_env = getenv("SG_BFS_BIG_WGS") ? atoi(getenv("SG_BFS_BIG_WGS")) : 16;   // developer knob
