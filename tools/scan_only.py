@@ -43,6 +43,21 @@ def main():
             r = dict(model(batch))
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
+    ctx = int(os.environ.get('SCAN_CONTEXTS', '0'))
+    if ctx > 1:      # the same scans in flight: throughput, and every result against the one-at-a-time result
+        from softgroup_amd.util.digest import result_digest
+        with torch.no_grad():
+            want = result_digest(dict(model(batch)))
+            model.scan_contexts = ctx
+            for r_ in [model(batch) for _ in range(2 * ctx)]:
+                r_.resolve()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rets = [model(batch) for _ in range(reps)]
+            same = [result_digest(dict(r_)) == want for r_ in rets]
+            torch.cuda.synchronize()
+            print(f'{ctx} scans in flight: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms/scan over {reps} scans, '
+                  f'{sum(same)} of {len(same)} identical to the scan run alone ({which})')
     ts.sort()
     print(f'{reps} scans, latency ms min {ts[0]:.3f} median {ts[len(ts) // 2]:.3f} max {ts[-1]:.3f}; '
           f'{len(r.get("pred_instances", []))} instances ({which})')
