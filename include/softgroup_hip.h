@@ -762,7 +762,8 @@ int sg_scan_instances(const sg_instances_cfg *cfg, const int32_t *proposals_idx,
 
 /* ------------------------------------------------------------------------------------------
  * One scan = one call (csrc/scan_forward.hip): the whole of SoftGroup.forward_test
- * (softgroup/model/softgroup.py:299-361) for the plain SoftGroup configuration -- voxel feature pooling
+ * (softgroup/model/softgroup.py:299-361) for the instance-segmentation configurations (SoftGroup, and SoftGroup++
+ * through desc->with_pyramid / with_octree; not panoptic fusion, lvl_fusion or x4_split) -- voxel feature pooling
  * (:305), backbone (:307-309 -> forward_backbone :363-378), point-wise heads + arg-max, softmax of the
  * semantic scores, grouping head and proposal voxelisation (:411-480, :655-709), tiny U-Net (:671-675),
  * mask / class / IoU heads (:676-686), instance extraction + RLE text (:537-604) and the dense per-point
@@ -811,6 +812,10 @@ typedef struct sg_scan_desc {
   float cls_score_thr, mask_score_thr;
   int min_npoint;
   int want_instances;                 /* 0: stop after the point-wise heads */
+  /* SoftGroup++ grouping (sg_scan_grouping_pp instead of sg_scan_grouping) when either switch is set; pp_radius /
+   * pp_base_size are the configuration's Python floats (grouping_cfg.radius, .pyramid_base_size) */
+  int with_pyramid, with_octree;
+  double pp_radius, pp_base_size;
 } sg_scan_desc;
 typedef struct sg_scan_input {        /* one collated batch, device pointers (data/custom.py:240-256) */
   int n_points, n_voxels, max_active; /* p2v_map is int32 [n_voxels, 1 + max_active] */

@@ -559,8 +559,22 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
       ~HookScope() { t_scan_emit_hook = nullptr; t_scan_emit_ctx = nullptr; }
     } hook(start_dense_copy, &dc);
     const size_t room = arena_bytes > ar.off ? arena_bytes - ar.off : 0;
-    const int rc = sg_scan_grouping(&gc, prob, off, in->coords_float, in->batch_idxs, out_feats,
-                                    static_cast<char *>(arena) + ar.off, room, &res->grouping, stream_);
+    int rc;
+    if (d->with_pyramid || d->with_octree) {      // SoftGroup++: the per-class loop inside its own C call
+      sg_grouping_pp_cfg pc;
+      memset(&pc, 0, sizeof(pc));
+      pc.base = gc;
+      pc.with_pyramid = d->with_pyramid;
+      pc.with_octree = d->with_octree;
+      pc.lvl_fusion = 0;
+      pc.radius = d->pp_radius;
+      pc.base_size = d->pp_base_size;
+      rc = sg_scan_grouping_pp(&pc, prob, off, in->coords_float, in->batch_idxs, out_feats,
+                               static_cast<char *>(arena) + ar.off, room, &res->grouping, stream_);
+    } else {
+      rc = sg_scan_grouping(&gc, prob, off, in->coords_float, in->batch_idxs, out_feats,
+                            static_cast<char *>(arena) + ar.off, room, &res->grouping, stream_);
+    }
     if (rc == SG_ERR_WORKSPACE) res->arena_needed = ar.off + res->grouping.arena_needed + (64u << 20);
     if (rc != SG_OK) return rc;      // (the guard waits for a copy the hook may have started)
   }

@@ -41,7 +41,9 @@ class ScanDesc(C.Structure):      # sg_scan_desc
                 ('semantic', Mlp2), ('offset', Mlp2), ('mask', Mlp2), ('cls', Linear), ('iou', Linear),
                 ('channels', C.c_int), ('with_coords', C.c_int), ('semantic_classes', C.c_int),
                 ('instance_classes', C.c_int), ('grouping', NS.GroupingCfg), ('cls_score_thr', C.c_float),
-                ('mask_score_thr', C.c_float), ('min_npoint', C.c_int), ('want_instances', C.c_int)]
+                ('mask_score_thr', C.c_float), ('min_npoint', C.c_int), ('want_instances', C.c_int),
+                ('with_pyramid', C.c_int), ('with_octree', C.c_int), ('pp_radius', C.c_double),
+                ('pp_base_size', C.c_double)]
 
 
 class ScanInput(C.Structure):     # sg_scan_input
@@ -161,9 +163,14 @@ class ScanForward:
             return False
         g = model.grouping_cfg
         n_seg = model.semantic_classes - len(set(_cfg(g, 'ignore_classes')))
-        if (_cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False) or not 0 < n_seg <= 32
-                or _cfg(model.instance_voxel_cfg, 'rand_quantize', False)):
+        if not 0 < n_seg <= 32 or _cfg(model.instance_voxel_cfg, 'rand_quantize', False):
             return False
+        if _cfg(g, 'with_pyramid', False) or _cfg(g, 'with_octree', False):
+            # SoftGroup++: the per-class loop in C (sg_scan_grouping_pp) carries the reference's get_level
+            # thresholds; a model whose get_level was replaced keeps the staged path
+            if not (model.use_native_grouping_pp and 'get_level' not in model.__dict__
+                    and type(model).get_level.__qualname__ == 'SoftGroup.get_level'):
+                return False
         return model.channels in (16, 32) and model.semantic_classes <= 32
 
     def _heads(self, model):
@@ -231,6 +238,9 @@ class ScanForward:
                 gc.n_seg, gc.seg_class, gc.seg_thr = cls32.numel(), cls32.data_ptr(), seg_thr.data_ptr()
                 gc.score_thr, gc.min_npoint, gc.radius = _cfg(g, 'score_thr'), _cfg(t, 'min_npoint'), _cfg(g, 'radius')
                 gc.voxel_scale, gc.voxel_shape = _cfg(v, 'scale'), _cfg(v, 'spatial_shape')
+                d.with_pyramid = int(bool(_cfg(g, 'with_pyramid', False)))
+                d.with_octree = int(bool(_cfg(g, 'with_octree', False)))
+                d.pp_radius, d.pp_base_size = float(_cfg(g, 'radius')), float(_cfg(g, 'pyramid_base_size', 0.02))
                 d.cls_score_thr, d.mask_score_thr = _cfg(t, 'cls_score_thr'), _cfg(t, 'mask_score_thr')
                 d.min_npoint = _cfg(t, 'min_npoint')
             torch.cuda.current_stream().synchronize()      # (BN affines just made on this stream; once per key)
