@@ -23,6 +23,7 @@
 // for a slot for 0.2 ms (profiles/r05_kernel_stats.csv: select_scan_kernel min 20.6 / max 230 us).
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 
 #include <map>
 #include <mutex>
@@ -203,7 +204,7 @@ struct ScanStream {
   hipStream_t copy = nullptr;
   hipEvent_t packed = nullptr, copied = nullptr, backbone_done = nullptr;
 };
-// Backbone token (SG_SCAN_TOKEN=1; off by default until measured): with several scans in flight on one
+// Backbone token: with several scans in flight on one
 // device (one host thread and stream each) only ONE of them is inside its backbone -- the part of a scan
 // whose kernels fill the whole chip and gain nothing from running next to another backbone -- while the
 // others' grouping / refinement stages (small grids, host read-backs) run in its shadow.  Scans that
@@ -213,17 +214,52 @@ struct ScanStream {
 // mutex is held only while the backbone is being enqueued, nobody blocks on the device.
 static std::mutex g_backbone_mu[16];
 static hipEvent_t g_backbone_last[16];        // event behind the latest backbone enqueued on the device (under the mutex)
+// Form 4 (SG_SCAN_TOKEN=4): like form 1 with SG_SCAN_TOKEN_PERMITS (default 2) backbones at a time -- a counting
+// semaphore instead of the mutex.
+struct BackboneSem {
+  std::mutex m;
+  std::condition_variable cv;
+  int in_use = 0;
+};
+static BackboneSem g_backbone_sem[16];
+static int backbone_permits() {
+  static const int p = getenv("SG_SCAN_TOKEN_PERMITS") ? atoi(getenv("SG_SCAN_TOKEN_PERMITS")) : 2;
+  return p < 1 ? 1 : p;
+}
 struct BackboneToken {
   int dev;
   hipStream_t stream;
   std::unique_lock<std::mutex> lock;
   bool taken = false;
+  bool sem = false;      // form 4: a permit of g_backbone_sem instead of the mutex
 };
 static void backbone_token_take(void *ctx) {      // (sg_unet_forward's pre-conv hook)
   BackboneToken *t = static_cast<BackboneToken *>(ctx);
+  if (t->sem) {
+    BackboneSem &s = g_backbone_sem[t->dev];
+    std::unique_lock<std::mutex> g(s.m);
+    s.cv.wait(g, [&] { return s.in_use < backbone_permits(); });
+    ++s.in_use;
+    t->taken = true;
+    return;
+  }
   t->lock = std::unique_lock<std::mutex>(g_backbone_mu[t->dev]);
   t->taken = true;
   if (g_backbone_last[t->dev] != nullptr) hipStreamWaitEvent(t->stream, g_backbone_last[t->dev], 0);
+}
+static void backbone_token_give(BackboneToken *t) {
+  if (!t->taken) return;
+  if (t->sem) {
+    BackboneSem &s = g_backbone_sem[t->dev];
+    {
+      std::lock_guard<std::mutex> g(s.m);
+      --s.in_use;
+    }
+    s.cv.notify_one();
+  } else {
+    t->lock.unlock();
+  }
+  t->taken = false;
 }
 static std::mutex g_scan_mu;
 static std::map<std::pair<int, hipStream_t>, ScanStream> g_scan_streams;
@@ -462,7 +498,11 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
   res->semantic_preds = ar.at(preds);
 
   // ---- 1. voxel feature pooling, backbone, point-wise heads, softmax
-  static const int token_env = getenv("SG_SCAN_TOKEN") ? atoi(getenv("SG_SCAN_TOKEN")) : 0;
+  // (default: form 4, two backbones at a time -- 2.66-2.83 ms/scan, median 2.70, against 2.74-3.04, median 2.81,
+  //  without a token over six interleaved runs of the bench's default region; 3.28-3.54 against 3.33-3.49 at 20 steps;
+  //  three permits: no gain; one permit, form 1: 2.70-2.85 but outliers of 4.1 / 4.6 at 20 steps.
+  //  profiles/r06_token_matrix.txt.  SG_SCAN_TOKEN=0: off)
+  static const int token_env = getenv("SG_SCAN_TOKEN") ? atoi(getenv("SG_SCAN_TOKEN")) : 4;
   int token_mode = 0;
   int dev = 0;
   if (token_env != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
@@ -474,11 +514,16 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
   const bool use_token = token_mode == 3;       // (3: host-held from before the index build, the first form measured)
   std::unique_lock<std::mutex> token;
   if (use_token) token = std::unique_lock<std::mutex>(g_backbone_mu[dev]);
-  BackboneToken bt{dev, stream, {}, false};
+  BackboneToken bt{dev, stream, {}, false, token_mode == 4};
   struct TokenHookScope {      // (the hook is cleared by sg_unet_forward when it runs; here for the error paths before that)
-    ~TokenHookScope() { t_unet_conv_hook = nullptr; t_unet_conv_ctx = nullptr; }
-  } token_hook_scope;
-  if (token_mode == 1 || token_mode == 2) {
+    BackboneToken &t;
+    ~TokenHookScope() {
+      t_unet_conv_hook = nullptr;
+      t_unet_conv_ctx = nullptr;
+      if (t.sem) backbone_token_give(&t);      // (an error return between the hook and the hand-back below)
+    }
+  } token_hook_scope{bt};
+  if (token_mode == 1 || token_mode == 2 || token_mode == 4) {
     t_unet_conv_hook = backbone_token_take;
     t_unet_conv_ctx = &bt;
   }
@@ -509,11 +554,10 @@ int sg_scan_forward(const sg_scan_desc *d, const sg_scan_input *in, void *arena,
   SG_TRY_(check_launch(kWhat));
   if (bt.taken) {       // behind this point of the stream the next scan's convolutions may run
     if (hipEventRecord(ss->backbone_done, stream) == hipSuccess) {
-      g_backbone_last[dev] = ss->backbone_done;
-      if (token_mode == 1) hipEventSynchronize(ss->backbone_done);      // form 1: the host holds the token until then
+      if (!bt.sem) g_backbone_last[dev] = ss->backbone_done;
+      if (token_mode == 1 || token_mode == 4) hipEventSynchronize(ss->backbone_done);      // forms 1, 4: the host holds the token until then
     }
-    bt.lock.unlock();
-    bt.taken = false;
+    backbone_token_give(&bt);
   }
   DenseCopy dc{ss, stream, dense_dev, host_dense, dense_total, false, false};
   struct DenseGuard {      // no return leaves a copy into the caller's host block in flight

@@ -2,14 +2,17 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-F=$OUT/r06z_driver_shape.txt
+F=$OUT/r06z_token_ab.txt
 : > $F
 B="python $R/bench.py --no-cpu-baseline --no-legs --no-roofline"
-for i in 1 2 3 4 5 6 7 8; do
-  $B --steps 20 --warmup 5 2>&1 | python -c "
+one() {
+  "$@" 2>&1 | python -c "
 import json,sys
 lines=sys.stdin.read().strip().splitlines()
 d=json.loads(lines[-1])
-print('  ms_per_step', d['ms_per_step'], 'windows', d.get('ms_per_step_windows'), 'latency', d.get('latency_ms'))" >> $F
+print(d['ms_per_step'], d.get('ms_per_step_windows'))"
+}
+for i in 1 2 3 4 5 6; do
+  for t in 0 4; do echo "160 steps token $t: $(SG_SCAN_TOKEN=$t one $B)" >> $F; done
 done
 echo done >> $F
