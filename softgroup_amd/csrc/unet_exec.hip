@@ -229,12 +229,18 @@ int unet_build_index(const char *who, int L, const int32_t *indices, int num_row
                "%s: event creation failed", who);
     st.ready = true;
   }
-  hipStream_t istream = st.istream;
+  // The index build runs on the CALLER's stream (since the end of round 6).  Until then it had a stream of its own per
+  // caller stream, so that the host's wait for the row counts did not wait for whatever the caller had queued; with the
+  // scan as one C call nothing is queued there, and one stream less per scan worker measured 2.42-2.57 against 2.66-2.81
+  // ms/scan with five scans in flight (five interleaved pairs), 3.20-3.48 against 3.38-3.91 in the 20-step region and
+  // 4.49 / 4.57 against 4.61 / 4.61 ms for one scan (profiles/r06_index_stream.txt).  SG_UNET_INDEX_STREAM=1: as before.
+  static const bool own_istream = getenv("SG_UNET_INDEX_STREAM") && atoi(getenv("SG_UNET_INDEX_STREAM")) != 0;
+  hipStream_t istream = own_istream ? st.istream : as_stream(stream);
   sg_stream_t is = reinterpret_cast<sg_stream_t>(istream);
   // the index stream starts where the caller's stream is now: the coordinates are ready, and the
   // previous forward's convolutions no longer read the tables about to be overwritten
-  if (hipEventRecord(st.ev_start, as_stream(stream)) != hipSuccess ||
-      hipStreamWaitEvent(istream, st.ev_start, 0) != hipSuccess) {
+  if (own_istream && (hipEventRecord(st.ev_start, as_stream(stream)) != hipSuccess ||
+                      hipStreamWaitEvent(istream, st.ev_start, 0) != hipSuccess)) {
     set_error("%s: event record/wait failed", who);
     return SG_ERR_LAUNCH;
   }
@@ -321,8 +327,8 @@ int unet_build_index(const char *who, int L, const int32_t *indices, int num_row
     ident_plan_kernel<<<dim3(grid_for(num_rows, 256), L - 1), 256, 0, istream>>>(segs);
   }
 #undef SG_IALLOC
-  if (hipEventRecord(st.ev_index, istream) != hipSuccess ||
-      hipStreamWaitEvent(as_stream(stream), st.ev_index, 0) != hipSuccess) {
+  if (own_istream && (hipEventRecord(st.ev_index, istream) != hipSuccess ||
+                      hipStreamWaitEvent(as_stream(stream), st.ev_index, 0) != hipSuccess)) {
     set_error("%s: event record/wait failed", who);
     return SG_ERR_LAUNCH;
   }
