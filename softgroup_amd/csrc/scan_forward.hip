@@ -313,19 +313,22 @@ static void start_dense_copy(void *ctx) {
   d->issued = true;
   // the copy waits for the point where the caller's stream is NOW (the packed block is long complete)
   static const int d2h_wgs = getenv("SG_SCAN_D2H_WGS") ? atoi(getenv("SG_SCAN_D2H_WGS")) : 0;
-  if (hipEventRecord(d->ss->packed, d->main) != hipSuccess ||
-      hipStreamWaitEvent(d->ss->copy, d->ss->packed, 0) != hipSuccess) {
+  // (SG_SCAN_COPY_STREAM=0, developer A/B: the copy on the caller's stream, in line, instead of the side stream)
+  static const bool side = !(getenv("SG_SCAN_COPY_STREAM") && atoi(getenv("SG_SCAN_COPY_STREAM")) == 0);
+  hipStream_t cs = side ? d->ss->copy : d->main;
+  if (side && (hipEventRecord(d->ss->packed, d->main) != hipSuccess ||
+               hipStreamWaitEvent(d->ss->copy, d->ss->packed, 0) != hipSuccess)) {
     d->failed = true;
     return;
   }
   if (d2h_wgs > 0 && d->bytes % 16 == 0) {
-    d2h_copy_kernel<<<d2h_wgs, 256, 0, d->ss->copy>>>(static_cast<const u32x4 *>(d->dev_block),
-                                                      static_cast<u32x4 *>(d->host_block), d->bytes / 16);
+    d2h_copy_kernel<<<d2h_wgs, 256, 0, cs>>>(static_cast<const u32x4 *>(d->dev_block),
+                                             static_cast<u32x4 *>(d->host_block), d->bytes / 16);
     if (hipGetLastError() != hipSuccess) d->failed = true;
-  } else if (hipMemcpyAsync(d->host_block, d->dev_block, d->bytes, hipMemcpyDeviceToHost, d->ss->copy) != hipSuccess) {
+  } else if (hipMemcpyAsync(d->host_block, d->dev_block, d->bytes, hipMemcpyDeviceToHost, cs) != hipSuccess) {
     d->failed = true;
   }
-  if (hipEventRecord(d->ss->copied, d->ss->copy) != hipSuccess) d->failed = true;
+  if (hipEventRecord(d->ss->copied, cs) != hipSuccess) d->failed = true;
 }
 
 static Mlp2 as_mlp(const sg_mlp2 &m) { return Mlp2{m.w1, m.b1, m.bn_scale, m.bn_shift, m.w2, m.b2, m.out}; }

@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-F=$OUT/r06z_index_stream.txt
+F=$OUT/r06z_copy_stream.txt
 : > $F
 B="python $R/bench.py --no-cpu-baseline --no-legs --no-roofline"
 one() {
@@ -13,9 +13,9 @@ d=json.loads(lines[-1])
 print(d['ms_per_step'], d.get('ms_per_step_windows'))"
 }
 for i in 1 2 3 4 5; do
-  for t in 0 1; do echo "160 steps index stream $t: $(SG_UNET_INDEX_STREAM=$t one $B)" >> $F; done
+  for t in 0 1; do echo "160 steps copy stream $t: $(SG_SCAN_COPY_STREAM=$t one $B)" >> $F; done
 done
 for i in 1 2 3 4; do
-  for t in 0 1; do echo "20 steps index stream $t: $(SG_UNET_INDEX_STREAM=$t one $B --steps 20 --warmup 5)" >> $F; done
+  for t in 0 1; do echo "20 steps copy stream $t: $(SG_SCAN_COPY_STREAM=$t one $B --steps 20 --warmup 5)" >> $F; done
 done
 echo done >> $F
