@@ -58,9 +58,9 @@ def parse():
     ap.add_argument('--scenes', type=int, default=4,
                     help='distinct pre-built scenes the timed region cycles through')
     ap.add_argument('--contexts', type=int, default=0,
-                    help='scans in flight in the timed region; 0 = 3 for regions of up to 40 steps, 5 beyond '
-                         '(a short region is one pipeline fill and one drain, which cost more with more scans '
-                         'in flight: profiles/README.md, round 4)')
+                    help='scans in flight in the timed region; 0 = 10 (with one stream less per scan worker and two '
+                         'backbone permits, 8-12 in flight beat 3-5 in the 20-step region and in the 160-step one: '
+                         'profiles/r06_token_matrix.txt, end of round 6)')
     ap.add_argument('--switch-interval-us', type=int, default=0,
                     help='sys.setswitchinterval for the process (0 = leave CPython\'s 5 ms)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -642,7 +642,7 @@ def measurement_legs(args, model, batch, xyz, rgb, inst):
         del rets
         # ... and the headline's shape -- scans in flight on the worker streams -- fed from pinned HOST scenes by the
         # loader thread instead of from HBM-resident batches: what a serving loop over a DataLoader sees
-        in_flight, _ = host_thread_plan(5, 1)
+        in_flight, _ = host_thread_plan(max(1, args.contexts), 1)
         n_loaders = int(os.environ.get('SG_BENCH_LOADERS', '1'))
         model.scan_contexts = in_flight
         try:
@@ -868,7 +868,7 @@ def stub_main(args, rank, world, devices):
 def main():
     args = parse()
     if args.contexts <= 0:
-        args.contexts = 3 if args.steps <= 40 else 5
+        args.contexts = 10
     if args.switch_interval_us > 0:
         sys.setswitchinterval(args.switch_interval_us * 1e-6)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -168,6 +168,10 @@ __global__ void __launch_bounds__(256) ident_plan_kernel(IdentSegs s) {
 // ---- runtime state per (device, caller's stream): callers that run scans concurrently on
 //      several streams (one host thread each) get an index stream of their own and never wait for
 //      each other; calls on the same stream are serialised by the state's mutex
+static bool index_stream_on() {      // SG_UNET_INDEX_STREAM=1: the index build on a stream of its own (see unet_build_index)
+  static const bool on = getenv("SG_UNET_INDEX_STREAM") && atoi(getenv("SG_UNET_INDEX_STREAM")) != 0;
+  return on;
+}
 struct StreamState {
   std::mutex mu;
   int32_t *host_rows = nullptr;     // pinned [SG_PYRAMID_MAX_LEVELS]
@@ -192,8 +196,10 @@ void unet_release_stream(int dev, hipStream_t stream) {
   {
     std::lock_guard<std::mutex> g(st->mu);      // (no forward of that stream is inside the build)
     if (st->ready) {
-      hipStreamSynchronize(st->istream);
-      hipStreamDestroy(st->istream);
+      if (st->istream != nullptr) {
+        hipStreamSynchronize(st->istream);
+        hipStreamDestroy(st->istream);
+      }
       hipEventDestroy(st->ev_start);
       hipEventDestroy(st->ev_index);
       hipHostFree(st->host_rows);
@@ -222,7 +228,7 @@ int unet_build_index(const char *who, int L, const int32_t *indices, int num_row
                "%s: pinned allocation failed", who);
     SG_REQUIRE(hipMalloc(reinterpret_cast<void **>(&st.dev_rows), SG_PYRAMID_MAX_LEVELS * 4) == hipSuccess,
                "%s: device allocation failed", who);
-    SG_REQUIRE(hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
+    SG_REQUIRE(!index_stream_on() || hipStreamCreateWithFlags(&st.istream, hipStreamNonBlocking) == hipSuccess,
                "%s: stream creation failed", who);
     SG_REQUIRE(hipEventCreateWithFlags(&st.ev_start, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&st.ev_index, hipEventDisableTiming) == hipSuccess,
@@ -234,7 +240,7 @@ int unet_build_index(const char *who, int L, const int32_t *indices, int num_row
   // scan as one C call nothing is queued there, and one stream less per scan worker measured 2.42-2.57 against 2.66-2.81
   // ms/scan with five scans in flight (five interleaved pairs), 3.20-3.48 against 3.38-3.91 in the 20-step region and
   // 4.49 / 4.57 against 4.61 / 4.61 ms for one scan (profiles/r06_index_stream.txt).  SG_UNET_INDEX_STREAM=1: as before.
-  static const bool own_istream = getenv("SG_UNET_INDEX_STREAM") && atoi(getenv("SG_UNET_INDEX_STREAM")) != 0;
+  const bool own_istream = index_stream_on();
   hipStream_t istream = own_istream ? st.istream : as_stream(stream);
   sg_stream_t is = reinterpret_cast<sg_stream_t>(istream);
   // the index stream starts where the caller's stream is now: the coordinates are ready, and the

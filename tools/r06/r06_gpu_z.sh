@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-F=$OUT/r06z_copy_stream.txt
+F=$OUT/r06z_pinned.txt
 : > $F
 B="python $R/bench.py --no-cpu-baseline --no-legs --no-roofline"
 one() {
@@ -12,10 +12,13 @@ lines=sys.stdin.read().strip().splitlines()
 d=json.loads(lines[-1])
 print(d['ms_per_step'], d.get('ms_per_step_windows'))"
 }
-for i in 1 2 3 4 5; do
-  for t in 0 1; do echo "160 steps copy stream $t: $(SG_SCAN_COPY_STREAM=$t one $B)" >> $F; done
+for i in 1 2 3 4; do
+  echo "160 steps pinned 256: $(one $B)" >> $F
+  echo "160 steps pinned 512: $(SG_PINNED_RESULTS_MB=512 one $B)" >> $F
 done
 for i in 1 2 3 4; do
-  for t in 0 1; do echo "20 steps copy stream $t: $(SG_SCAN_COPY_STREAM=$t one $B --steps 20 --warmup 5)" >> $F; done
+  echo "20 steps pinned 256: $(one $B --steps 20 --warmup 5)" >> $F
+  echo "20 steps pinned 512: $(SG_PINNED_RESULTS_MB=512 one $B --steps 20 --warmup 5)" >> $F
 done
+SG_BENCH_DIAG=1 $B 2>&1 | grep "bench diag" | cut -c1-200 >> $F
 echo done >> $F
