@@ -50,8 +50,8 @@ const char *sg_last_error(void);
 /* name/CU count/clock of the current device, for bench records */
 int sg_device_info(char *name_host, int name_cap, int *num_cu_host, int *clock_khz_host);
 
-/* Runtime state the library keeps per (device, caller stream) -- the executors' pinned read-back words, events
- * and pinned read-back words, the conv launches' arrival-counter and ticket pools (8 MB of device
+/* Runtime state the library keeps per (device, caller stream) -- the executors' events and pinned read-back
+ * words, the conv launches' arrival-counter and ticket pools (8 MB of device
  * memory) -- is created on a stream's first use and normally lives as long as the process.  A caller
  * that retires a stream (a pool of scan threads being resized) calls this once the stream is idle and
  * before destroying it, on the stream's device.  No counterpart in the reference (spconv keeps its
