@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-F=$OUT/r06z_pinned.txt
+F=$OUT/r06z_shared_copy.txt
 : > $F
 B="python $R/bench.py --no-cpu-baseline --no-legs --no-roofline"
 one() {
@@ -12,13 +12,10 @@ lines=sys.stdin.read().strip().splitlines()
 d=json.loads(lines[-1])
 print(d['ms_per_step'], d.get('ms_per_step_windows'))"
 }
-for i in 1 2 3 4; do
-  echo "160 steps pinned 256: $(one $B)" >> $F
-  echo "160 steps pinned 512: $(SG_PINNED_RESULTS_MB=512 one $B)" >> $F
+for i in 1 2 3 4 5; do
+  for t in 0 1; do echo "160 steps shared copy $t: $(SG_SCAN_SHARED_COPY=$t one $B)" >> $F; done
 done
 for i in 1 2 3 4; do
-  echo "20 steps pinned 256: $(one $B --steps 20 --warmup 5)" >> $F
-  echo "20 steps pinned 512: $(SG_PINNED_RESULTS_MB=512 one $B --steps 20 --warmup 5)" >> $F
+  for t in 0 1; do echo "20 steps shared copy $t: $(SG_SCAN_SHARED_COPY=$t one $B --steps 20 --warmup 5)" >> $F; done
 done
-SG_BENCH_DIAG=1 $B 2>&1 | grep "bench diag" | cut -c1-200 >> $F
 echo done >> $F
